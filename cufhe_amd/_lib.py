@@ -1,0 +1,84 @@
+"""ctypes binding of libcufhe_amd.so (the C ABI of include/cufhe_amd.h).
+
+The library is the product; there is no CPU fallback.  Importing this module when the
+shared object has not been built raises ImportError with the build command.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcufhe_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first "
+        "(python -c 'import __graft_entry__ as g; g.build()' at the repo root)")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_void = ctypes.c_void_p
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in
+                ("n", "N", "nbit", "k", "l", "Bgbit", "t", "basebit", "mu", "lvl0_words", "lvl1_words")] + \
+               [(n, ctypes.c_uint64) for n in ("bk_words", "ksk_words", "bk_ntt_bytes")]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [("blind_rotate_ms", ctypes.c_double), ("blind_rotate_launches", ctypes.c_uint64),
+                ("blind_rotations", ctypes.c_uint64), ("keyswitch_ms", ctypes.c_double),
+                ("keyswitch_launches", ctypes.c_uint64), ("keyswitches", ctypes.c_uint64)]
+
+
+# every symbol include/cufhe_amd.h declares, with its signature
+SIGNATURES = {
+    "cufhe_amd_get_params": (ctypes.c_int, [ctypes.POINTER(Params)]),
+    "cufhe_amd_last_error": (ctypes.c_char_p, []),
+    "cufhe_amd_set_gpu_num": (ctypes.c_int, [ctypes.c_int]),
+    "cufhe_amd_get_gpu_num": (ctypes.c_int, []),
+    "cufhe_amd_device_count": (ctypes.c_int, []),
+    "cufhe_amd_initialize_ntt": (ctypes.c_int, []),
+    "cufhe_amd_initialize": (ctypes.c_int, [c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
+    "cufhe_amd_cleanup": (ctypes.c_int, []),
+    "cufhe_amd_synchronize": (ctypes.c_int, []),
+    "cufhe_amd_stream_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_void)]),
+    "cufhe_amd_stream_destroy": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_stream_synchronize": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_malloc": (ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(c_void)]),
+    "cufhe_amd_free": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_host_register": (ctypes.c_int, [c_void, ctypes.c_size_t]),
+    "cufhe_amd_host_unregister": (ctypes.c_int, [c_void]),
+    "cufhe_amd_memcpy_h2d": (ctypes.c_int, [ctypes.c_int, c_void, c_void, c_void, ctypes.c_size_t]),
+    "cufhe_amd_memcpy_d2h": (ctypes.c_int, [ctypes.c_int, c_void, c_void, c_void, ctypes.c_size_t]),
+    "cufhe_amd_gate": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "cufhe_amd_gate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_size_t, c_void, ctypes.c_int,
+                                            c_void, c_void, c_void, c_void, ctypes.c_size_t]),
+    "cufhe_amd_gate_list": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_size_t, c_void,
+                                           c_void, c_void, c_void, c_void]),
+    "cufhe_amd_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
+    "cufhe_amd_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_polymul_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
+    "cufhe_amd_profile_enable": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "cufhe_amd_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(Profile), ctypes.c_int]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = the .so is stale: rebuild
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class CufheAmdError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Raise on a negative status, mirroring the reference's abort-on-error
+    (include/details/error_gpu.cuh:40-60) as an exception."""
+    if rc < 0:
+        raise CufheAmdError(f"cufhe_amd error {rc}: {lib.cufhe_amd_last_error().decode()}")
+    return rc

@@ -1,0 +1,245 @@
+"""Python mirror of the cuFHE host API for the gate path, over the C ABI.
+
+Names, argument order and completion semantics follow include/cufhe_gpu.cuh of the
+reference (SetGPUNum / Initialize / CleanUp / Synchronize / Stream / StreamQuery / Ctxt /
+And ... NMux, Not, Copy and the g-prefixed device-resident variants,
+/root/reference/include/cufhe_gpu.cuh:54-313, src/cufhe_gates_gpu.cu:148-665).
+Everything here is plumbing: the arithmetic runs in libcufhe_amd.so.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check, Params, Profile
+
+# op codes (include/cufhe_amd.h)
+NAND, NOR, XNOR, AND, OR, XOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NMUX, NOT, COPY = range(14)
+OP_NAMES = ["NAND", "NOR", "XNOR", "AND", "OR", "XOR", "ANDNY", "ANDYN", "ORNY", "ORYN",
+            "MUX", "NMUX", "NOT", "COPY"]
+
+
+def params():
+    p = Params()
+    check(lib.cufhe_amd_get_params(ctypes.byref(p)))
+    return p
+
+
+PARAMS = params()
+LVL_WORDS = (PARAMS.lvl0_words, PARAMS.lvl1_words)
+
+_stream_count = 0          # `streamCount`, src/cufhe_gates_gpu.cu:36
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if isinstance(a, np.ndarray) else a
+
+
+def SetGPUNum(gpu_num):
+    check(lib.cufhe_amd_set_gpu_num(int(gpu_num)))
+
+
+def GetGPUNum():
+    return lib.cufhe_amd_get_gpu_num()
+
+
+def DeviceCount():
+    return lib.cufhe_amd_device_count()
+
+
+def Initialize(bk=None, ksk=None):
+    """Initialize() / Initialize(ek): bk, ksk are the torus-domain keys as uint32 arrays."""
+    if bk is None:
+        check(lib.cufhe_amd_initialize_ntt())
+        return
+    bk = np.ascontiguousarray(bk, dtype=np.uint32).ravel()
+    ksk = np.ascontiguousarray(ksk, dtype=np.uint32).ravel()
+    check(lib.cufhe_amd_initialize(_ptr(bk), bk.size, _ptr(ksk), ksk.size))
+
+
+def CleanUp():
+    check(lib.cufhe_amd_cleanup())
+
+
+def Synchronize():
+    check(lib.cufhe_amd_synchronize())
+
+
+class Stream:
+    """class Stream, include/cufhe_gpu.cuh:152-189: default ctor round-robins devices,
+    Create() makes a non-blocking stream, the destructor does not destroy it."""
+
+    def __init__(self, device_id=None):
+        global _stream_count
+        self._device_id = (_stream_count % GetGPUNum()) if device_id is None else int(device_id)
+        _stream_count += 1
+        self._st = ctypes.c_void_p(None)
+
+    def Create(self):
+        check(lib.cufhe_amd_stream_create(self._device_id, ctypes.byref(self._st)))
+
+    def Destroy(self):
+        check(lib.cufhe_amd_stream_destroy(self._device_id, self._st))
+        self._st = ctypes.c_void_p(None)
+
+    def st(self):
+        return self._st
+
+    def device_id(self):
+        return self._device_id
+
+
+def StreamQuery(st):
+    return check(lib.cufhe_amd_stream_query(st.device_id(), st.st())) == 1
+
+
+class DeviceBuffer:
+    """`words` uint32 words of device memory on one GPU."""
+
+    def __init__(self, words, device=0):
+        self.words, self.device = int(words), int(device)
+        p = ctypes.c_void_p()
+        check(lib.cufhe_amd_malloc(self.device, self.words * 4, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host, stream=None):
+        host = np.ascontiguousarray(host, dtype=np.uint32).ravel()
+        assert host.size <= self.words
+        check(lib.cufhe_amd_memcpy_h2d(self.device, stream, self.ptr, _ptr(host), host.size * 4))
+        check(lib.cufhe_amd_stream_synchronize(self.device, stream))
+        return self
+
+    def download(self, words=None, stream=None):
+        out = np.empty(self.words if words is None else words, dtype=np.uint32)
+        check(lib.cufhe_amd_memcpy_d2h(self.device, stream, _ptr(out), self.ptr, out.size * 4))
+        check(lib.cufhe_amd_stream_synchronize(self.device, stream))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib.cufhe_amd_free(self.device, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ctxt:
+    """template<class P> struct Ctxt, include/cufhe_gpu.cuh:102-121: a pinned host TLWE
+    (`tlwehost`) plus one device buffer per GPU (`tlwedevices`).  level 0 = lvl0param,
+    level 1 = lvl1param."""
+
+    def __init__(self, level=0):
+        self.level = int(level)
+        self.tlwehost = np.zeros(LVL_WORDS[self.level], dtype=np.uint32)
+        check(lib.cufhe_amd_host_register(_ptr(self.tlwehost), self.tlwehost.nbytes))
+        self.tlwedevices = [DeviceBuffer(LVL_WORDS[self.level], d) for d in range(GetGPUNum())]
+
+    def __del__(self):
+        try:
+            lib.cufhe_amd_host_unregister(_ptr(self.tlwehost))
+        except Exception:
+            pass
+
+
+def CtxtCopyH2D(c, st):
+    check(lib.cufhe_amd_memcpy_h2d(st.device_id(), st.st(), c.tlwedevices[st.device_id()].ptr,
+                                   _ptr(c.tlwehost), c.tlwehost.nbytes))
+
+
+def CtxtCopyD2H(c, st):
+    check(lib.cufhe_amd_memcpy_d2h(st.device_id(), st.st(), _ptr(c.tlwehost),
+                                   c.tlwedevices[st.device_id()].ptr, c.tlwehost.nbytes))
+
+
+def CopyOnHost(out, inp):
+    out.tlwehost[:] = inp.tlwehost
+
+
+def _dev(c, st):
+    return c.tlwedevices[st.device_id()].ptr
+
+
+def _gate(op, copying, out, ins, st):
+    if copying:                                   # src/cufhe_gates_gpu.cu:148-158
+        for c in ins:
+            CtxtCopyH2D(c, st)
+    ptrs = [_dev(c, st) for c in ins] + [None] * (3 - len(ins))
+    check(lib.cufhe_amd_gate(st.device_id(), st.st(), op, out.level, _dev(out, st), *ptrs))
+    if copying:
+        CtxtCopyD2H(out, st)
+
+
+def _make2(op, copying):
+    def f(out, in0, in1, st):
+        _gate(op, copying, out, [in0, in1], st)
+    return f
+
+
+def _make1(op, copying):
+    def f(out, in0, st):
+        _gate(op, copying, out, [in0], st)
+    return f
+
+
+def _make3(op, copying):
+    def f(out, inc, in1, in0, st):               # Mux(out, inc, in1, in0, st)
+        _gate(op, copying, out, [inc, in1, in0], st)
+    return f
+
+
+And, gAnd = _make2(AND, True), _make2(AND, False)
+AndYN, gAndYN = _make2(ANDYN, True), _make2(ANDYN, False)
+AndNY, gAndNY = _make2(ANDNY, True), _make2(ANDNY, False)
+Or, gOr = _make2(OR, True), _make2(OR, False)
+OrYN, gOrYN = _make2(ORYN, True), _make2(ORYN, False)
+OrNY, gOrNY = _make2(ORNY, True), _make2(ORNY, False)
+Nand, gNand = _make2(NAND, True), _make2(NAND, False)
+Nor, gNor = _make2(NOR, True), _make2(NOR, False)
+Xor, gXor = _make2(XOR, True), _make2(XOR, False)
+Xnor, gXnor = _make2(XNOR, True), _make2(XNOR, False)
+Not, gNot = _make1(NOT, True), _make1(NOT, False)
+Copy, gCopy = _make1(COPY, True), _make1(COPY, False)
+Mux, gMux = _make3(MUX, True), _make3(MUX, False)
+NMux, gNMux = _make3(NMUX, True), _make3(NMUX, False)
+
+
+# ---- native batched entry points (what bench.py and the parity tests drive) ----
+def gate_batch(ops, level, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
+    """ops: one op code or an int array of `count` codes; operands are DeviceBuffers holding
+    `count` contiguous ciphertexts."""
+    words = LVL_WORDS[level]
+    if count is None:
+        count = out.words // words
+    if np.isscalar(ops):
+        ops_arr, stride = np.array([ops], dtype=np.int32), 0
+    else:
+        ops_arr, stride = np.ascontiguousarray(ops, dtype=np.int32), 1
+        assert ops_arr.size >= count
+    check(lib.cufhe_amd_gate_batch(device, stream, level, count, _ptr(ops_arr), stride, out.ptr, in0.ptr,
+                                   in1.ptr if in1 is not None else None,
+                                   in2.ptr if in2 is not None else None, words))
+
+
+def blind_rotate_batch(tlwe0, acc, count, steps=-1, device=0, stream=None):
+    check(lib.cufhe_amd_blind_rotate_batch(device, stream, count, tlwe0.ptr, acc.ptr, steps))
+
+
+def keyswitch_batch(tlwe1, tlwe0, count, device=0, stream=None):
+    check(lib.cufhe_amd_keyswitch_batch(device, stream, count, tlwe1.ptr, tlwe0.ptr))
+
+
+def polymul_batch(a, b, res, count, device=0, stream=None):
+    check(lib.cufhe_amd_polymul_batch(device, stream, count, a.ptr, b.ptr, res.ptr))
+
+
+def profile_enable(on=True, device=0):
+    check(lib.cufhe_amd_profile_enable(device, 1 if on else 0))
+
+
+def profile_get(device=0, reset=True):
+    p = Profile()
+    check(lib.cufhe_amd_profile_get(device, ctypes.byref(p), 1 if reset else 0))
+    return p

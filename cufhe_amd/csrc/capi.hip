@@ -1,0 +1,654 @@
+// capi.hip -- implementation of the C ABI declared in include/cufhe_amd.h.
+// Host side of the gate path: device/key management (reference: src/cufhe_gates_gpu.cu:38-65,
+// src/bootstrap_gpu.cu:97-155, src/keyswitch_gpu.cu:6-24) and the launch sequences that
+// replace the per-gate launchers of src/bootstrap_gpu.cu:834-1292.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cufhe_amd.h"
+#include "kernels.hip.h"
+
+using namespace cufhe_amd;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                std::to_string(__LINE__) + ")");                               \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; uint64_t units; };
+
+// Pinned host staging for descriptor uploads.  hipMemcpyAsync from pageable memory may
+// return before the bytes have been read, so descriptors are staged in pinned blocks that
+// are recycled only once the event recorded behind their copy has completed.
+struct PinnedBlock { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false; };
+
+// Per-stream device workspace (temporaries + descriptor arrays of one launch sequence).
+// Work on one stream is ordered, so the next sequence on the same stream may overwrite the
+// workspace of the previous one; distinct streams get distinct workspaces.  Grow-only.
+struct Workspace { char* base = nullptr; size_t bytes = 0; };
+
+struct DeviceState {
+    bool ntt_ready = false, keys_ready = false;
+    NttTables* tables = nullptr;
+    double* bk_ntt = nullptr;
+    uint32_t* ksk = nullptr;
+    bool profiling = false;
+    std::vector<EventPair> br_events, ks_events;
+    cufhe_amd_profile prof{};
+    std::deque<PinnedBlock> staging;
+    std::map<hipStream_t, Workspace> workspaces;
+    std::mutex staging_mu;
+    DeviceState() = default;
+    DeviceState(const DeviceState&) {}
+    DeviceState& operator=(const DeviceState&) { return *this; }
+};
+
+int g_gpu_num = 1;
+std::vector<DeviceState> g_dev(1);   // resized only while no device is initialised
+std::mutex g_mu;
+
+// ---- exact host arithmetic for the tables ----
+typedef unsigned __int128 u128;
+uint64_t mulmod_u64(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % fpf::P_U64); }
+uint64_t powmod_u64(uint64_t a, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mulmod_u64(r, a);
+        a = mulmod_u64(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+double balanced(uint64_t v) { return v > fpf::P_U64 / 2 ? -(double)(fpf::P_U64 - v) : (double)v; }
+uint32_t bitrev10(uint32_t x)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 10; i++) r |= ((x >> i) & 1u) << (9 - i);
+    return r;
+}
+double n_inverse_balanced() { return balanced(powmod_u64(kN, fpf::P_U64 - 2)); }
+
+// root[i] = psi^bitrev(i): the reference's table order, src/ntt_gpu/ntt_gpuntt.cu:88-111
+void build_tables(NttTables& t)
+{
+    std::vector<double> fwd(kN), inv(kN);
+    const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
+    for (uint32_t i = 0; i < (uint32_t)kN; i++) {
+        fwd[i] = balanced(powmod_u64(psi, bitrev10(i)));
+        inv[i] = balanced(powmod_u64(psi_inv, bitrev10(i)));
+    }
+    memset(&t, 0, sizeof(t));
+    for (int k = 0; k < 15; k++) {
+        int lvl = 0;
+        while ((2 << lvl) <= k + 1) lvl++;
+        const int j = k + 1 - (1 << lvl);
+        t.tu_fwd[k] = fwd[(1 << lvl) + j];
+        t.tu_inv[k] = inv[(1 << lvl) + j];
+        for (int lam = 0; lam < 16; lam++) {
+            const int idx = (16 << lvl) + (lam << lvl) + j;
+            t.tb_fwd[k * 16 + lam] = fwd[idx];
+            t.tb_inv[k * 16 + lam] = inv[idx];
+        }
+    }
+    for (int k = 0; k < kTcCount; k++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int lam = lane & 15, h = lane >> 4;
+            const int idx = k < 4 ? 256 + ((lam << 4) | (h << 2) | k) : 512 + ((lam << 5) | (h << 3) | (k - 4));
+            t.tc_fwd[k * 64 + lane] = fwd[idx];
+            t.tc_inv[k * 64 + lane] = inv[idx];
+        }
+}
+
+int check_device(int device)
+{
+    if (device < 0 || device >= g_gpu_num) return fail(-1, "device index out of range (SetGPUNum first)");
+    return 0;
+}
+int use_device(int device)
+{
+    if (int rc = check_device(device)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return 0;
+}
+
+int ensure_ntt(int device)
+{
+    DeviceState& s = g_dev[device];
+    if (s.ntt_ready) return 0;
+    HIP_TRY(hipSetDevice(device));
+    NttTables host;
+    build_tables(host);
+    HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
+    HIP_TRY(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
+    s.ntt_ready = true;
+    return 0;
+}
+
+
+struct Scratch {   // bump allocator over the stream's workspace
+    char* cur;
+    char* end;
+    hipStream_t st;
+    int alloc(void** p, size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (cur + bytes > end) return fail(-4, "internal: workspace under-sized");
+        *p = cur;
+        cur += bytes;
+        return 0;
+    }
+};
+
+int open_scratch(DeviceState& s, hipStream_t st, size_t bytes, Scratch* sc)
+{
+    std::lock_guard<std::mutex> lk(s.staging_mu);
+    Workspace& w = s.workspaces[st];
+    if (w.bytes < bytes) {
+        if (w.base) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipFree(w.base));
+            w.base = nullptr; w.bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4 + (1 << 20);
+        HIP_TRY(hipMalloc((void**)&w.base, want));
+        w.bytes = want;
+    }
+    sc->cur = w.base; sc->end = w.base + w.bytes; sc->st = st;
+    return 0;
+}
+
+int acquire_staging(DeviceState& s, size_t bytes, PinnedBlock** out)
+{
+    std::lock_guard<std::mutex> lk(s.staging_mu);
+    for (auto& b : s.staging) {
+        if (b.busy && hipEventQuery(b.done) == hipSuccess) b.busy = false;
+        if (!b.busy && b.bytes >= bytes) { b.busy = true; *out = &b; return 0; }
+    }
+    PinnedBlock nb;
+    nb.bytes = bytes < 65536 ? 65536 : bytes;
+    HIP_TRY(hipHostMalloc(&nb.host, nb.bytes, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&nb.done, hipEventDisableTiming));
+    nb.busy = true;
+    s.staging.push_back(nb);
+    *out = &s.staging.back();
+    return 0;
+}
+
+int upload_descs(DeviceState& s, Scratch& sc, const std::vector<LinDesc>& h, LinDesc** d)
+{
+    *d = nullptr;
+    if (h.empty()) return 0;
+    const size_t bytes = h.size() * sizeof(LinDesc);
+    if (int rc = sc.alloc((void**)d, bytes)) return rc;
+    PinnedBlock* blk = nullptr;
+    if (int rc = acquire_staging(s, bytes, &blk)) return rc;
+    memcpy(blk->host, h.data(), bytes);
+    HIP_TRY(hipMemcpyAsync(*d, blk->host, bytes, hipMemcpyHostToDevice, sc.st));
+    HIP_TRY(hipEventRecord(blk->done, sc.st));
+    return 0;
+}
+
+int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count, int steps, uint32_t* acc_dump)
+{
+    if (count == 0) return 0;
+    EventPair ev{};
+    if (s.profiling) {
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, st));
+    }
+    const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
+    hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
+                       s.bk_ntt, s.tables, steps, acc_dump);
+    HIP_TRY(hipGetLastError());
+    if (s.profiling) {
+        HIP_TRY(hipEventRecord(ev.b, st));
+        ev.units = count;
+        s.br_events.push_back(ev);
+    }
+    return 0;
+}
+int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count)
+{
+    if (count == 0) return 0;
+    EventPair ev{};
+    if (s.profiling) {
+        HIP_TRY(hipEventCreate(&ev.a));
+        HIP_TRY(hipEventCreate(&ev.b));
+        HIP_TRY(hipEventRecord(ev.a, st));
+    }
+    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
+    HIP_TRY(hipGetLastError());
+    if (s.profiling) {
+        HIP_TRY(hipEventRecord(ev.b, st));
+        ev.units = count;
+        s.ks_events.push_back(ev);
+    }
+    return 0;
+}
+int launch_lincomb(hipStream_t st, const LinDesc* d, size_t count, int words)
+{
+    if (count == 0) return 0;
+    const unsigned blocks = (unsigned)(count < 4096 ? count : 4096);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(blocks), dim3(256), 0, st, d, (int)count, words);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// (ca, cb, offset/mu) of the ten two-input gates, src/bootstrap_gpu.cu:424-512,591-679
+const int kGateTab[10][3] = {
+    {-1, -1, 1}, {-1, -1, -1}, {-2, -2, -2}, {1, 1, -1}, {1, 1, 1},
+    {2, 2, 2},   {-1, 1, -1},  {1, -1, -1},  {-1, 1, 1}, {1, -1, 1},
+};
+
+struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1; const uint32_t* in2; };
+
+template <class GetGate>
+int run_gates(int device, void* stream, int level, size_t count, GetGate get)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (level != 0 && level != 1) return fail(-1, "level must be 0 or 1");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t negmu = 0u - kMu;
+
+    std::vector<LinDesc> rot, ks, lin;
+    rot.reserve(count * 2); ks.reserve(count * 2); lin.reserve(count);
+    // first pass: count temporaries
+    size_t nrot = 0;
+    for (size_t g = 0; g < count; g++) {
+        const int op = get(g).op;
+        if (op < 0 || op >= CUFHE_AMD_NUM_OPS) return fail(-1, "unknown gate op");
+        if (op == CUFHE_AMD_MUX || op == CUFHE_AMD_NMUX) nrot += 2;
+        else if (op < CUFHE_AMD_MUX) nrot += 1;
+    }
+    Scratch sc;
+    {
+        const size_t need = nrot * (kLvl1Words + kLvl0Words) * sizeof(uint32_t) +
+                            (count * 5 + 8) * sizeof(LinDesc) + 4096;
+        if (int rc = open_scratch(s, st, need, &sc)) return rc;
+    }
+    uint32_t *tmp1 = nullptr, *tmp0 = nullptr;   // lvl1 / lvl0 temporaries, one per rotation
+    if (nrot) {
+        if (int rc = sc.alloc((void**)&tmp1, nrot * kLvl1Words * sizeof(uint32_t))) return rc;
+        if (level == 1)
+            if (int rc = sc.alloc((void**)&tmp0, nrot * kLvl0Words * sizeof(uint32_t))) return rc;
+    }
+    size_t ir = 0;
+    for (size_t g = 0; g < count; g++) {
+        const GateRef gr = get(g);
+        if (!gr.out || !gr.in0) return fail(-1, "null ciphertext pointer");
+        if (gr.op == CUFHE_AMD_NOT || gr.op == CUFHE_AMD_COPY) {
+            lin.push_back({gr.in0, gr.in0, gr.out, gr.op == CUFHE_AMD_NOT ? -1 : 1, 0, 0u, 0u});
+            continue;
+        }
+        if (!gr.in1) return fail(-1, "gate needs a second operand");
+        if (gr.op == CUFHE_AMD_MUX || gr.op == CUFHE_AMD_NMUX) {
+            if (!gr.in2) return fail(-1, "mux needs a third operand");
+            uint32_t* t1a = tmp1 + (ir + 0) * kLvl1Words;
+            uint32_t* t1b = tmp1 + (ir + 1) * kLvl1Words;
+            const bool neg = gr.op == CUFHE_AMD_NMUX;
+            if (level == 0) {   // src/bootstrap_gpu.cu:515-588
+                rot.push_back({gr.in0, gr.in1, t1a, 1, 1, negmu, 0u});
+                rot.push_back({gr.in0, gr.in2, t1b, -1, 1, negmu, 0u});
+                ks.push_back({t1a, t1b, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            } else {            // src/bootstrap_gpu.cu:706-780
+                uint32_t* t0a = tmp0 + (ir + 0) * kLvl0Words;
+                uint32_t* t0b = tmp0 + (ir + 1) * kLvl0Words;
+                ks.push_back({gr.in0, gr.in1, t0a, 1, 1, negmu, 0u});
+                ks.push_back({gr.in0, gr.in2, t0b, -1, 1, negmu, 0u});
+                rot.push_back({t0a, t0a, t1a, 1, 0, 0u, 0u});
+                rot.push_back({t0b, t0b, t1b, 1, 0, 0u, 0u});
+                lin.push_back({t1a, t1b, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            }
+            ir += 2;
+            continue;
+        }
+        const int ca = kGateTab[gr.op][0], cb = kGateTab[gr.op][1];
+        const uint32_t off = (uint32_t)kGateTab[gr.op][2] * kMu;
+        if (level == 0) {       // __HomGate__ br->iks, src/bootstrap_gpu.cu:402-421
+            uint32_t* t1 = tmp1 + ir * kLvl1Words;
+            rot.push_back({gr.in0, gr.in1, t1, ca, cb, off, 0u});
+            ks.push_back({t1, t1, gr.out, 1, 0, 0u, 0u});
+        } else {                // __HomGate__ iks->br, src/bootstrap_gpu.cu:383-400
+            uint32_t* t0 = tmp0 + ir * kLvl0Words;
+            ks.push_back({gr.in0, gr.in1, t0, ca, cb, off, 0u});
+            rot.push_back({t0, t0, gr.out, 1, 0, 0u, 0u});
+        }
+        ir += 1;
+    }
+    // Mux/NMux at level 1 write their rotations to temporaries, two-input gates at level 1
+    // write straight to `out`; a lincomb that reads tmp1 must run after the rotations.
+    LinDesc *drot, *dks, *dlin;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = upload_descs(s, sc, lin, &dlin)) return rc;
+    const int words = level ? kLvl1Words : kLvl0Words;
+    if (level == 0) {
+        if (int rc = launch_blind_rotate(s, st, drot, rot.size(), kLvl0N, nullptr)) return rc;
+        if (int rc = launch_keyswitch(s, st, dks, ks.size())) return rc;
+    } else {
+        if (int rc = launch_keyswitch(s, st, dks, ks.size())) return rc;
+        if (int rc = launch_blind_rotate(s, st, drot, rot.size(), kLvl0N, nullptr)) return rc;
+    }
+    if (int rc = launch_lincomb(st, dlin, lin.size(), words)) return rc;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cufhe_amd_last_error(void) { return g_err.c_str(); }
+
+int cufhe_amd_get_params(cufhe_amd_params* p)
+{
+    if (!p) return fail(-1, "null");
+    p->n = kLvl0N; p->N = kN; p->nbit = kNbit; p->k = 1; p->l = kL; p->Bgbit = kBgbit;
+    p->t = kKsT; p->basebit = kKsBasebit; p->mu = kMu;
+    p->lvl0_words = kLvl0Words; p->lvl1_words = kLvl1Words;
+    p->bk_words = (uint64_t)kLvl0N * kBkStepDoubles;
+    p->ksk_words = (uint64_t)kN * kKsT * kKsNumBase * kKsRowWords;
+    p->bk_ntt_bytes = (uint64_t)kLvl0N * kBkStepDoubles * sizeof(double);
+    return 0;
+}
+
+int cufhe_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int cufhe_amd_set_gpu_num(int gpu_num)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (gpu_num < 1) return fail(-1, "gpu_num must be >= 1");
+    for (auto& d : g_dev)
+        if (d.ntt_ready || d.keys_ready) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
+    int have = cufhe_amd_device_count();
+    if (gpu_num > have) return fail(-1, "gpu_num exceeds the visible device count");
+    g_gpu_num = gpu_num;
+    g_dev = std::vector<DeviceState>(gpu_num);
+    return 0;
+}
+int cufhe_amd_get_gpu_num(void) { return g_gpu_num; }
+
+int cufhe_amd_initialize_ntt(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < g_gpu_num; i++)
+        if (int rc = ensure_ntt(i)) return rc;
+    return 0;
+}
+
+int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    const size_t want_bk = (size_t)kLvl0N * kBkStepDoubles;
+    const size_t want_ksk = (size_t)kN * kKsT * kKsNumBase * kKsRowWords;
+    if (!bk || !ksk) return fail(-1, "null key pointer");
+    if (bk_words != want_bk) return fail(-1, "bootstrapping key has the wrong size for this parameter set");
+    if (ksk_words != want_ksk) return fail(-1, "key-switching key has the wrong size for this parameter set");
+    for (int i = 0; i < g_gpu_num; i++) {
+        if (int rc = ensure_ntt(i)) return rc;
+        DeviceState& s = g_dev[i];
+        HIP_TRY(hipSetDevice(i));
+        if (s.keys_ready) {
+            HIP_TRY(hipFree(s.bk_ntt));
+            HIP_TRY(hipFree(s.ksk));
+            s.keys_ready = false;
+        }
+        HIP_TRY(hipMalloc((void**)&s.bk_ntt, want_bk * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&s.ksk, want_ksk * sizeof(uint32_t)));
+        uint32_t* d_bk = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_bk, want_bk * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s.ksk, ksk, want_ksk * sizeof(uint32_t), hipMemcpyHostToDevice));
+        const size_t polys = want_bk / kN;
+        const unsigned blocks = (unsigned)((polys + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
+        hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, 0, s.bk_ntt, d_bk,
+                           polys, s.tables, n_inverse_balanced());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(d_bk));
+        s.keys_ready = true;
+    }
+    return 0;
+}
+
+int cufhe_amd_cleanup(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int i = 0; i < g_gpu_num; i++) {
+        DeviceState& s = g_dev[i];
+        if (!s.ntt_ready && !s.keys_ready) continue;
+        HIP_TRY(hipSetDevice(i));
+        HIP_TRY(hipDeviceSynchronize());
+        for (auto* v : {&s.br_events, &s.ks_events}) {
+            for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+            v->clear();
+        }
+        if (s.keys_ready) { HIP_TRY(hipFree(s.bk_ntt)); HIP_TRY(hipFree(s.ksk)); }
+        if (s.ntt_ready) HIP_TRY(hipFree(s.tables));
+        for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
+        s.staging.clear();
+        for (auto& kv : s.workspaces) (void)hipFree(kv.second.base);
+        s.workspaces.clear();
+        s.ntt_ready = s.keys_ready = false;
+        s.tables = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
+        s.prof = cufhe_amd_profile{};
+    }
+    return 0;
+}
+
+int cufhe_amd_synchronize(void)
+{
+    for (int i = 0; i < g_gpu_num; i++) {
+        HIP_TRY(hipSetDevice(i));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    return 0;
+}
+
+int cufhe_amd_stream_create(int device, void** stream)
+{
+    if (int rc = use_device(device)) return rc;
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void*)st;
+    return 0;
+}
+int cufhe_amd_stream_destroy(int device, void* stream)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    {
+        std::lock_guard<std::mutex> lk(s.staging_mu);
+        auto it = s.workspaces.find((hipStream_t)stream);
+        if (it != s.workspaces.end()) {
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            (void)hipFree(it->second.base);
+            s.workspaces.erase(it);
+        }
+    }
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+int cufhe_amd_stream_query(int device, void* stream)
+{
+    if (int rc = use_device(device)) return rc;
+    hipError_t e = hipStreamQuery((hipStream_t)stream);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(-2, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+}
+int cufhe_amd_stream_synchronize(int device, void* stream)
+{
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int cufhe_amd_malloc(int device, size_t bytes, void** dptr)
+{
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+int cufhe_amd_free(int device, void* dptr)
+{
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(hipFree(dptr));
+    return 0;
+}
+int cufhe_amd_host_register(void* hptr, size_t bytes)
+{
+    HIP_TRY(hipHostRegister(hptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+int cufhe_amd_host_unregister(void* hptr)
+{
+    HIP_TRY(hipHostUnregister(hptr));
+    return 0;
+}
+int cufhe_amd_memcpy_h2d(int device, void* stream, void* dptr, const void* hptr, size_t bytes)
+{
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+int cufhe_amd_memcpy_d2h(int device, void* stream, void* hptr, const void* dptr, size_t bytes)
+{
+    if (int rc = use_device(device)) return rc;
+    HIP_TRY(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+
+int cufhe_amd_gate(int device, void* stream, int op, int level, uint32_t* out, const uint32_t* in0,
+                   const uint32_t* in1, const uint32_t* in2)
+{
+    return run_gates(device, stream, level, 1, [&](size_t) { return GateRef{op, out, in0, in1, in2}; });
+}
+
+int cufhe_amd_gate_batch(int device, void* stream, int level, size_t count, const int32_t* ops, int ops_stride,
+                         uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2,
+                         size_t stride_words)
+{
+    if (!ops) return fail(-1, "null ops");
+    return run_gates(device, stream, level, count, [&](size_t g) {
+        return GateRef{ops[g * (size_t)ops_stride], out + g * stride_words, in0 ? in0 + g * stride_words : nullptr,
+                       in1 ? in1 + g * stride_words : nullptr, in2 ? in2 + g * stride_words : nullptr};
+    });
+}
+
+int cufhe_amd_gate_list(int device, void* stream, int level, size_t count, const int32_t* ops,
+                        uint32_t* const* outs, const uint32_t* const* in0s, const uint32_t* const* in1s,
+                        const uint32_t* const* in2s)
+{
+    if (!ops || !outs || !in0s) return fail(-1, "null array");
+    return run_gates(device, stream, level, count, [&](size_t g) {
+        return GateRef{ops[g], outs[g], in0s[g], in1s ? in1s[g] : nullptr, in2s ? in2s[g] : nullptr};
+    });
+}
+
+int cufhe_amd_blind_rotate_batch(int device, void* stream, size_t count, const uint32_t* tlwe0, uint32_t* acc, int steps)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!tlwe0 || !acc) return fail(-1, "null pointer");
+    if (steps < 0 || steps > kLvl0N) steps = kLvl0N;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LinDesc> rot(count);
+    for (size_t g = 0; g < count; g++) rot[g] = {tlwe0 + g * kLvl0Words, tlwe0 + g * kLvl0Words, nullptr, 1, 0, 0u, 0u};
+    Scratch sc;
+    if (int rc = open_scratch(s, st, count * sizeof(LinDesc) + 4096, &sc)) return rc;
+    LinDesc* d;
+    if (int rc = upload_descs(s, sc, rot, &d)) return rc;
+    return launch_blind_rotate(s, st, d, count, steps, acc);
+}
+
+int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint32_t* tlwe1, uint32_t* tlwe0)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!tlwe0 || !tlwe1) return fail(-1, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LinDesc> ks(count);
+    for (size_t g = 0; g < count; g++)
+        ks[g] = {tlwe1 + g * kLvl1Words, tlwe1 + g * kLvl1Words, tlwe0 + g * kLvl0Words, 1, 0, 0u, 0u};
+    Scratch sc;
+    if (int rc = open_scratch(s, st, count * sizeof(LinDesc) + 4096, &sc)) return rc;
+    LinDesc* d;
+    if (int rc = upload_descs(s, sc, ks, &d)) return rc;
+    return launch_keyswitch(s, st, d, count);
+}
+
+int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a, const uint32_t* b, uint32_t* res)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (count == 0) return 0;
+    const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
+    hipLaunchKernelGGL(polymul_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, (hipStream_t)stream, res, a, b,
+                       (int)count, g_dev[device].tables, n_inverse_balanced());
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cufhe_amd_profile_enable(int device, int on)
+{
+    if (int rc = check_device(device)) return rc;
+    g_dev[device].profiling = on != 0;
+    return 0;
+}
+
+int cufhe_amd_profile_get(int device, cufhe_amd_profile* out, int reset)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    auto drain = [&](std::vector<EventPair>& v, double& ms, uint64_t& launches, uint64_t& units) -> int {
+        for (auto& e : v) {
+            HIP_TRY(hipEventSynchronize(e.b));
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, e.a, e.b));
+            ms += t; launches += 1; units += e.units;
+            (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        }
+        v.clear();
+        return 0;
+    };
+    if (int rc = drain(s.br_events, s.prof.blind_rotate_ms, s.prof.blind_rotate_launches, s.prof.blind_rotations)) return rc;
+    if (int rc = drain(s.ks_events, s.prof.keyswitch_ms, s.prof.keyswitch_launches, s.prof.keyswitches)) return rc;
+    if (out) *out = s.prof;
+    if (reset) s.prof = cufhe_amd_profile{};
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// fpfield.h -- exact arithmetic modulo a 50-bit prime carried in FP64 registers.
+//
+// Why FP64: on gfx950 a 64-bit integer modular butterfly costs 73-129 SIMD cycles
+// per wave (Goldilocks shift / general multiply), two 31-bit Shoup butterflies 89,
+// while the FP64 butterfly below costs 38 (tools/ubench/ubench_arith.hip, numbers in
+// profiles/r01_ubench_arith.txt): v_fma_f64 is the widest exact multiplier the CU
+// has at full VALU rate.  The external product is exact integer arithmetic
+// (SURVEY.md F5), so any prime p with p/2 > max|sum| gives the reference's words.
+//
+// Bound: digits are in [-Bg/2, Bg/2) and the bootstrapping key is taken as SIGNED
+// 32-bit torus words (congruent mod 2^32 to the reference's unsigned reading,
+// include/ntt_gpu/ntt_gpuntt.cuh:495-496, and the result is only used mod 2^32), so
+// |sum| <= (k+1) l N (Bg/2) 2^31 = 6144 * 32 * 2^31 = 2^48.585 < p/2 = 2^48.628.
+//
+// Representation: a residue is ANY integer-valued double x with |x| < 2^53 that is
+// congruent to the value mod p ("lazy, balanced").  Additions never reduce; the
+// multiplications below reduce as a side effect.  Every intermediate is an exact
+// integer, so results do not depend on evaluation order.  In units of p:
+//   2^53 / p = 10.356   (any value, additive headroom)
+//   2^52 / p =  5.178   (largest |a| mulmod() accepts)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FPF_HD __host__ __device__ __forceinline__
+#else
+#define FPF_HD static inline
+#endif
+
+namespace fpf {
+
+constexpr uint64_t P_U64 = 869757679894529ull;   // prime, = 1 (mod 2^16), 2^49.63
+constexpr uint64_t PSI_2048 = 594421426086543ull; // primitive 2048-th root of unity (3^((p-1)/2048))
+constexpr double P = 869757679894529.0;
+constexpr double PINV = 0x1.4b643eeb017dep-50;    // fl(1/p)
+constexpr double MAGIC0 = 6755399441055744.0;     // 1.5 * 2^52: adding it rounds to an integer
+constexpr double MAGIC1 = 13510798882111488.0;    // 1.5 * 2^53: rounds to an even integer
+
+// a*w mod p for |a| < 2^52 (5.178 p), |w| <= p/2.  |result| <= (0.5 + 0.097 |a|/p) p.
+FPF_HD double mulmod(double a, double w)
+{
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);            // exact low part of the product
+    const double q = __builtin_fma(h, PINV, MAGIC0) - MAGIC0;   // nearest integer to a*w/p
+    const double r = __builtin_fma(-q, P, h);            // exact: |h - q p| < 2^53, integer
+    return r + l;
+}
+// Same for |a| < 2^53 (10.356 p): q is rounded to an even integer, so
+// |result| <= (1 + 0.097 |a|/p) p.
+FPF_HD double mulmod_wide(double a, double w)
+{
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_fma(h, PINV, MAGIC1) - MAGIC1;
+    const double r = __builtin_fma(-q, P, h);
+    return r + l;
+}
+// centred residue of any |a| < 2^53: |result| <= p/2 (+1 at a tie)
+FPF_HD double reduce(double a)
+{
+    const double q = __builtin_fma(a, PINV, MAGIC0) - MAGIC0;
+    return __builtin_fma(-q, P, a);
+}
+// low 32 bits (two's complement) of an integer-valued double |a| < 2^51
+FPF_HD uint32_t low32(double a)
+{
+    const double t = a + MAGIC0;                          // mantissa = 2^51 + a
+    uint64_t bits;
+    __builtin_memcpy(&bits, &t, 8);
+    return (uint32_t)bits;
+}
+// torus word of a lazy residue whose true value c satisfies |c| < p/2
+FPF_HD uint32_t lift_u32(double a) { return low32(reduce(a)); }
+
+}  // namespace fpf

@@ -1,0 +1,365 @@
+// kernels.hip.h -- gfx950 kernels of the gate-bootstrapping path.
+//
+//   bk_to_ntt_kernel       __TRGSW2NTT__            src/bootstrap_gpu.cu:43-70
+//   blind_rotate_kernel    __BlindRotatePreAdd__ / __BlindRotate__ + Accumulate +
+//                          __SampleExtractIndex__   include/gatebootstrapping_gpu.cuh:115-345,
+//                                                   src/bootstrap_gpu.cu:366-381
+//   keyswitch_kernel       KeySwitchFromTLWE / IdentityKeySwitchPreAdd
+//                                                   include/keyswitch_gpu.cuh:83-188
+//   lincomb_kernel         __NotBootstrap__/__CopyBootstrap__ and the Mux/NMux sums
+//                                                   src/bootstrap_gpu.cu:681-703,728-740
+//   polymul_kernel         the NTT product check of test/test_polynomial_mult_1024.cu:76-99
+//
+// Execution model (not the reference's one-block-per-gate/one-launch-per-gate): a launch
+// covers a whole batch; ONE WAVEFRONT owns one blind rotation from the first CMux to the
+// sample extract.  Its accumulator (2 x 1024 torus words) and the two NTT-domain sums
+// (2 x 1024 residues) stay in VGPRs for all n = 630 steps, so the only global traffic of
+// the hot loop is the read of the bootstrapping key.  Waves never synchronise with each
+// other after the twiddle tables are staged in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ntt_wave.h"
+
+namespace cufhe_amd {
+
+// TFHE parameters; symbolic so another set is a one-line change
+constexpr int kLvl0N = 630;            // lvl0param::n
+constexpr int kNbit = 10;              // lvl1param::nbit
+constexpr int kL = 3;                  // lvl1param::l
+constexpr int kBgbit = 6;              // lvl1param::Bgbit
+constexpr int kKsT = 8;                // lvl10param::t
+constexpr int kKsBasebit = 2;          // lvl10param::basebit
+constexpr uint32_t kMu = 1u << 29;     // lvl0/lvl1 mu
+constexpr int kLvl0Words = kLvl0N + 1;
+constexpr int kLvl1Words = kN + 1;
+constexpr int kBkRows = 2 * kL;                         // (k+1) l
+constexpr int kBkPolysPerStep = kBkRows * 2;            // (k+1)^2 l = 12
+constexpr size_t kBkStepDoubles = (size_t)kBkPolysPerStep * kN;   // 12288 doubles = 98304 B
+constexpr int kKsRowWords = kLvl0Words;                 // 631
+constexpr int kKsNumBase = 1 << (kKsBasebit - 1);       // 2
+
+// out = ca * in0 + cb * in1 + (0, ..., 0, off): the linear part of every gate
+struct LinDesc {
+    const uint32_t* in0;
+    const uint32_t* in1;   // never null (equal to in0 when cb == 0)
+    uint32_t* out;
+    int32_t ca, cb;
+    uint32_t off;
+    uint32_t pad;
+};
+
+constexpr int kBrWavesPerBlock = 4;
+constexpr int kBrThreads = 64 * kBrWavesPerBlock;
+constexpr int kBrLdsBytes = kLdsTableBytes + kBrWavesPerBlock * kTileBytes;   // 49920
+
+// gadget decomposition constants, include/gatebootstrapping_gpu.cuh:18-27,145-150
+__host__ __device__ constexpr uint32_t decomp_offset()
+{
+    uint32_t o = 0;
+    for (int i = 1; i <= kL; i++) o += (1u << (kBgbit - 1)) << (32 - i * kBgbit);
+    return o + (1u << (32 - kL * kBgbit - 1));     // + roundoffset
+}
+
+// ----------------------------------------------------------------------------------
+// BK -> NTT domain.  One wave per torus polynomial.  Values are read as SIGNED words
+// (see fpfield.h), transformed, scaled by N^-1 (so the inverse transform needs no
+// scaling) and stored centred, in layout C order: [poly][q = reg/2][lane][reg & 1].
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBrThreads) void bk_to_ntt_kernel(
+    double* __restrict__ bk_ntt, const uint32_t* __restrict__ bk, size_t polys,
+    const NttTables* __restrict__ gt, double n_inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tabs = (double*)smem;
+    load_tables_to_lds(tabs, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t poly = (size_t)blockIdx.x * kBrWavesPerBlock + wave;
+    if (poly >= polys) return;
+    const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
+    double x[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) x[r] = (double)(int32_t)bk[poly * kN + lane + 64 * r];
+    ntt_forward(x, ctx);
+    double2* dst = (double2*)(bk_ntt + poly * kN);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        double2 v;
+        v.x = fpf::reduce(fpf::mulmod_wide(x[2 * q], n_inverse));
+        v.y = fpf::reduce(fpf::mulmod_wide(x[2 * q + 1], n_inverse));
+        dst[q * 64 + lane] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Blind rotate + sample extract, one wave per rotation.
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uniform_select10(const uint32_t (&v)[10], int idx)
+{
+    uint32_t s = v[0];
+#pragma unroll
+    for (int k = 1; k < 10; k++) s = (idx == k) ? v[k] : s;
+    return s;
+}
+
+// acc_j -> digits of ((X^abar - 1) acc_j), include/gatebootstrapping_gpu.cuh:157-181.
+// The rotation goes through the wave's LDS tile: the polynomial is written twice
+// (e and e + N) so the rotated read is base + 256*r with no wrap-around arithmetic.
+__device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32_t (&acc)[kRegs],
+                                           char* tile, int lane, uint32_t abar)
+{
+    char* wbase = tile + 4 * lane;
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        *(uint32_t*)(wbase + 256 * r) = acc[r];
+        *(uint32_t*)(wbase + 256 * r + 4096) = acc[r];
+    }
+    const int alo = (int)(abar & (kN - 1));
+    const bool ahi = (abar >> kNbit) != 0;
+    const char* rbase = tile + 4 * ((lane - alo) & (kN - 1));
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        const uint32_t v = *(const uint32_t*)(rbase + 256 * r);
+        const bool neg = (lane < alo - 64 * r) != ahi;      // (e < abar mod N) xor (abar >= N)
+        temp[r] = (neg ? 0u - v : v) - acc[r] + decomp_offset();
+    }
+}
+
+__device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double (&A1)[kRegs],
+                                                     const double (&x)[kRegs],
+                                                     const double2* __restrict__ row, int lane)
+{
+    // row: two NTT-domain polynomials (out = 0, 1) of one TRGSW row, layout C
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const double2 b0 = row[q * 64 + lane];
+        A0[2 * q] += fpf::mulmod_wide(x[2 * q], b0.x);
+        A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b0.y);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const double2 b1 = row[512 + q * 64 + lane];
+        A1[2 * q] += fpf::mulmod_wide(x[2 * q], b1.x);
+        A1[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b1.y);
+    }
+}
+
+// one component j: rotate/subtract/decompose, then l forward NTTs, each multiplied into
+// both accumulators (include/gatebootstrapping_gpu.cuh:153-224)
+__device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)[kRegs],
+                                               const uint32_t (&accj)[kRegs], const WaveCtx& ctx,
+                                               char* tile, int lane, uint32_t abar,
+                                               const double2* __restrict__ rows)
+{
+    uint32_t temp[kRegs];
+    rotate_sub(temp, accj, tile, lane, abar);
+#pragma unroll 1
+    for (int d = 0; d < kL; d++) {
+        const int shift = 32 - (d + 1) * kBgbit;
+        double x[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++)
+            x[r] = (double)((int32_t)((temp[r] >> shift) & ((1u << kBgbit) - 1)) - (1 << (kBgbit - 1)));
+        ntt_forward(x, ctx);
+        pointwise_accumulate(A0, A1, x, rows + (size_t)d * kN, lane);
+    }
+}
+
+__device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&accj)[kRegs], const WaveCtx& ctx)
+{
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) A[r] = fpf::reduce(A[r]);
+    ntt_inverse(A, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) accj[r] += fpf::lift_u32(A[r]);   // centred lift, :258-281
+}
+
+// descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at
+// index 0).  steps < n is only used by the parity tests; acc_dump (optional) receives the
+// raw accumulator (2N words per rotation) instead of nothing.
+__global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tabs = (double*)smem;
+    load_tables_to_lds(tabs, gt);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kBrWavesPerBlock + wave;
+    if (g >= count) return;
+    char* tile = smem + kLdsTableBytes + wave * kTileBytes;
+    const WaveCtx ctx = make_wave_ctx(tile, tabs, gt, lane);
+
+    const LinDesc d = descs[g];
+    // pre-add (gate linear part) and modulus switch, :316-345
+    uint32_t ab[10];
+    uint32_t bword = 0;
+#pragma unroll
+    for (int rr = 0; rr < 10; rr++) {
+        const int i = lane + 64 * rr;
+        uint32_t c = 0;
+        if (i <= kLvl0N) c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (rr == 9) bword = c;
+        ab[rr] = (c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit);
+    }
+    bword = __builtin_amdgcn_readlane(bword, kLvl0N - 64 * 9) + d.off;
+    const uint32_t bbar = 2 * kN - (bword >> (32 - 1 - kNbit));
+
+    // RotatedTestVector, :29-52
+    uint32_t acc0[kRegs], acc1[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        const uint32_t e = lane + 64 * r;
+        acc0[r] = 0;
+        const bool neg = (bbar != 2 * kN) && ((e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
+        acc1[r] = neg ? 0u - kMu : kMu;
+    }
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t sel = uniform_select10(ab, i >> 6);
+        const uint32_t abar = __builtin_amdgcn_readlane(sel, i & 63);
+        if (abar == 0) continue;                   // (X^0 - 1) acc = 0: all digits are zero
+        const double2* bk_i = (const double2*)(bk_ntt + (size_t)i * kBkStepDoubles);
+        double A0[kRegs], A1[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
+        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, bk_i);
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) { A0[r] = fpf::reduce(A0[r]); A1[r] = fpf::reduce(A1[r]); }
+        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, bk_i + (size_t)kL * kN);
+        inverse_and_add(A0, acc0, ctx);
+        inverse_and_add(A1, acc1, ctx);
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) {
+            o[lane + 64 * r] = acc0[r];
+            o[kN + lane + 64 * r] = acc1[r];
+        }
+    }
+    if (d.out) {
+        // __SampleExtractIndex__<P,0>: out[0] = a[0], out[m] = -a[N-m], out[N] = b[0]
+        uint32_t* o = d.out;
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) {
+            const int e = lane + 64 * r;
+            if (e == 0) { o[0] = acc0[r]; o[kN] = acc1[r]; }
+            else o[kN - e] = 0u - acc0[r];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Key switch lvl1 -> lvl0 with the linear pre-add fused (IdentityKeySwitchPreAdd).
+// One block per ciphertext, thread i owns output words i, i+128, ...  The digit of
+// a'_j is wave-uniform, so the row choice is a scalar branch.
+// ----------------------------------------------------------------------------------
+constexpr int kKsThreads = 128;
+constexpr int kKsCols = (kLvl0Words + kKsThreads - 1) / kKsThreads;   // 5
+
+__global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk)
+{
+    __shared__ uint32_t tl[kLvl1Words];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const LinDesc d = descs[g];
+    for (int j = threadIdx.x; j < kLvl1Words; j += kKsThreads) {
+        uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
+        if (j == kN) v += d.off;
+        tl[j] = v;
+    }
+    __syncthreads();
+
+    // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98
+    uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
+    for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
+
+    uint32_t res[kKsCols];
+    int col[kKsCols];
+#pragma unroll
+    for (int c = 0; c < kKsCols; c++) {
+        col[c] = threadIdx.x + c * kKsThreads;
+        res[c] = (col[c] == kLvl0N) ? tl[kN] : 0u;
+        if (col[c] > kLvl0N) col[c] = kLvl0N;      // clamp: harmless duplicate read, never stored
+    }
+    for (int j = 0; j < kN; j++) {
+        const uint32_t tmp = __builtin_amdgcn_readfirstlane(tl[j]) + koff;
+        const uint32_t* rowj = ksk + (size_t)j * kKsT * kKsNumBase * kKsRowWords;
+#pragma unroll
+        for (int k = 0; k < kKsT; k++) {
+            const int val = (int)((tmp >> (32 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
+            if (val != 0) {
+                const uint32_t* row = rowj + (size_t)(k * kKsNumBase + (val > 0 ? val : -val) - 1) * kKsRowWords;
+                if (val > 0) {
+#pragma unroll
+                    for (int c = 0; c < kKsCols; c++) res[c] -= row[col[c]];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kKsCols; c++) res[c] += row[col[c]];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kKsCols; c++) {
+        const int i = threadIdx.x + c * kKsThreads;
+        if (i <= kLvl0N) d.out[i] = res[c];
+    }
+}
+
+// out = ca*in0 + cb*in1 + (0,..,off) over `words` words; grid-stride over ciphertexts
+__global__ __launch_bounds__(256) void lincomb_kernel(const LinDesc* __restrict__ descs, int count, int words)
+{
+    for (int g = blockIdx.x; g < count; g += gridDim.x) {
+        const LinDesc d = descs[g];
+        for (int i = threadIdx.x; i < words; i += blockDim.x) {
+            uint32_t v = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+            if (i == words - 1) v += d.off;
+            d.out[i] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// res = a (signed small) * b (torus) negacyclic mod 2^32, one wave per product: the
+// device-side mirror of test/test_polynomial_mult_1024.cu (ForwardNTT, PointwiseMultiply,
+// InverseNTT kernels).  Also exposes the raw forward+inverse round trip.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBrThreads) void polymul_kernel(
+    uint32_t* __restrict__ res, const int32_t* __restrict__ a, const uint32_t* __restrict__ b,
+    int count, const NttTables* __restrict__ gt, double n_inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* tabs = (double*)smem;
+    load_tables_to_lds(tabs, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kBrWavesPerBlock + wave;
+    if (g >= count) return;
+    const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
+    double x[kRegs], y[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        x[r] = (double)a[(size_t)g * kN + lane + 64 * r];
+        y[r] = (double)(int32_t)b[(size_t)g * kN + lane + 64 * r];
+    }
+    ntt_forward(x, ctx);
+    ntt_forward(y, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        y[r] = fpf::reduce(fpf::mulmod_wide(y[r], n_inverse));
+        x[r] = fpf::reduce(fpf::mulmod_wide(x[r], y[r]));
+    }
+    ntt_inverse(x, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) res[(size_t)g * kN + lane + 64 * r] = fpf::lift_u32(x[r]);
+}
+
+}  // namespace cufhe_amd

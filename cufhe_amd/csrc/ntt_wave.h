@@ -1,0 +1,221 @@
+// ntt_wave.h -- one negacyclic NTT-1024 per wavefront, 16 coefficients per lane in VGPRs.
+//
+// Replaces the reference's shared-memory radix-2 NTT (SmallForwardNTT_1024 /
+// SmallInverseNTT_1024, include/ntt_gpu/ntt_gpuntt.cuh:232-276,342-392: 512 threads,
+// 5-6 block barriers per transform).  Same transform (merged-psi Cooley-Tukey forward,
+// Gentleman-Sande inverse, twiddle index m+g), different machine mapping:
+//
+//   element index e (10 bits); the wave keeps three register layouts
+//     A: lane = e[5:0]                 reg = e[9:6]      (natural: global/torus side)
+//     B: lane = e[9:6] | e[1:0] << 4   reg = e[5:2]
+//     C: lane = e[9:6] | e[5:4] << 4   reg = e[3:0]      (spectrum side: BK layout)
+//   forward: stages 0-3 in A (strides 512..64 are register strides 8..1, twiddles are
+//   wave-uniform scalars), transpose, stages 4-7 in B (15 per-lane twiddles),
+//   transpose, stages 8-9 in C.  Inverse mirrors it.  No block barrier anywhere: the
+//   two transposes go through a wave-private LDS tile.
+//
+//   Tile addressing is additive (slot = pitch * e[9:6] + e[5:0], pitch 65 or 66) so that
+//   in every layout the address is (per-lane base VGPR) + (compile-time offset): the
+//   transposes cost no VALU instructions at all.  Pitch 66 makes the 32-lane
+//   ds_read_b64 of layout B conflict-free (2*lambda + g), pitch 65 does the same for the
+//   layout-C read and the layout-B write; the remaining patterns are at worst 2-way
+//   conflicts on ds_write_b64, which the store's own issue time covers.
+//
+// Lazy-reduction schedule (bounds in units of p, see fpfield.h; checked on the host by
+// tests/host_model.cpp through tests/test_fpfield.py):
+//   forward  in <= 2^-18      after s0..s9: .5 1.05 1.65 2.31 3.04 3.83 4.70 5.66 7.2 8.9
+//            (stages 8,9 use mulmod_wide because their inputs exceed 5.178)
+//   inverse  in <= .5         s9 1.0  s8 2.0  s7 4.0  s6 8.0(wide) reduce  s5 1.0  s4 2.0
+//            s3 4.0  s2 8.0(wide) reduce  s1 1.0  s0 2.0
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fpfield.h"
+
+namespace cufhe_amd {
+
+constexpr int kN = 1024;
+constexpr int kRegs = 16;            // coefficients per lane
+constexpr int kTbCount = 15;         // per-lane twiddles of stages 4-7
+constexpr int kTcCount = 12;         // per-lane twiddles of stages 8-9
+constexpr int kTileSlots = 66 * 16;  // 8-byte slots in a wave's transpose tile
+constexpr int kTileBytes = kTileSlots * 8;   // 8448
+
+// twiddle tables, generated on the host with exact integer arithmetic (capi.cpp)
+struct NttTables {
+    double tu_fwd[16];               // [k] k<15: root[2^lvl + j], lvl=floor(log2(k+1)), j=k+1-2^lvl
+    double tu_inv[16];
+    double tb_fwd[kTbCount * 16];    // [k][lambda]: root[16*2^lvl + lambda*2^lvl + j]
+    double tb_inv[kTbCount * 16];
+    double tc_fwd[kTcCount * 64];    // [k][lane]: k<4: root[256 + (lambda<<4|h<<2|k)]; else root[512 + (lambda<<5|h<<3|(k-4))]
+    double tc_inv[kTcCount * 64];
+};
+constexpr int kLdsTableDoubles = 2 * kTbCount * 16 + 2 * kTcCount * 64;   // 2016
+constexpr int kLdsTableBytes = kLdsTableDoubles * 8;                        // 16128
+
+// cooperative copy global -> LDS (whole workgroup), caller barriers afterwards
+__device__ __forceinline__ void load_tables_to_lds(double* lds, const NttTables* g)
+{
+    const double* src = g->tb_fwd;   // tb_fwd, tb_inv, tc_fwd, tc_inv are contiguous
+    for (int i = threadIdx.x; i < kLdsTableDoubles; i += blockDim.x) lds[i] = src[i];
+}
+
+// Per-lane LDS byte addresses, computed once per kernel and kept in VGPRs.
+struct WaveCtx {
+    char* a65;   // layout A, pitch 65:  tile + 8*lane                 (+ 8*65*r)
+    char* a66;   // layout A, pitch 66:  same base                      (+ 8*66*r)
+    char* b65;   // layout B, pitch 65:  tile + 8*(65*lambda + g)       (+ 32*r)
+    char* b66;   // layout B, pitch 66:  tile + 8*(66*lambda + g)       (+ 32*r)
+    char* c65;   // layout C, pitch 65:  tile + 8*(65*lambda + 16*h)    (+ 8*r)
+    char* c66;   // layout C, pitch 66
+    const char* tb_fwd;   // LDS tables + 8*lambda  (+ 128*k)
+    const char* tb_inv;
+    const char* tc_fwd;   // LDS tables + 8*lane    (+ 512*k)
+    const char* tc_inv;
+    const NttTables* gt;  // global tables (uniform scalars)
+};
+
+__device__ __forceinline__ WaveCtx make_wave_ctx(char* tile, const double* lds_tables,
+                                                 const NttTables* gt, int lane)
+{
+    const int lam = lane & 15, hi = lane >> 4;
+    WaveCtx c;
+    c.a65 = tile + 8 * lane;
+    c.a66 = c.a65;
+    c.b65 = tile + 8 * (65 * lam + hi);
+    c.b66 = tile + 8 * (66 * lam + hi);
+    c.c65 = tile + 8 * (65 * lam + 16 * hi);
+    c.c66 = tile + 8 * (66 * lam + 16 * hi);
+    const char* t = (const char*)lds_tables;
+    c.tb_fwd = t + 8 * lam;
+    c.tb_inv = t + 8 * (kTbCount * 16) + 8 * lam;
+    c.tc_fwd = t + 8 * (2 * kTbCount * 16) + 8 * lane;
+    c.tc_inv = t + 8 * (2 * kTbCount * 16 + kTcCount * 64) + 8 * lane;
+    c.gt = gt;
+    return c;
+}
+
+__device__ __forceinline__ double lds_ld(const char* p, int off) { return *(const double*)(p + off); }
+__device__ __forceinline__ void lds_st(char* p, int off, double v) { *(double*)(p + off) = v; }
+
+// ---- butterflies -----------------------------------------------------------------
+template <bool WIDE>
+__device__ __forceinline__ void ct_bfly(double& a, double& b, double w)
+{
+    const double t = WIDE ? fpf::mulmod_wide(b, w) : fpf::mulmod(b, w);
+    const double u = a;
+    a = u + t;
+    b = u - t;
+}
+template <bool WIDE>
+__device__ __forceinline__ void gs_bfly(double& a, double& b, double w)
+{
+    const double u = a, v = b;
+    a = u + v;
+    b = WIDE ? fpf::mulmod_wide(u - v, w) : fpf::mulmod(u - v, w);
+}
+
+struct TwUniform {                   // stages 0-3: wave-uniform scalars from global memory
+    const double* t;
+    __device__ __forceinline__ double operator()(int k) const { return t[k]; }
+};
+struct TwLane {                      // stages 4-7: tb[k][lambda] from LDS
+    const char* t;
+    __device__ __forceinline__ double operator()(int k) const { return lds_ld(t, 128 * k); }
+};
+
+// Four radix-2 stages on register strides 8,4,2,1 with twiddles tw(0..14)
+// (tw(0) | tw(1..2) | tw(3..6) | tw(7..14)); identical in layouts A and B.
+template <class TW>
+__device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
+{
+    {
+        const double w = tw(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ct_bfly<false>(x[r], x[r + 8], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const double w = tw(1 + g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) ct_bfly<false>(x[8 * g + r], x[8 * g + r + 4], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const double w = tw(3 + g);
+#pragma unroll
+        for (int r = 0; r < 2; r++) ct_bfly<false>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g++) ct_bfly<false>(x[2 * g], x[2 * g + 1], tw(7 + g));
+}
+template <class TW>
+__device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
+{
+#pragma unroll
+    for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], tw(7 + g));
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const double w = tw(3 + g);
+#pragma unroll
+        for (int r = 0; r < 2; r++) gs_bfly<true>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = fpf::reduce(x[r]);
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const double w = tw(1 + g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) gs_bfly<false>(x[8 * g + r], x[8 * g + r + 4], w);
+    }
+    {
+        const double w = tw(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) gs_bfly<false>(x[r], x[r + 8], w);
+    }
+}
+
+// ---- layout changes through the wave-private LDS tile -----------------------------
+// DS operations of one wave execute in issue order, so a wave may reuse its own tile
+// without any barrier.
+#define CUFHE_AMD_XPOSE(WBASE, WSTRIDE, RBASE, RSTRIDE)                              \
+    {                                                                                \
+        _Pragma("unroll") for (int r = 0; r < kRegs; r++) lds_st(WBASE, (WSTRIDE) * r, x[r]); \
+        _Pragma("unroll") for (int r = 0; r < kRegs; r++) x[r] = lds_ld(RBASE, (RSTRIDE) * r); \
+    }
+
+// forward: x in layout A (natural order), out in layout C (spectrum order)
+__device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
+{
+    ct_four_stages(x, TwUniform{c.gt->tu_fwd});
+    CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
+    ct_four_stages(x, TwLane{c.tb_fwd});
+    CUFHE_AMD_XPOSE(c.b65, 32, c.c65, 8)             // B -> C
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const double w = lds_ld(c.tc_fwd, 512 * g);
+#pragma unroll
+        for (int r = 0; r < 2; r++) ct_bfly<true>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], lds_ld(c.tc_fwd, 512 * (4 + g)));
+}
+
+// inverse: x in layout C with |x| <= p/2, out in layout A with |x| <= 2p, NOT scaled by
+// 1/N (N^-1 is folded into the NTT-domain bootstrapping key)
+__device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c)
+{
+#pragma unroll
+    for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], lds_ld(c.tc_inv, 512 * (4 + g)));
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const double w = lds_ld(c.tc_inv, 512 * g);
+#pragma unroll
+        for (int r = 0; r < 2; r++) gs_bfly<false>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+    CUFHE_AMD_XPOSE(c.c66, 8, c.b66, 32)             // C -> B
+    gs_four_stages(x, TwLane{c.tb_inv});
+    CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
+    gs_four_stages(x, TwUniform{c.gt->tu_inv});
+}
+
+}  // namespace cufhe_amd

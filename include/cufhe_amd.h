@@ -1,0 +1,123 @@
+/*
+ * cufhe_amd.h -- C ABI of the MI355X gate-bootstrapping engine.
+ *
+ * This is the drop-in boundary for the gate path of virtualsecureplatform/cuFHE: every
+ * entry point below replaces one piece of the reference's host interface (file:line
+ * under /root/reference cited per function).  Plain pointers and sizes only; no HIP,
+ * torch or C++ types.  All functions return 0 on success and a negative code on failure
+ * (cufhe_amd_last_error() gives the text); the reference aborts instead
+ * (include/details/error_gpu.cuh:40-60) and the C++ shim include/cufhe_amd.hpp restores
+ * that behaviour.
+ *
+ * Conventions
+ *   - "device" is the reference's GPU index in [0, gpuNum) (Stream::device_id(),
+ *     include/cufhe_gpu.cuh:152-189).
+ *   - "stream" is an opaque hipStream_t (NULL = the device's default stream).
+ *   - level 0 ciphertexts are lvl0 TLWEs: n+1 = 631 uint32 words (a[0..n-1], b);
+ *     level 1 ciphertexts are lvl1 TLWEs: N+1 = 1025 words (TFHEpp::TLWE<P>,
+ *     include/cufhe_gpu.cuh:118).  All ciphertext pointers passed to gate functions are
+ *     DEVICE pointers, as in the reference's launchers (src/bootstrap_gpu.cu:834-1292).
+ *   - op codes: enum cufhe_amd_op.  For CUFHE_AMD_MUX/NMUX the operands are
+ *     (in0, in1, in2) = (inc, in1, in0) of Mux(out, inc, in1, in0).
+ */
+#ifndef CUFHE_AMD_H
+#define CUFHE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum cufhe_amd_op {
+    CUFHE_AMD_NAND = 0, CUFHE_AMD_NOR, CUFHE_AMD_XNOR, CUFHE_AMD_AND, CUFHE_AMD_OR, CUFHE_AMD_XOR,
+    CUFHE_AMD_ANDNY, CUFHE_AMD_ANDYN, CUFHE_AMD_ORNY, CUFHE_AMD_ORYN,
+    CUFHE_AMD_MUX, CUFHE_AMD_NMUX, CUFHE_AMD_NOT, CUFHE_AMD_COPY, CUFHE_AMD_NUM_OPS
+};
+
+/* parameter set compiled into the library (TFHEpp lvl0/lvl1/lvl10 params) */
+typedef struct cufhe_amd_params {
+    uint32_t n, N, nbit, k, l, Bgbit, t, basebit, mu;
+    uint32_t lvl0_words, lvl1_words;
+    uint64_t bk_words;        /* n * (k+1)l * (k+1) * N torus words   */
+    uint64_t ksk_words;       /* k N * t * 2^(basebit-1) * (n+1) words */
+    uint64_t bk_ntt_bytes;    /* bytes one blind rotation reads        */
+} cufhe_amd_params;
+int cufhe_amd_get_params(cufhe_amd_params* out);
+const char* cufhe_amd_last_error(void);
+
+/* ---- device management: src/cufhe_gates_gpu.cu:38-65, include/cufhe_gpu.cuh:54-74 ---- */
+int cufhe_amd_set_gpu_num(int gpu_num);                 /* SetGPUNum             :38 */
+int cufhe_amd_get_gpu_num(void);
+int cufhe_amd_device_count(void);                       /* physical GPUs visible     */
+int cufhe_amd_initialize_ntt(void);                     /* Initialize()          :40 */
+/* Initialize(const EvalKey&) :42-47 = InitializeNTThandlers + BootstrappingKeyToNTT
+ * (src/bootstrap_gpu.cu:111-138) + KeySwitchingKeyToDevice (src/keyswitch_gpu.cu:6-16).
+ * bk: host, [n][(k+1)l][k+1][N] torus words; ksk: host, [kN][t][2^(basebit-1)][n+1]. */
+int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
+int cufhe_amd_cleanup(void);                            /* CleanUp               :49 */
+int cufhe_amd_synchronize(void);                        /* Synchronize  cufhe_gpu.cuh:68-74 */
+
+/* ---- streams: class Stream include/cufhe_gpu.cuh:152-189, StreamQuery :55-65 ---- */
+int cufhe_amd_stream_create(int device, void** stream);
+int cufhe_amd_stream_destroy(int device, void* stream);
+int cufhe_amd_stream_query(int device, void* stream);   /* 1 = idle, 0 = busy, <0 = error */
+int cufhe_amd_stream_synchronize(int device, void* stream);
+
+/* ---- ciphertext storage: ctxtInitialize/ctxtDelete include/cufhe_gpu.cuh:76-95,
+ *      CtxtCopyH2D/D2H :193-207 ---- */
+int cufhe_amd_malloc(int device, size_t bytes, void** dptr);
+int cufhe_amd_free(int device, void* dptr);
+int cufhe_amd_host_register(void* hptr, size_t bytes);
+int cufhe_amd_host_unregister(void* hptr);
+int cufhe_amd_memcpy_h2d(int device, void* stream, void* dptr, const void* hptr, size_t bytes);
+int cufhe_amd_memcpy_d2h(int device, void* stream, void* hptr, const void* dptr, size_t bytes);
+
+/* ---- gates on device-resident ciphertexts ----
+ * One gate, one launch sequence on `stream`: the g-prefixed gates of
+ * src/cufhe_gates_gpu.cu:160-167 etc. (NandBootstrap ... NMuxBootstrap, NotBootstrap,
+ * CopyBootstrap).  in1/in2 may be NULL where the op does not read them. */
+int cufhe_amd_gate(int device, void* stream, int op, int level, uint32_t* out,
+                   const uint32_t* in0, const uint32_t* in1, const uint32_t* in2);
+/* The native batched entry: `count` independent gates in one launch sequence.
+ * ops[g * ops_stride] is the op of gate g (ops_stride 0: ops[0] for all; ops is a HOST
+ * array).  Operand g of each array is at base + g * stride_words. */
+int cufhe_amd_gate_batch(int device, void* stream, int level, size_t count,
+                         const int32_t* ops, int ops_stride, uint32_t* out,
+                         const uint32_t* in0, const uint32_t* in1, const uint32_t* in2,
+                         size_t stride_words);
+/* Same with per-gate operand pointers (HOST arrays of DEVICE pointers): what the
+ * stream scheduler of include/cufhe_amd.hpp flushes. */
+int cufhe_amd_gate_list(int device, void* stream, int level, size_t count, const int32_t* ops,
+                        uint32_t* const* outs, const uint32_t* const* in0s,
+                        const uint32_t* const* in1s, const uint32_t* const* in2s);
+
+/* ---- pieces of the path (TRLWE-level primitives and parity hooks) ----
+ * BootstrapTLWE2TRLWE (src/bootstrap_gpu.cu:806-815): tlwe0[count][n+1] -> acc[count][2N]
+ * after `steps` CMux steps (steps < 0: all n); also the accumulator parity hook. */
+int cufhe_amd_blind_rotate_batch(int device, void* stream, size_t count, const uint32_t* tlwe0,
+                                 uint32_t* acc, int steps);
+/* SEIandKS (src/keyswitch_gpu.cu:26-40) on already extracted lvl1 TLWEs:
+ * tlwe1[count][N+1] -> tlwe0[count][n+1] */
+int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint32_t* tlwe1,
+                              uint32_t* tlwe0);
+/* NTT product check of test/test_polynomial_mult_1024.cu: res = a * b negacyclic mod 2^32,
+ * a signed with |a| <= 128 (exactness bound of the field), all [count][N], device. */
+int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a,
+                            const uint32_t* b, uint32_t* res);
+
+/* ---- measurement ----
+ * When enabled, every blind-rotate / key-switch launch is bracketed by HIP events on the
+ * stream it runs on; get_profile synchronises and returns accumulated kernel time. */
+typedef struct cufhe_amd_profile {
+    double blind_rotate_ms; uint64_t blind_rotate_launches; uint64_t blind_rotations;
+    double keyswitch_ms;    uint64_t keyswitch_launches;    uint64_t keyswitches;
+} cufhe_amd_profile;
+int cufhe_amd_profile_enable(int device, int on);
+int cufhe_amd_profile_get(int device, cufhe_amd_profile* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""ctypes wrapper of oracle/liboracle.so (CPU restatement, test infrastructure only)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libplain_ref.so")
+
+n, N = 630, 1024
+LVL_WORDS = (n + 1, N + 1)
+BK_WORDS = n * 6 * 2 * N
+KSK_WORDS = N * 8 * 2 * (n + 1)
+MU = 1 << 29
+OPS = ["NAND", "NOR", "XNOR", "AND", "OR", "XOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NMUX", "NOT", "COPY"]
+
+_u32 = np.ctypeslib.ndpointer(np.uint32, flags="C")
+_i32 = np.ctypeslib.ndpointer(np.int32, flags="C")
+_u8 = np.ctypeslib.ndpointer(np.uint8, flags="C")
+_u64 = np.ctypeslib.ndpointer(np.uint64, flags="C")
+
+
+def build():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "tfhe_oracle.c")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(REF_LIB) and os.path.exists("/root/reference/test/plain.h"):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+def load():
+    build()
+    L = ctypes.CDLL(LIB)
+    L.orc_keygen.argtypes = [ctypes.c_uint64, _u32, _u32]
+    L.orc_bkgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u32]
+    L.orc_kskgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u32]
+    L.orc_tlwe_encrypt_batch.argtypes = [ctypes.c_uint64, ctypes.c_int, _u32, _u8, ctypes.c_size_t, _u32]
+    L.orc_tlwe_decrypt_batch.argtypes = [ctypes.c_int, _u32, _u32, ctypes.c_size_t, _u8]
+    L.orc_polymul_schoolbook.argtypes = [_u32, _i32, _u32]
+    L.orc_polymul_ntt.argtypes = [_u32, _i32, _u32]
+    L.orc_ntt_forward.argtypes = [_u64]
+    L.orc_ntt_inverse.argtypes = [_u64]
+    for f in ("orc_ntt_modulus", "orc_ntt_psi", "orc_ntt_barrett_mu", "orc_ntt_n_inverse"):
+        getattr(L, f).restype = ctypes.c_uint64
+    L.orc_ntt_mulmod.restype = ctypes.c_uint64
+    L.orc_ntt_mulmod.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+    L.orc_evalkey_create.restype = ctypes.c_void_p
+    L.orc_evalkey_create.argtypes = [_u32, _u32]
+    L.orc_evalkey_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_blind_rotate.argtypes = [ctypes.c_void_p, _u32, _u32, ctypes.c_int]
+    L.orc_sample_extract0.argtypes = [_u32, _u32]
+    L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32, _u32]
+    L.orc_gate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _u32, _u32, _u32, _u32]
+    L.orc_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                 _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.orc_truth.argtypes = [ctypes.c_int] * 4
+    L.orc_gate_coeffs.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
+    return L
+
+
+class Keys:
+    """Seeded secret keys + evaluation key (deterministic: same seed, same words)."""
+
+    def __init__(self, L, seed=1):
+        self.L = L
+        self.seed = seed
+        self.s0 = np.zeros(n, np.uint32)
+        self.s1 = np.zeros(N, np.uint32)
+        L.orc_keygen(seed, self.s0, self.s1)
+        self.bk = np.zeros(BK_WORDS, np.uint32)
+        self.ksk = np.zeros(KSK_WORDS, np.uint32)
+        L.orc_bkgen(seed + 1000, self.s0, self.s1, self.bk)
+        L.orc_kskgen(seed + 2000, self.s0, self.s1, self.ksk)
+        self.ek = L.orc_evalkey_create(self.bk, self.ksk)
+
+    def key(self, level):
+        return self.s1 if level else self.s0
+
+    def encrypt(self, bits, level, seed):
+        bits = np.ascontiguousarray(bits, dtype=np.uint8).ravel()
+        cts = np.zeros(bits.size * LVL_WORDS[level], np.uint32)
+        self.L.orc_tlwe_encrypt_batch(seed, level, self.key(level), bits, bits.size, cts)
+        return cts.reshape(bits.size, LVL_WORDS[level])
+
+    def decrypt(self, cts, level):
+        cts = np.ascontiguousarray(cts, dtype=np.uint32).reshape(-1, LVL_WORDS[level])
+        bits = np.zeros(cts.shape[0], np.uint8)
+        self.L.orc_tlwe_decrypt_batch(level, self.key(level), cts.ravel(), cts.shape[0], bits)
+        return bits
+
+    def gate_batch(self, ops, level, in0, in1=None, in2=None, threads=None):
+        in0 = np.ascontiguousarray(in0, dtype=np.uint32)
+        count = in0.reshape(-1, LVL_WORDS[level]).shape[0]
+        if np.isscalar(ops):
+            ops_arr, stride = np.array([ops], np.int32), 0
+        else:
+            ops_arr, stride = np.ascontiguousarray(ops, np.int32), 1
+        out = np.zeros(count * LVL_WORDS[level], np.uint32)
+        p1 = np.ascontiguousarray(in1, np.uint32).ctypes.data if in1 is not None else None
+        p2 = np.ascontiguousarray(in2, np.uint32).ctypes.data if in2 is not None else None
+        if in1 is not None:
+            in1 = np.ascontiguousarray(in1, np.uint32); p1 = in1.ctypes.data
+        if in2 is not None:
+            in2 = np.ascontiguousarray(in2, np.uint32); p2 = in2.ctypes.data
+        if threads is None:
+            threads = self.L.orc_max_threads()
+        self.L.orc_gate_batch(self.ek, ops_arr, stride, level, count, out, in0.ravel(), p1, p2, threads)
+        return out.reshape(count, LVL_WORDS[level])
+
+
+def truth(L, op, a, b=0, c=0):
+    return L.orc_truth(op, int(a), int(b), int(c))
