@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- NAND gate-bootstraps/s of the HIP gate path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: 4096 independent NAND gates
+(BASELINE.json configs[1]) per GPU, inputs and keys already resident in HBM, one
+cufhe_amd_gate_batch call = one blind-rotate launch + one key-switch launch.  With N > 1
+ranks (one per GPU, launched by torch.distributed.run) every rank runs its own 4096 gates
+against its own BK/KSK replica: weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (blind rotate)
+with the BK-sweep accounting of SURVEY.md 8(d): 61 931 520 algorithmic bytes per rotation,
+divided by the launch time measured with HIP events on the launch stream.  `cpu_baseline`
+times the CPU oracle (oracle/, a restatement of the same gate) on this box's host cores on
+a bounded sample of the same inputs and checks the GPU words against it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+RANK = int(os.environ.get("RANK", "0"))
+LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
+WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+
+# one process per GPU: make this rank's GPU the only visible device (before any HIP call)
+if WORLD > 1:
+    vis = os.environ.get("HIP_VISIBLE_DEVICES")
+    if vis:
+        ids = [v for v in vis.split(",") if v != ""]
+        os.environ["HIP_VISIBLE_DEVICES"] = ids[LOCAL_RANK % len(ids)]
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(LOCAL_RANK)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: its bundled HIP runtime is the one the process uses)
+import torch.distributed as dist  # noqa: E402
+
+BK_BYTES_PER_ROTATION = 61931520          # n (k+1)^2 l N 8, SURVEY.md 8(d)
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
+    """Time the CPU oracle on a bounded sample of the same workload; verify GPU words."""
+    import ctypes
+    L = ol.load()
+    ek = L.orc_evalkey_create(bk, ksk)
+    threads = L.orc_max_threads()
+    nand = np.array([0], np.int32)
+    words = ol.n + 1
+
+    def run(count):
+        out = np.zeros(count * words, np.uint32)
+        a = np.ascontiguousarray(in0[:count]).ravel()
+        b = np.ascontiguousarray(in1[:count])
+        t = time.perf_counter()
+        L.orc_gate_batch(ek, nand, 0, 0, count, out, a, b.ctypes.data, None, threads)
+        return time.perf_counter() - t, out.reshape(count, words)
+
+    dt, out = run(threads)                                   # calibration pass
+    per_round = max(dt, 1e-3)
+    count = int(min(in0.shape[0], max(threads, threads * round(target_seconds / per_round))))
+    dt, out = run(count)
+    L.orc_evalkey_destroy(ek)
+    match = bool(np.array_equal(out, gpu_out[:count]))
+    return {
+        "value": count / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
+        "sample": f"{count} of the batch's NAND gates, OpenMP over gates, {dt:.1f} s",
+        "ms_per_gate_per_core": 1e3 * dt * threads / count,
+        "gpu_words_match_oracle": match,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus != WORLD:
+        if WORLD == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+
+    if WORLD > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=RANK, world_size=WORLD)
+    torch.cuda.set_device(0)
+    torch.cuda.init()
+
+    import cufhe_amd as eng                  # fails loudly if the HIP library is missing
+    import oracle_lib as ol                   # sizes only, until the cpu_baseline leg
+
+    count = args.gates
+    rng = np.random.default_rng(42 + RANK)
+    # synthetic keys and ciphertexts: uniform torus words (the path's work is data-independent)
+    bk = rng.integers(0, 2**32, size=ol.BK_WORDS, dtype=np.uint64).astype(np.uint32)
+    ksk = rng.integers(0, 2**32, size=ol.KSK_WORDS, dtype=np.uint64).astype(np.uint32)
+    in0 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+    in1 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+
+    eng.SetGPUNum(1)
+    eng.Initialize(bk, ksk)
+    d0 = eng.api.DeviceBuffer(in0.size).upload(in0)
+    d1 = eng.api.DeviceBuffer(in1.size).upload(in1)
+    dout = eng.api.DeviceBuffer(count * (ol.n + 1))
+    st = eng.Stream(0)
+    st.Create()
+
+    def step():
+        eng.gate_batch(eng.api.NAND, 0, dout, d0, d1, count=count, device=0, stream=st.st())
+
+    def barrier():
+        if WORLD > 1:
+            dist.barrier()
+        eng.Synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_get(reset=True)
+    eng.profile_enable(False)
+    if WORLD > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if RANK == 0:
+        total_gates = count * args.steps * WORLD
+        br_ms = prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1)
+        ks_ms = prof.keyswitch_ms / max(prof.keyswitch_launches, 1)
+        achieved = BK_BYTES_PER_ROTATION * count / (br_ms * 1e-3) / 1e9
+        res = {
+            "metric": "nand_gate_bootstraps_per_sec",
+            "value": total_gates / elapsed,
+            "unit": "gate-bootstraps/s",
+            "n_gpus": WORLD,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{count} independent NAND gates per GPU per step (BASELINE configs[1]), "
+                            "TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2, lvl0 ciphertexts resident in HBM",
+                "gates_per_gpu": count,
+                "sharding": "gates split across ranks, per-GPU BK/KSK replica, no collective",
+            },
+            "ms_per_gate_throughput": 1e3 * elapsed / (count * args.steps),
+            "roofline": {
+                "bound": "hbm", "kernel": "blind_rotate_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "launch_ms": br_ms, "rotations_per_launch": count,
+                "algorithmic_bytes_per_rotation": BK_BYTES_PER_ROTATION,
+                "keyswitch_launch_ms": ks_ms,
+            },
+        }
+        if not args.no_cpu_baseline and WORLD == 1:
+            gpu_out = dout.download().reshape(count, ol.n + 1)
+            res["cpu_baseline"] = cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out)
+        print(json.dumps(res), flush=True)
+
+    st.Destroy()
+    eng.CleanUp()
+    if WORLD > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
