@@ -49,6 +49,9 @@ struct LinDesc {
     uint32_t pad;
 };
 
+#ifndef CUFHE_AMD_BR_OCC
+#define CUFHE_AMD_BR_OCC 2          // blind-rotate waves per SIMD the register budget is sized for
+#endif
 constexpr int kBrWavesPerBlock = 4;
 constexpr int kBrThreads = 64 * kBrWavesPerBlock;
 constexpr int kBrLdsBytes = kLdsTableBytes + kBrWavesPerBlock * kTileBytes;   // 49920
@@ -178,7 +181,7 @@ __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&a
 // descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at
 // index 0).  steps < n is only used by the parity tests; acc_dump (optional) receives the
 // raw accumulator (2N words per rotation) instead of nothing.
-__global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
+__global__ __launch_bounds__(kBrThreads, CUFHE_AMD_BR_OCC) void blind_rotate_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {

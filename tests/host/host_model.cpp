@@ -1,0 +1,204 @@
+// host_model.cpp -- host-side model of the device arithmetic (test infrastructure).
+//
+// Compiles cufhe_amd/csrc/fpfield.h with g++ and replays, on scalar loops, exactly the
+// lazy-reduction schedule of cufhe_amd/csrc/ntt_wave.h (which stages use mulmod,
+// mulmod_wide, reduce).  It checks what cannot be seen from GPU parity tests alone:
+//   - every intermediate stays an exact integer below 2^53 and every mulmod input
+//     stays inside its documented range, for random AND adversarial inputs;
+//   - the per-stage magnitude bounds written in ntt_wave.h hold;
+//   - the result equals the exact negacyclic product (checked by the caller against the
+//     oracle's schoolbook product).
+// Index order here is the plain radix-2 order (no lane layouts): the layouts of the device
+// code only permute which register holds which element.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../cufhe_amd/csrc/fpfield.h"
+
+namespace {
+typedef unsigned __int128 u128;
+constexpr int N = 1024;
+const uint64_t P = fpf::P_U64;
+
+uint64_t mulmod_u(uint64_t a, uint64_t b) { return (uint64_t)((u128)a * b % P); }
+uint64_t powmod_u(uint64_t a, uint64_t e)
+{
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = mulmod_u(r, a); a = mulmod_u(a, a); e >>= 1; }
+    return r;
+}
+double bal(uint64_t v) { return v > P / 2 ? -(double)(P - v) : (double)v; }
+uint32_t bitrev10(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 10; i++) r |= ((x >> i) & 1u) << (9 - i); return r; }
+
+std::vector<double> g_fwd, g_inv;
+double g_ninv;
+void tables()
+{
+    if (!g_fwd.empty()) return;
+    g_fwd.resize(N); g_inv.resize(N);
+    uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u(psi, P - 2);
+    for (uint32_t i = 0; i < N; i++) { g_fwd[i] = bal(powmod_u(psi, bitrev10(i))); g_inv[i] = bal(powmod_u(psi_inv, bitrev10(i))); }
+    g_ninv = bal(powmod_u(N, P - 2));
+}
+
+struct Track {           // violation flags + per-stage maxima (units of p)
+    double max_abs = 0;  // largest |value| seen anywhere / p
+    double max_mul_in = 0, max_wide_in = 0;
+    int bad = 0;         // non-integer / out-of-range events
+    void val(double v)
+    {
+        double a = std::fabs(v);
+        if (a >= 9007199254740992.0 || v != std::nearbyint(v)) bad++;
+        if (a / fpf::P > max_abs) max_abs = a / fpf::P;
+    }
+    void mul_in(double v, bool wide)
+    {
+        double a = std::fabs(v);
+        if (wide) { if (a >= 9007199254740992.0) bad++; if (a / fpf::P > max_wide_in) max_wide_in = a / fpf::P; }
+        else { if (a >= 4503599627370496.0) bad++; if (a / fpf::P > max_mul_in) max_mul_in = a / fpf::P; }
+    }
+};
+
+double mm(double a, double w, bool wide, Track& t)
+{
+    t.mul_in(a, wide);
+    double r = wide ? fpf::mulmod_wide(a, w) : fpf::mulmod(a, w);
+    t.val(r);
+    return r;
+}
+
+// forward: stages 0..7 mulmod, stages 8,9 mulmod_wide (ntt_wave.h ntt_forward)
+void fwd(double* x, Track& t, double* stage_max)
+{
+    int tt = N >> 1, s = 0;
+    for (int m = 1; m < N; m <<= 1, tt >>= 1, s++) {
+        const bool wide = s >= 8;
+        double mx = 0;
+        for (int g = 0; g < m; g++) {
+            const double w = g_fwd[m + g];
+            double* a = x + 2 * g * tt;
+            for (int j = 0; j < tt; j++) {
+                double v = mm(a[j + tt], w, wide, t), u = a[j];
+                a[j] = u + v; a[j + tt] = u - v;
+                t.val(a[j]); t.val(a[j + tt]);
+                mx = std::fmax(mx, std::fmax(std::fabs(a[j]), std::fabs(a[j + tt])));
+            }
+        }
+        if (stage_max) stage_max[s] = mx / fpf::P;
+    }
+}
+// inverse: s9 s8 | s7 s6(wide) reduce s5 s4 | s3 s2(wide) reduce s1 s0   (ntt_wave.h ntt_inverse)
+void inv(double* x, Track& t, double* stage_max)
+{
+    int tt = 1, s = 9;
+    for (int m = N >> 1; m >= 1; m >>= 1, tt <<= 1, s--) {
+        const bool wide = (s == 6 || s == 2);
+        double mx = 0;
+        for (int g = 0; g < m; g++) {
+            const double w = g_inv[m + g];
+            double* a = x + 2 * g * tt;
+            for (int j = 0; j < tt; j++) {
+                double u = a[j], v = a[j + tt];
+                a[j] = u + v; t.val(a[j]);
+                double d = u - v; t.val(d);
+                a[j + tt] = mm(d, w, wide, t);
+                mx = std::fmax(mx, std::fmax(std::fabs(a[j]), std::fabs(a[j + tt])));
+            }
+        }
+        if (stage_max) stage_max[9 - s] = mx / fpf::P;
+        if (s == 6 || s == 2)
+            for (int i = 0; i < N; i++) { x[i] = fpf::reduce(x[i]); t.val(x[i]); }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// scalar checks: returns number of mismatches against exact arithmetic
+int hm_check_mulmod(const double* a, const double* w, int count, int wide)
+{
+    int bad = 0;
+    for (int i = 0; i < count; i++) {
+        double r = wide ? fpf::mulmod_wide(a[i], w[i]) : fpf::mulmod(a[i], w[i]);
+        // exact: (a*w - r) must be divisible by p and |r| within the documented bound
+        __int128 prod = (__int128)(int64_t)a[i] * (int64_t)w[i];
+        __int128 diff = prod - (__int128)(int64_t)r;
+        if (diff % (__int128)P != 0) bad++;
+        double c = std::fabs(a[i]) / fpf::P;
+        double bound = (wide ? 1.0 : 0.5) + 0.097 * c + 1e-9;
+        if (std::fabs(r) > bound * fpf::P) bad++;
+        if (r != std::nearbyint(r)) bad++;
+    }
+    return bad;
+}
+int hm_check_reduce_lift(const double* a, int count)
+{
+    int bad = 0;
+    for (int i = 0; i < count; i++) {
+        double r = fpf::reduce(a[i]);
+        __int128 diff = (__int128)(int64_t)a[i] - (__int128)(int64_t)r;
+        if (diff % (__int128)P != 0) bad++;
+        if (std::fabs(r) > 0.5 * fpf::P + 1) bad++;
+        int64_t c = (int64_t)r;
+        if (fpf::low32(r) != (uint32_t)(uint64_t)c) bad++;
+        if (fpf::lift_u32(a[i]) != (uint32_t)(uint64_t)c) bad++;
+    }
+    return bad;
+}
+
+// res = a * b negacyclic mod 2^32 through the device schedule.
+// stats[0]=bad events, [1]=max|v|/p, [2]=max mulmod input/p, [3]=max wide input/p,
+// [4..13] forward per-stage maxima of the digit transform, [14..23] inverse per-stage maxima.
+void hm_polymul(uint32_t* res, const int32_t* a, const uint32_t* b, double* stats)
+{
+    tables();
+    Track t;
+    std::vector<double> x(N), y(N);
+    for (int i = 0; i < N; i++) { x[i] = (double)a[i]; y[i] = (double)(int32_t)b[i]; }
+    fwd(x.data(), t, stats ? stats + 4 : nullptr);
+    fwd(y.data(), t, nullptr);
+    for (int i = 0; i < N; i++) {
+        // BK conversion: scale by N^-1 and centre (bk_to_ntt_kernel)
+        y[i] = fpf::reduce(mm(y[i], g_ninv, true, t));
+        // pointwise (pointwise_accumulate) + pre-inverse reduce (inverse_and_add)
+        x[i] = fpf::reduce(mm(x[i], y[i], true, t));
+        t.val(x[i]);
+    }
+    inv(x.data(), t, stats ? stats + 14 : nullptr);
+    for (int i = 0; i < N; i++) res[i] = fpf::lift_u32(x[i]);
+    if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
+}
+
+// One external product with the device's accumulation schedule: rows = 6 digit polys
+// dig[6][N] (signed), bk[6][2][N] torus words -> out[2][N] torus words (the value added to
+// the accumulator).  Mirrors cmux_component / inverse_and_add incl. the mid reduce.
+void hm_external_product(uint32_t* out, const int32_t* dig, const uint32_t* bk, double* stats)
+{
+    tables();
+    Track t;
+    std::vector<double> A0(N, 0.0), A1(N, 0.0), x(N), y0(N), y1(N);
+    for (int row = 0; row < 6; row++) {
+        for (int i = 0; i < N; i++) {
+            x[i] = (double)dig[row * N + i];
+            y0[i] = (double)(int32_t)bk[(row * 2 + 0) * N + i];
+            y1[i] = (double)(int32_t)bk[(row * 2 + 1) * N + i];
+        }
+        fwd(x.data(), t, nullptr); fwd(y0.data(), t, nullptr); fwd(y1.data(), t, nullptr);
+        for (int i = 0; i < N; i++) {
+            y0[i] = fpf::reduce(mm(y0[i], g_ninv, true, t));
+            y1[i] = fpf::reduce(mm(y1[i], g_ninv, true, t));
+            A0[i] += mm(x[i], y0[i], true, t); t.val(A0[i]);
+            A1[i] += mm(x[i], y1[i], true, t); t.val(A1[i]);
+        }
+        if (row == 2) for (int i = 0; i < N; i++) { A0[i] = fpf::reduce(A0[i]); A1[i] = fpf::reduce(A1[i]); }
+    }
+    for (int i = 0; i < N; i++) { A0[i] = fpf::reduce(A0[i]); A1[i] = fpf::reduce(A1[i]); }
+    inv(A0.data(), t, nullptr); inv(A1.data(), t, nullptr);
+    for (int i = 0; i < N; i++) { out[i] = fpf::lift_u32(A0[i]); out[N + i] = fpf::lift_u32(A1[i]); }
+    if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
+}
+
+double hm_p(void) { return fpf::P; }
+}

@@ -1,0 +1,59 @@
+"""CPU tests of the C-ABI boundary: libcufhe_amd.so loads and exports exactly what
+include/cufhe_amd.h declares; no compute call is made (there is no GPU here), but the
+argument checking that does not need one is exercised."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import oracle_lib as ol
+
+HDR = os.path.join(ol.ROOT, "include", "cufhe_amd.h")
+LIB = os.path.join(ol.ROOT, "cufhe_amd", "libcufhe_amd.so")
+
+
+def header_symbols():
+    text = open(HDR).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cufhe_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "build the HIP extension first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(LIB)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/cufhe_amd.h but not exported"
+
+
+def test_python_binding_covers_the_header():
+    from cufhe_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+
+
+def test_params_and_sizes_match_the_oracle():
+    import cufhe_amd
+    p = cufhe_amd.PARAMS
+    assert (p.n, p.N, p.nbit, p.k, p.l, p.Bgbit, p.t, p.basebit, p.mu) == (630, 1024, 10, 1, 3, 6, 8, 2, 1 << 29)
+    assert (p.lvl0_words, p.lvl1_words) == ol.LVL_WORDS
+    assert p.bk_words == ol.BK_WORDS and p.ksk_words == ol.KSK_WORDS
+    assert p.bk_ntt_bytes == 61931520            # bytes one blind rotation reads
+
+
+def test_errors_are_reported_not_fatal():
+    import cufhe_amd
+    from cufhe_amd import _lib
+    lib = _lib.lib
+    # wrong key sizes are rejected before any device work
+    rc = lib.cufhe_amd_initialize(None, 0, None, 0)
+    assert rc < 0 and b"null" in lib.cufhe_amd_last_error()
+    buf = (ctypes.c_uint32 * 4)()
+    rc = lib.cufhe_amd_initialize(buf, 4, buf, 4)
+    assert rc < 0 and b"wrong size" in lib.cufhe_amd_last_error()
+    assert lib.cufhe_amd_set_gpu_num(0) < 0
+    # a gate before Initialize(ek) / on a bad device index fails with a status
+    assert lib.cufhe_amd_gate(5, None, 0, 0, None, None, None, None) < 0
+    with pytest.raises(cufhe_amd.CufheAmdError):
+        _lib.check(lib.cufhe_amd_gate(5, None, 0, 0, None, None, None, None))

@@ -1,0 +1,126 @@
+"""CPU tests of the FP64 prime-field arithmetic the HIP kernels use (cufhe_amd/csrc/fpfield.h)
+and of the lazy-reduction schedule of cufhe_amd/csrc/ntt_wave.h, replayed on the host by
+tests/host/host_model.cpp.  The product path is NOT exercised here (no GPU): this checks the
+exactness argument -- every intermediate an exact integer < 2^53, every multiplication
+input inside its documented range -- on random and worst-case inputs, and the final words
+against the oracle's schoolbook product."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host", "host_model.cpp")
+LIB = os.path.join(HERE, "host", "libhost_model.so")
+P = 869757679894529
+
+
+@pytest.fixture(scope="module")
+def hm():
+    deps = [SRC, os.path.join(ol.ROOT, "cufhe_amd", "csrc", "fpfield.h")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, SRC])
+    L = ctypes.CDLL(LIB)
+    f64 = np.ctypeslib.ndpointer(np.float64, flags="C")
+    L.hm_check_mulmod.argtypes = [f64, f64, ctypes.c_int, ctypes.c_int]
+    L.hm_check_reduce_lift.argtypes = [f64, ctypes.c_int]
+    u32 = np.ctypeslib.ndpointer(np.uint32, flags="C")
+    i32 = np.ctypeslib.ndpointer(np.int32, flags="C")
+    L.hm_polymul.argtypes = [u32, i32, u32, f64]
+    L.hm_external_product.argtypes = [u32, i32, u32, f64]
+    L.hm_p.restype = ctypes.c_double
+    return L
+
+
+def test_prime_and_root():
+    import sympy
+    assert sympy.isprime(P) and (P - 1) % (1 << 16) == 0
+    psi = 594421426086543
+    assert pow(psi, 1024, P) == P - 1 and pow(psi, 2048, P) == 1
+    # exactness bound: (k+1) l N (Bg/2) 2^31 < p/2   (signed BK words)
+    assert 6144 * 32 * 2**31 < P // 2
+    assert float.fromhex("0x1.4b643eeb017dep-50") == 1.0 / P
+
+
+def test_header_constants_match(hm):
+    assert hm.hm_p() == float(P)
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_mulmod_exact_and_bounded(hm, wide):
+    rng = np.random.default_rng(1 + wide)
+    count = 200000
+    lim = (2**53 if wide else 2**52) - 1
+    a = rng.integers(-lim, lim + 1, size=count).astype(np.float64)
+    w = rng.integers(-(P // 2), P // 2 + 1, size=count).astype(np.float64)
+    # edges: largest legal inputs, largest twiddle, zeros, ones
+    a[:8] = [lim, -lim, lim, -lim, 0, 1, -1, lim]
+    w[:8] = [P // 2, P // 2, -(P // 2), -(P // 2), P // 2, P // 2, -(P // 2), 1]
+    assert hm.hm_check_mulmod(a, w, count, wide) == 0
+
+
+def test_reduce_and_lift(hm):
+    rng = np.random.default_rng(3)
+    a = rng.integers(-(2**53 - 1), 2**53, size=200000).astype(np.float64)
+    a[:6] = [0, 1, -1, P // 2, -(P // 2), 2**53 - 1]
+    assert hm.hm_check_reduce_lift(a, a.size) == 0
+
+
+def _school(oracle, a, b):
+    want = np.zeros(ol.N, np.uint32)
+    oracle.orc_polymul_schoolbook(want, np.ascontiguousarray(a, np.int32), np.ascontiguousarray(b, np.uint32))
+    return want
+
+
+def test_polymul_schedule_random_and_bounds(hm, oracle):
+    rng = np.random.default_rng(5)
+    fwd_doc = [.5, 1.05, 1.65, 2.31, 3.04, 3.83, 4.70, 5.66, 7.2, 8.9]        # ntt_wave.h header
+    inv_doc = [1.0, 2.0, 4.0, 8.0, 1.0, 2.0, 4.0, 8.0, 1.0, 2.0]
+    for trial in range(20):
+        a = rng.integers(-32, 32, size=ol.N, dtype=np.int32)
+        b = rng.integers(0, 2**32, size=ol.N, dtype=np.uint64).astype(np.uint32)
+        res = np.zeros(ol.N, np.uint32)
+        st = np.zeros(24)
+        hm.hm_polymul(res, a, b, st)
+        assert st[0] == 0, "non-integer or out-of-range intermediate"
+        assert st[1] < 10.356 and st[2] < 5.178 and st[3] < 10.356
+        assert all(st[4 + s] <= fwd_doc[s] + 1e-9 for s in range(10)), st[4:14]
+        assert all(st[14 + s] <= inv_doc[s] + 1e-9 for s in range(10)), st[14:24]
+        assert np.array_equal(res, _school(oracle, a, b))
+
+
+def test_external_product_worst_case(hm, oracle):
+    """All digits -32 against all BK words 0x80000000: coefficient N-1 of every row reaches
+    1024*32*2^31, and the six rows add up to the bound 2^48.585 -- still exact."""
+    dig = np.full((6, ol.N), -32, np.int32)
+    bk = np.full((6, 2, ol.N), 0x80000000, np.uint32)
+    out = np.zeros(2 * ol.N, np.uint32)
+    st = np.zeros(4)
+    hm.hm_external_product(out, dig.ravel(), bk.ravel(), st)
+    assert st[0] == 0 and st[1] < 10.356 and st[2] < 5.178 and st[3] < 10.356
+    want = np.zeros(ol.N, np.uint32)
+    for row in range(6):
+        want += _school(oracle, dig[row], bk[row, 0])
+    assert np.array_equal(out[:ol.N], want) and np.array_equal(out[ol.N:], want)
+    # the true integer at coefficient N-1 is +6*2^46 (not representable mod 2^32 without care)
+    assert int(want[ol.N - 1]) == (6 * 2**46) % 2**32
+
+
+def test_external_product_random(hm, oracle):
+    rng = np.random.default_rng(9)
+    for trial in range(5):
+        dig = rng.integers(-32, 32, size=(6, ol.N), dtype=np.int32)
+        bk = rng.integers(0, 2**32, size=(6, 2, ol.N), dtype=np.uint64).astype(np.uint32)
+        out = np.zeros(2 * ol.N, np.uint32)
+        st = np.zeros(4)
+        hm.hm_external_product(out, dig.ravel(), bk.ravel(), st)
+        assert st[0] == 0 and st[1] < 10.356
+        for c in range(2):
+            want = np.zeros(ol.N, np.uint32)
+            for row in range(6):
+                want += _school(oracle, dig[row], bk[row, c])
+            assert np.array_equal(out[c * ol.N:(c + 1) * ol.N], want)

@@ -1,0 +1,173 @@
+"""CPU tests of the oracle (oracle/tfhe_oracle.c): what pins it.
+
+ - the reference's published NTT constants (include/ntt_gpu/ntt_gpuntt.cuh:36-40,
+   src/ntt_gpu/ntt_gpuntt.cu:31-32) and its Barrett multiplication against big-int arithmetic;
+ - NTT product == schoolbook negacyclic product mod 2^32, the check of
+   test/test_polynomial_mult_1024.cu:51-73,209-223 (exact here, the reference allows diff<=2);
+ - plaintext truth tables == the reference's own, compiled from /root/reference/test/plain.h
+   into oracle/_ref/ (test/plain.h:10-69);
+ - decrypt(gate(...)) == truth table for all 13 gate kinds + COPY, both ciphertext levels
+   (test/test_gate_gpu.cc:72-84 exercises lvl1, test/test_gate_gpu_multi.cc lvl0);
+ - the committed golden vectors (tests/golden/golden_v1.json).
+"""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint32).tobytes()).hexdigest()
+
+
+def test_reference_ntt_constants(oracle):
+    p, psi, mu = oracle.orc_ntt_modulus(), oracle.orc_ntt_psi(), oracle.orc_ntt_barrett_mu()
+    assert p == 1152921504606877697 == 2**60 + 30721          # ntt_gpuntt.cuh:36
+    assert psi == 1689264667710614                              # ntt_gpuntt.cu:32
+    assert mu == 9223372036854530040 == (1 << 123) // p         # ntt_gpuntt.cuh:39, bit = 61
+    assert pow(psi, 1024, p) == p - 1 and pow(psi, 2048, p) == 1
+    assert (p - 1) % 2048 == 0 and (p - 1) % 4096 != 0          # 2-adicity 11: N <= 1024 only
+    assert oracle.orc_ntt_n_inverse() == pow(1024, -1, p) == 1151795604700035043
+
+
+def test_barrett_matches_bigint(oracle):
+    p = oracle.orc_ntt_modulus()
+    rng = np.random.default_rng(0)
+    vals = [0, 1, 2, p - 1, p - 2, p // 2, p // 2 + 1, 2**32, 2**59, 2**60]
+    pairs = [(a, b) for a in vals for b in vals]
+    pairs += [(int(a), int(b)) for a, b in zip(rng.integers(0, p, 20000, dtype=np.uint64), rng.integers(0, p, 20000, dtype=np.uint64))]
+    for a, b in pairs:
+        assert oracle.orc_ntt_mulmod(a, b) == a * b % p
+
+
+def test_ntt_roundtrip_and_spectrum(oracle):
+    p = oracle.orc_ntt_modulus()
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, p, ol.N, dtype=np.uint64)
+    y = x.copy()
+    oracle.orc_ntt_forward(y)
+    # spectrum value at bit-reversed slot br(i) is the evaluation at psi^(2 i + 1)
+    psi = oracle.orc_ntt_psi()
+    br = lambda v: int(format(v, "010b")[::-1], 2)
+    for i in (0, 1, 5, 1023):
+        root = pow(psi, 2 * i + 1, p)
+        ev = 0
+        for c in reversed([int(v) for v in x]):
+            ev = (ev * root + c) % p
+        assert int(y[br(i)]) == ev
+    oracle.orc_ntt_inverse(y)
+    assert np.array_equal(x, y)
+
+
+def test_polymul_ntt_equals_schoolbook(oracle):
+    """test/test_polynomial_mult_1024.cu: u32 polynomial x small (<= 18 bit) polynomial."""
+    rng = np.random.default_rng(2)
+    for trial in range(12):
+        bits = [6, 8, 18][trial % 3]
+        a = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), ol.N, dtype=np.int32)
+        b = rng.integers(0, 2**32, ol.N, dtype=np.uint64).astype(np.uint32)
+        if trial == 0:
+            a[:] = -32; b[:] = 0x80000000
+        if trial == 1:
+            a[:] = 31; b[:] = 0xFFFFFFFF
+        r1, r2 = np.zeros(ol.N, np.uint32), np.zeros(ol.N, np.uint32)
+        oracle.orc_polymul_schoolbook(r1, a, b)
+        oracle.orc_polymul_ntt(r2, a, b)
+        assert np.array_equal(r1, r2)
+
+
+REF_NAMES = {   # mangled names of namespace cufhe's truth functions in test/plain.h
+    "NAND": "_ZN5cufhe9NandCheckERhRKhS2_", "OR": "_ZN5cufhe7OrCheckERhRKhS2_",
+    "ORYN": "_ZN5cufhe9OrYNCheckERhRKhS2_", "ORNY": "_ZN5cufhe9OrNYCheckERhRKhS2_",
+    "AND": "_ZN5cufhe8AndCheckERhRKhS2_", "ANDYN": "_ZN5cufhe10AndYNCheckERhRKhS2_",
+    "ANDNY": "_ZN5cufhe10AndNYCheckERhRKhS2_", "XOR": "_ZN5cufhe8XorCheckERhRKhS2_",
+    "XNOR": "_ZN5cufhe9XnorCheckERhRKhS2_", "MUX": "_ZN5cufhe8MuxCheckERhRKhS2_S2_",
+    "NMUX": "_ZN5cufhe9NMuxCheckERhRKhS2_S2_", "NOT": "_ZN5cufhe8NotCheckERhRKh",
+    "COPY": "_ZN5cufhe9CopyCheckERhRKh",
+}
+
+
+def test_truth_tables_match_reference_plain_h(oracle):
+    """oracle/_ref/libplain_ref.so is /root/reference/test/plain.h compiled as is."""
+    if not os.path.exists(ol.REF_LIB):
+        pytest.skip("oracle/_ref not built (reference tree not mounted)")
+    ref = ctypes.CDLL(ol.REF_LIB)
+    u8 = ctypes.c_uint8
+    for name, sym in REF_NAMES.items():
+        fn = getattr(ref, sym)
+        op = ol.OPS.index(name)
+        for a in (0, 1):
+            for b in (0, 1):
+                for c in (0, 1):
+                    out, x, y, z = u8(7), u8(a), u8(b), u8(c)
+                    if name in ("NOT", "COPY"):
+                        fn(ctypes.byref(out), ctypes.byref(x))
+                    elif name in ("MUX", "NMUX"):
+                        fn(ctypes.byref(out), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z))
+                    else:
+                        fn(ctypes.byref(out), ctypes.byref(x), ctypes.byref(y))
+                    assert out.value == ol.truth(oracle, op, a, b, c), (name, a, b, c)
+    # NOR is in the reference's gate set (src/bootstrap_gpu.cu:433-440) but not in plain.h
+    assert [ol.truth(oracle, ol.OPS.index("NOR"), a, b) for a in (0, 1) for b in (0, 1)] == [1, 0, 0, 0]
+
+
+def test_encrypt_decrypt_and_noise(keys):
+    rng = np.random.default_rng(4)
+    for level in (0, 1):
+        bits = rng.integers(0, 2, 256).astype(np.uint8)
+        cts = keys.encrypt(bits, level, seed=31 + level)
+        assert np.array_equal(keys.decrypt(cts, level), bits)
+        # phase = +-mu + e with tiny e
+        key = keys.key(level)
+        ph = (cts[:, -1] - (cts[:, :-1] * key).sum(axis=1, dtype=np.uint64).astype(np.uint32)).astype(np.int32)
+        err = ph.astype(np.int64) - np.where(bits == 1, ol.MU, -ol.MU)
+        assert np.abs(err).max() < ol.MU // 8
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_every_gate_decrypts_to_truth_table(keys, oracle, level):
+    combos = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.uint8)
+    ins = [keys.encrypt(combos[:, i], level, seed=900 + 10 * level + i) for i in range(3)]
+    for op in range(14):
+        out = keys.gate_batch(op, level, ins[0], ins[1], ins[2])
+        assert list(keys.decrypt(out, level)) == [ol.truth(oracle, op, *c) for c in combos], ol.OPS[op]
+
+
+def test_pieces_compose_to_gate(keys, oracle):
+    """blind rotate -> sample extract -> key switch == orc_gate (lvl0 NAND)."""
+    ins = [keys.encrypt([1], 0, seed=61), keys.encrypt([0], 0, seed=62)]
+    c = (-ins[0][0].astype(np.int64) - ins[1][0].astype(np.int64)).astype(np.uint32)
+    c[ol.n] = (int(c[ol.n]) + ol.MU) % 2**32
+    acc = np.zeros(2 * ol.N, np.uint32)
+    oracle.orc_blind_rotate(keys.ek, acc, np.ascontiguousarray(c), -1)
+    t1 = np.zeros(ol.N + 1, np.uint32)
+    oracle.orc_sample_extract0(t1, acc)
+    t0 = np.zeros(ol.n + 1, np.uint32)
+    oracle.orc_keyswitch(keys.ek, t0, t1)
+    want = keys.gate_batch(0, 0, ins[0], ins[1])[0]
+    assert np.array_equal(t0, want) and keys.decrypt(t0, 0)[0] == 1
+    assert keys.decrypt(t1, 1)[0] == 1      # the extracted lvl1 TLWE already decrypts
+
+
+def test_golden_vectors(keys, oracle):
+    with open(os.path.join(ol.ROOT, "tests", "golden", "golden_v1.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == keys.seed
+    for name in ("s0", "s1", "bk", "ksk"):
+        assert sha(getattr(keys, name)) == g["keys_sha256"][name], f"key {name} is not reproducible"
+    triples = np.array(g["triples"], np.uint8)
+    for level in (0, 1):
+        ins = [keys.encrypt(triples[:, i], level, seed=5000 + 100 * level + i) for i in range(3)]
+        lv = g["levels"][str(level)]
+        assert [sha(x) for x in ins] == lv["inputs_sha256"]
+        for op, name in enumerate(ol.OPS):
+            out = keys.gate_batch(op, level, ins[0], ins[1], ins[2])
+            assert sha(out) == lv["ops"][name]["out_sha256"], (name, level)
+            assert [int(x) for x in keys.decrypt(out, level)] == lv["ops"][name]["decrypt"]
+            if "out_words_gate0" in lv["ops"][name]:
+                assert [int(x) for x in out[0]] == lv["ops"][name]["out_words_gate0"]
