@@ -59,6 +59,13 @@ SIGNATURES = {
                                             c_void, c_void, c_void, c_void, ctypes.c_size_t]),
     "cufhe_amd_gate_list": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_size_t, c_void,
                                            c_void, c_void, c_void, c_void]),
+    "cufhe_amd_ctxt_create": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.POINTER(c_void)]),
+    "cufhe_amd_ctxt_destroy": (ctypes.c_int, [c_void]),
+    "cufhe_amd_ctxt_device_ptr": (c_void, [c_void, ctypes.c_int]),
+    "cufhe_amd_enqueue_gate": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "cufhe_amd_enqueue_copy": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int]),
+    "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
+    "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),
     "cufhe_amd_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_polymul_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),

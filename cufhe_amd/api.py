@@ -134,42 +134,44 @@ class Ctxt:
     def __init__(self, level=0):
         self.level = int(level)
         self.tlwehost = np.zeros(LVL_WORDS[self.level], dtype=np.uint32)
-        check(lib.cufhe_amd_host_register(_ptr(self.tlwehost), self.tlwehost.nbytes))
-        self.tlwedevices = [DeviceBuffer(LVL_WORDS[self.level], d) for d in range(GetGPUNum())]
+        h = ctypes.c_void_p()
+        check(lib.cufhe_amd_ctxt_create(self.level, _ptr(self.tlwehost), ctypes.byref(h)))
+        self._h = h
+
+    @property
+    def tlwedevices(self):
+        return [lib.cufhe_amd_ctxt_device_ptr(self._h, d) for d in range(GetGPUNum())]
 
     def __del__(self):
         try:
-            lib.cufhe_amd_host_unregister(_ptr(self.tlwehost))
+            if self._h:
+                lib.cufhe_amd_ctxt_destroy(self._h)
+                self._h = None
         except Exception:
             pass
 
 
 def CtxtCopyH2D(c, st):
-    check(lib.cufhe_amd_memcpy_h2d(st.device_id(), st.st(), c.tlwedevices[st.device_id()].ptr,
-                                   _ptr(c.tlwehost), c.tlwehost.nbytes))
+    check(lib.cufhe_amd_enqueue_copy(st.device_id(), st.st(), c._h, 1))
 
 
 def CtxtCopyD2H(c, st):
-    check(lib.cufhe_amd_memcpy_d2h(st.device_id(), st.st(), _ptr(c.tlwehost),
-                                   c.tlwedevices[st.device_id()].ptr, c.tlwehost.nbytes))
+    check(lib.cufhe_amd_enqueue_copy(st.device_id(), st.st(), c._h, 0))
 
 
 def CopyOnHost(out, inp):
     out.tlwehost[:] = inp.tlwehost
 
 
-def _dev(c, st):
-    return c.tlwedevices[st.device_id()].ptr
+def Flush(device=0):
+    """Launch the recorded gates of `device` without waiting (no reference counterpart:
+    the reference launches at call time)."""
+    check(lib.cufhe_amd_flush(device))
 
 
 def _gate(op, copying, out, ins, st):
-    if copying:                                   # src/cufhe_gates_gpu.cu:148-158
-        for c in ins:
-            CtxtCopyH2D(c, st)
-    ptrs = [_dev(c, st) for c in ins] + [None] * (3 - len(ins))
-    check(lib.cufhe_amd_gate(st.device_id(), st.st(), op, out.level, _dev(out, st), *ptrs))
-    if copying:
-        CtxtCopyD2H(out, st)
+    hs = [c._h for c in ins] + [None] * (3 - len(ins))
+    check(lib.cufhe_amd_enqueue_gate(st.device_id(), st.st(), op, 1 if copying else 0, out._h, *hs))
 
 
 def _make2(op, copying):

@@ -358,6 +358,8 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 
 }  // namespace
 
+#include "sched.inc.h"
+
 extern "C" {
 
 const char* cufhe_amd_last_error(void) { return g_err.c_str(); }
@@ -440,6 +442,11 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
 
 int cufhe_amd_cleanup(void)
 {
+    {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        (void)sched_synchronize_all();
+        sched_destroy_all();
+    }
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < g_gpu_num; i++) {
         DeviceState& s = g_dev[i];
@@ -465,6 +472,10 @@ int cufhe_amd_cleanup(void)
 
 int cufhe_amd_synchronize(void)
 {
+    {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        if (int rc = sched_synchronize_all()) return rc;
+    }
     for (int i = 0; i < g_gpu_num; i++) {
         HIP_TRY(hipSetDevice(i));
         HIP_TRY(hipDeviceSynchronize());
@@ -499,6 +510,10 @@ int cufhe_amd_stream_destroy(int device, void* stream)
 int cufhe_amd_stream_query(int device, void* stream)
 {
     if (int rc = use_device(device)) return rc;
+    if (sched_active()) {
+        int q = cufhe_amd_sched_stream_query(device, stream);
+        if (q <= 0) return q;
+    }
     hipError_t e = hipStreamQuery((hipStream_t)stream);
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) return 0;

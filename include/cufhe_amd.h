@@ -93,6 +93,26 @@ int cufhe_amd_gate_list(int device, void* stream, int level, size_t count, const
                         uint32_t* const* outs, const uint32_t* const* in0s,
                         const uint32_t* const* in1s, const uint32_t* const* in2s);
 
+/* ---- the reference's per-gate API on host-visible ciphertexts ----
+ * template<class P> struct Ctxt (include/cufhe_gpu.cuh:102-121): `host_words` is the
+ * caller-owned tlwehost storage (n+1 or N+1 words, kept alive by the caller); the handle
+ * adds the per-GPU device buffers (tlwedevices).  Create after SetGPUNum. */
+typedef struct cufhe_amd_ctxt cufhe_amd_ctxt;
+int cufhe_amd_ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out);
+int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c);
+uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
+/* Nand(out, in0, in1, st) ... NMux, Not, Copy (copying != 0: src/cufhe_gates_gpu.cu:148-158,
+ * inputs taken from tlwehost, result delivered to out's tlwehost) and gNand ... (copying == 0:
+ * :160-167, device buffers only).  The gate is recorded; recorded gates of a device run as
+ * one batch at Synchronize / StreamQuery / dependence / 16384 gates.  Stream order, output
+ * aliasing and completion semantics are those of the reference (see csrc/sched.inc.h). */
+int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
+                           cufhe_amd_ctxt* in0, cufhe_amd_ctxt* in1, cufhe_amd_ctxt* in2);
+/* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207), ordered with the recorded gates */
+int cufhe_amd_enqueue_copy(int device, void* stream, cufhe_amd_ctxt* c, int to_device);
+int cufhe_amd_flush(int device);                        /* launch what is recorded, do not wait */
+int cufhe_amd_sched_stream_query(int device, void* stream);  /* scheduler half of StreamQuery */
+
 /* ---- pieces of the path (TRLWE-level primitives and parity hooks) ----
  * BootstrapTLWE2TRLWE (src/bootstrap_gpu.cu:806-815): tlwe0[count][n+1] -> acc[count][2N]
  * after `steps` CMux steps (steps < 0: all n); also the accumulator parity hook. */

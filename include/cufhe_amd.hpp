@@ -1,0 +1,169 @@
+// cufhe_amd.hpp -- the cuFHE gate API (namespace cufhe) on top of the C ABI of cufhe_amd.h.
+//
+// Drop-in for the gate path of /root/reference/include/cufhe_gpu.cuh: same names, same
+// argument order, same completion rules (results are in `tlwehost` after Synchronize() or
+// once StreamQuery(st) is true), same abort-on-error behaviour
+// (include/details/error_gpu.cuh:40-60).  Host code stays C++; this header contains no HIP.
+//
+//   reference (include/cufhe_gpu.cuh)                 here
+//   SetGPUNum / Initialize / CleanUp / Synchronize    :54-74      same
+//   class Stream, StreamQuery                         :152-191    same (Create/Destroy/st/device_id)
+//   template<class P> struct Ctxt                     :102-121    same members tlwehost, tlwedevices
+//   CtxtCopyH2D / CtxtCopyD2H / CopyOnHost            :193-255    same
+//   And ... NMux, Not, Copy and g-variants            :218-313    same, P in {lvl0param, lvl1param}
+//
+// TFHEpp is not vendored in the reference tree (thirdparties/TFHEpp is an empty submodule),
+// so the parameter structs and TLWE<P> used by the reference's signatures are declared
+// here with the same member names; define CUFHE_AMD_USE_TFHEPP before including this
+// header to take them from <params.hpp>/<cloudkey.hpp> instead (then Initialize(ek) accepts
+// a TFHEpp::EvalKey exactly as the reference does, src/cufhe_gates_gpu.cu:42-47).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "cufhe_amd.h"
+
+#ifdef CUFHE_AMD_USE_TFHEPP
+#include <cloudkey.hpp>
+#include <params.hpp>
+#else
+namespace TFHEpp {
+struct lvl0param {
+    using T = uint32_t;
+    static constexpr uint32_t n = 630, k = 1;
+    static constexpr T mu = 1u << 29;
+};
+struct lvl1param {
+    using T = uint32_t;
+    static constexpr uint32_t nbit = 10, n = 1u << nbit, k = 1, l = 3, Bgbit = 6, Bg = 1u << Bgbit;
+    static constexpr T mu = 1u << 29;
+};
+struct lvl01param { using domainP = lvl0param; using targetP = lvl1param; };
+struct lvl10param {
+    using domainP = lvl1param; using targetP = lvl0param;
+    static constexpr uint32_t t = 8, basebit = 2;
+};
+template <class P> using TLWE = std::array<typename P::T, P::k * P::n + 1>;
+}  // namespace TFHEpp
+#endif
+
+namespace cufhe {
+
+namespace detail {
+inline void check(int rc, const char* what, const char* file, int line)
+{
+    if (rc < 0) {   // CuSafeCall semantics: print and exit(-1)
+        std::fprintf(stderr, "%s failed at %s:%d : %s\n", what, file, line, cufhe_amd_last_error());
+        std::exit(-1);
+    }
+}
+template <class P> constexpr int level_of() { return P::n == TFHEpp::lvl0param::n ? 0 : 1; }
+}  // namespace detail
+#define CUFHE_AMD_CHECK(expr) ::cufhe::detail::check((expr), #expr, __FILE__, __LINE__)
+
+inline int& stream_count() { static int c = 0; return c; }      // `streamCount`
+
+inline void SetGPUNum(int gpuNum) { CUFHE_AMD_CHECK(cufhe_amd_set_gpu_num(gpuNum)); }
+inline int GetGPUNum() { return cufhe_amd_get_gpu_num(); }
+inline void Initialize() { CUFHE_AMD_CHECK(cufhe_amd_initialize_ntt()); }
+/// bk: [n][(k+1)l][k+1][N], ksk: [kN][t][2^(basebit-1)][n+1] torus words (TFHEpp's in-memory layouts)
+inline void Initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
+{
+    CUFHE_AMD_CHECK(cufhe_amd_initialize(bk, bk_words, ksk, ksk_words));
+}
+#ifdef CUFHE_AMD_USE_TFHEPP
+inline void Initialize(const TFHEpp::EvalKey& ek)
+{
+    const auto& bk = ek.getbk<TFHEpp::lvl01param>();
+    const auto& ksk = ek.getiksk<TFHEpp::lvl10param>();
+    Initialize(reinterpret_cast<const uint32_t*>(bk.data()), sizeof(bk) / sizeof(uint32_t),
+               reinterpret_cast<const uint32_t*>(ksk.data()), sizeof(ksk) / sizeof(uint32_t));
+}
+#endif
+inline void CleanUp() { CUFHE_AMD_CHECK(cufhe_amd_cleanup()); }
+inline void Synchronize() { CUFHE_AMD_CHECK(cufhe_amd_synchronize()); }
+
+/// class Stream, include/cufhe_gpu.cuh:152-189 (passed by value, never auto-destroyed)
+class Stream {
+   public:
+    inline Stream() : st_(nullptr), _device_id(stream_count() % GetGPUNum()) { stream_count()++; }
+    inline Stream(int device_id) : st_(nullptr), _device_id(device_id) { stream_count()++; }
+    inline ~Stream() {}
+    inline void Create() { CUFHE_AMD_CHECK(cufhe_amd_stream_create(_device_id, &st_)); }
+    inline void Destroy() { CUFHE_AMD_CHECK(cufhe_amd_stream_destroy(_device_id, st_)); st_ = nullptr; }
+    inline void* st() { return st_; }
+    inline int device_id() { return _device_id; }
+
+   private:
+    void* st_;
+    int _device_id;
+};
+
+inline bool StreamQuery(Stream st)
+{
+    int q = cufhe_amd_stream_query(st.device_id(), st.st());
+    CUFHE_AMD_CHECK(q);
+    return q == 1;
+}
+
+/// template<class P> struct Ctxt, include/cufhe_gpu.cuh:102-121
+template <class P>
+struct Ctxt {
+    Ctxt()
+    {
+        CUFHE_AMD_CHECK(cufhe_amd_ctxt_create(detail::level_of<P>(), tlwehost.data(), &handle));
+        tlwedevices.resize(GetGPUNum());
+        for (int i = 0; i < GetGPUNum(); i++) tlwedevices[i] = cufhe_amd_ctxt_device_ptr(handle, i);
+    }
+    ~Ctxt() { cufhe_amd_ctxt_destroy(handle); }
+    Ctxt(const Ctxt&) = delete;
+    Ctxt& operator=(const Ctxt&) = delete;
+
+    alignas(64) TFHEpp::TLWE<P> tlwehost;
+    std::vector<typename P::T*> tlwedevices;
+    cufhe_amd_ctxt* handle = nullptr;
+};
+
+template <class P> inline void CtxtCopyH2D(Ctxt<P>& c, Stream st) { CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), c.handle, 1)); }
+template <class P> inline void CtxtCopyD2H(Ctxt<P>& c, Stream st) { CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), c.handle, 0)); }
+template <class P> inline void CopyOnHost(Ctxt<P>& out, Ctxt<P>& in) { out.tlwehost = in.tlwehost; }
+
+#define CUFHE_AMD_GATE2(Name, OP)                                                                     \
+    template <class P> inline void Name(Ctxt<P>& out, Ctxt<P>& in0, Ctxt<P>& in1, Stream st)          \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 1, out.handle, in0.handle, in1.handle, nullptr)); } \
+    template <class P> inline void g##Name(Ctxt<P>& out, Ctxt<P>& in0, Ctxt<P>& in1, Stream st)       \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 0, out.handle, in0.handle, in1.handle, nullptr)); }
+#define CUFHE_AMD_GATE1(Name, OP)                                                                     \
+    template <class P> inline void Name(Ctxt<P>& out, Ctxt<P>& in, Stream st)                         \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 1, out.handle, in.handle, nullptr, nullptr)); } \
+    template <class P> inline void g##Name(Ctxt<P>& out, Ctxt<P>& in, Stream st)                      \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 0, out.handle, in.handle, nullptr, nullptr)); }
+#define CUFHE_AMD_GATE3(Name, OP)                                                                     \
+    template <class P> inline void Name(Ctxt<P>& out, Ctxt<P>& inc, Ctxt<P>& in1, Ctxt<P>& in0, Stream st) \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 1, out.handle, inc.handle, in1.handle, in0.handle)); } \
+    template <class P> inline void g##Name(Ctxt<P>& out, Ctxt<P>& inc, Ctxt<P>& in1, Ctxt<P>& in0, Stream st) \
+    { CUFHE_AMD_CHECK(cufhe_amd_enqueue_gate(st.device_id(), st.st(), OP, 0, out.handle, inc.handle, in1.handle, in0.handle)); }
+
+CUFHE_AMD_GATE2(And, CUFHE_AMD_AND)
+CUFHE_AMD_GATE2(AndYN, CUFHE_AMD_ANDYN)
+CUFHE_AMD_GATE2(AndNY, CUFHE_AMD_ANDNY)
+CUFHE_AMD_GATE2(Or, CUFHE_AMD_OR)
+CUFHE_AMD_GATE2(OrYN, CUFHE_AMD_ORYN)
+CUFHE_AMD_GATE2(OrNY, CUFHE_AMD_ORNY)
+CUFHE_AMD_GATE2(Nand, CUFHE_AMD_NAND)
+CUFHE_AMD_GATE2(Nor, CUFHE_AMD_NOR)
+CUFHE_AMD_GATE2(Xor, CUFHE_AMD_XOR)
+CUFHE_AMD_GATE2(Xnor, CUFHE_AMD_XNOR)
+CUFHE_AMD_GATE1(Not, CUFHE_AMD_NOT)
+CUFHE_AMD_GATE1(Copy, CUFHE_AMD_COPY)
+CUFHE_AMD_GATE3(Mux, CUFHE_AMD_MUX)
+CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
+
+#undef CUFHE_AMD_GATE1
+#undef CUFHE_AMD_GATE2
+#undef CUFHE_AMD_GATE3
+
+}  // namespace cufhe

@@ -1,0 +1,176 @@
+// test_gate_api.cpp -- the reference's gate tests, written against include/cufhe_amd.hpp.
+//
+// Follows /root/reference/test/test_gate_gpu.cc:36-91 + test/test_util.h:8-95 (every gate on
+// many streams, decrypt == plain truth function, Ctxt<lvl1param>), test_gate_gpu_multi.cc
+// (same for Ctxt<lvl0param>), test_intensive.cc:21-128 (StreamQuery poll-and-refill over
+// shared inputs) and test_api_gpu.cu:140-159 (chained in-place gates on one stream).
+// Keys, encryption and decryption come from the CPU oracle (test infrastructure); seeds are
+// fixed where the reference uses std::random_device.
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+#include "../../include/cufhe_amd.hpp"
+#include "../../oracle/tfhe_oracle.h"
+
+using namespace cufhe;
+
+static std::vector<uint32_t> g_s0(ORC_n), g_s1(ORC_N);
+static orc_rng g_rng;
+static int g_failures = 0;
+
+template <class P> const uint32_t* key() { return detail::level_of<P>() ? g_s1.data() : g_s0.data(); }
+template <class P> void encrypt(Ctxt<P>& c, int bit) { orc_tlwe_encrypt(&g_rng, detail::level_of<P>(), key<P>(), bit, c.tlwehost.data()); }
+template <class P> int decrypt(Ctxt<P>& c) { return orc_tlwe_decrypt(detail::level_of<P>(), key<P>(), c.tlwehost.data()); }
+
+// test/test_util.h Test<P>(): out = ct[i], inputs ct[i+k*kNumTests]
+template <class P, class Func>
+void Test(const char* type, int op, int arity, Func func, std::vector<Ctxt<P>>& ct, std::vector<uint8_t>& pt,
+          Stream* st, int kNumTests, int kNumSMs, std::mt19937& eng)
+{
+    for (int i = 0; i < 4 * kNumTests; i++) {
+        pt[i] = eng() & 1;
+        encrypt(ct[i], pt[i]);
+    }
+    for (int i = 0; i < kNumTests; i++) func(i, st[i % kNumSMs]);
+    Synchronize();
+    int bad = 0;
+    for (int i = 0; i < kNumTests; i++) {
+        int exp = orc_truth(op, pt[i + kNumTests], arity > 1 ? pt[i + 2 * kNumTests] : 0, arity > 2 ? pt[i + 3 * kNumTests] : 0);
+        if (decrypt(ct[i]) != exp) bad++;
+    }
+    std::printf("%-6s level %d: %s (%d/%d failures)\n", type, detail::level_of<P>(), bad ? "FAIL" : "PASS", bad, kNumTests);
+    g_failures += bad;
+}
+
+template <class P>
+void AllGates(int kNumSMs, int kNumTests, std::mt19937& eng)
+{
+    std::vector<uint8_t> pt(4 * kNumTests);
+    std::vector<Ctxt<P>> ct(4 * kNumTests);
+    Stream* st = new Stream[kNumSMs];
+    for (int i = 0; i < kNumSMs; i++) st[i].Create();
+    const int K = kNumTests;
+#define T2(NAME, OP, FN) Test<P>(NAME, OP, 2, [&](int i, Stream s) { FN<P>(ct[i], ct[i + K], ct[i + 2 * K], s); }, ct, pt, st, K, kNumSMs, eng)
+    T2("NAND", ORC_NAND, Nand); T2("OR", ORC_OR, Or); T2("ORYN", ORC_ORYN, OrYN); T2("ORNY", ORC_ORNY, OrNY);
+    T2("AND", ORC_AND, And); T2("ANDYN", ORC_ANDYN, AndYN); T2("ANDNY", ORC_ANDNY, AndNY);
+    T2("XOR", ORC_XOR, Xor); T2("XNOR", ORC_XNOR, Xnor); T2("NOR", ORC_NOR, Nor);
+#undef T2
+    Test<P>("MUX", ORC_MUX, 3, [&](int i, Stream s) { Mux<P>(ct[i], ct[i + K], ct[i + 2 * K], ct[i + 3 * K], s); }, ct, pt, st, K, kNumSMs, eng);
+    Test<P>("NMUX", ORC_NMUX, 3, [&](int i, Stream s) { NMux<P>(ct[i], ct[i + K], ct[i + 2 * K], ct[i + 3 * K], s); }, ct, pt, st, K, kNumSMs, eng);
+    Test<P>("NOT", ORC_NOT, 1, [&](int i, Stream s) { Not<P>(ct[i], ct[i + K], s); }, ct, pt, st, K, kNumSMs, eng);
+    Test<P>("COPY", ORC_COPY, 1, [&](int i, Stream s) { Copy<P>(ct[i], ct[i + K], s); }, ct, pt, st, K, kNumSMs, eng);
+    for (int i = 0; i < kNumSMs; i++) st[i].Destroy();
+    delete[] st;
+}
+
+// test/test_api_gpu.cu:140-159: chained gates, output aliasing an input, one Synchronize
+void Chained(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl0param;
+    const int kNumTests = 64, kNumSMs = 8;
+    std::vector<Ctxt<P>> a(kNumTests), b(kNumTests), c(kNumTests);
+    std::vector<uint8_t> pa(kNumTests), pb(kNumTests), pc(kNumTests);
+    Stream* st = new Stream[kNumSMs];
+    for (int i = 0; i < kNumSMs; i++) st[i].Create();
+    for (int i = 0; i < kNumTests; i++) {
+        pa[i] = eng() & 1; pb[i] = eng() & 1; pc[i] = eng() & 1;
+        encrypt(a[i], pa[i]); encrypt(b[i], pb[i]); encrypt(c[i], pc[i]);
+    }
+    for (int i = 0; i < kNumTests; i++) {
+        Stream s = st[i % kNumSMs];
+        Nand(a[i], a[i], b[i], s); pa[i] = 1 - pa[i] * pb[i];
+        Or(a[i], a[i], b[i], s);   pa[i] = pa[i] | pb[i];
+        Xor(a[i], a[i], c[i], s);  pa[i] = pa[i] ^ pc[i];
+        Not(a[i], a[i], s);        pa[i] = 1 - pa[i];
+        Mux(a[i], a[i], b[i], c[i], s); pa[i] = pa[i] ? pb[i] : pc[i];
+    }
+    Synchronize();
+    int bad = 0;
+    for (int i = 0; i < kNumTests; i++) bad += decrypt(a[i]) != pa[i];
+    std::printf("chained in-place gates: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, kNumTests);
+    g_failures += bad;
+    for (int i = 0; i < kNumSMs; i++) st[i].Destroy();
+    delete[] st;
+}
+
+// test/test_intensive.cc:21-128: poll StreamQuery and refill, inputs shared by all streams
+void Intensive(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl0param;
+    const int kNumStreams = 200, kRounds = 4;
+    Ctxt<P> in0, in1, inc;
+    int p0 = eng() & 1, p1 = eng() & 1, pcb = eng() & 1;
+    encrypt(in0, p0); encrypt(in1, p1); encrypt(inc, pcb);
+    std::vector<Ctxt<P>> out(kNumStreams);
+    std::vector<int> round(kNumStreams, 0);
+    Stream* st = new Stream[kNumStreams];
+    for (int i = 0; i < kNumStreams; i++) st[i].Create();
+    int bad = 0, done = 0;
+    for (int i = 0; i < kNumStreams; i++) Nand(out[i], in0, in1, st[i]);
+    while (done < kNumStreams) {
+        for (int i = 0; i < kNumStreams; i++) {
+            if (round[i] >= kRounds || !StreamQuery(st[i])) continue;
+            const bool was_nand = (round[i] % 2) == 0;
+            int exp = was_nand ? 1 - p0 * p1 : (pcb ? p1 : p0);
+            bad += decrypt(out[i]) != exp;
+            if (++round[i] == kRounds) { done++; continue; }
+            if (round[i] % 2) Mux(out[i], inc, in1, in0, st[i]);
+            else Nand(out[i], in0, in1, st[i]);
+        }
+    }
+    Synchronize();
+    std::printf("intensive poll-and-refill: %s (%d failures over %d gates)\n", bad ? "FAIL" : "PASS", bad, kNumStreams * kRounds);
+    g_failures += bad;
+    for (int i = 0; i < kNumStreams; i++) st[i].Destroy();
+    delete[] st;
+}
+
+// g-gates: device-resident chaining with explicit copies (include/cufhe_gpu.cuh:282-313)
+void DeviceResident(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl1param;
+    const int K = 32;
+    std::vector<Ctxt<P>> a(K), b(K), o(K);
+    std::vector<uint8_t> pa(K), pb(K);
+    Stream st;
+    st.Create();
+    for (int i = 0; i < K; i++) { pa[i] = eng() & 1; pb[i] = eng() & 1; encrypt(a[i], pa[i]); encrypt(b[i], pb[i]); }
+    for (int i = 0; i < K; i++) {
+        CtxtCopyH2D(a[i], st); CtxtCopyH2D(b[i], st);
+        gAnd(o[i], a[i], b[i], st);
+        gXor(o[i], o[i], b[i], st);
+        CtxtCopyD2H(o[i], st);
+    }
+    Synchronize();
+    int bad = 0;
+    for (int i = 0; i < K; i++) bad += decrypt(o[i]) != ((pa[i] & pb[i]) ^ pb[i]);
+    std::printf("g-gates with explicit copies: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, K);
+    g_failures += bad;
+    st.Destroy();
+}
+
+int main(int argc, char** argv)
+{
+    const int gpus = argc > 1 ? atoi(argv[1]) : 1;
+    const int kNumSMs = 64, kNumTests = kNumSMs * 4;
+    std::mt19937 eng(12345);
+    orc_rng_seed(&g_rng, 999);
+    orc_keygen(1, g_s0.data(), g_s1.data());
+    std::vector<uint32_t> bk(ORC_BK_WORDS), ksk(ORC_KSK_WORDS);
+    orc_bkgen(1001, g_s0.data(), g_s1.data(), bk.data());
+    orc_kskgen(2001, g_s0.data(), g_s1.data(), ksk.data());
+
+    SetGPUNum(gpus);
+    Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
+    AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc
+    AllGates<TFHEpp::lvl0param>(kNumSMs, kNumTests, eng);   // test_gate_gpu_multi.cc
+    Chained(eng);
+    Intensive(eng);
+    DeviceResident(eng);
+    CleanUp();
+    std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
+    return g_failures ? 1 : 0;
+}

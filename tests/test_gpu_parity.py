@@ -131,6 +131,7 @@ def test_reference_api_mirror_streams(engine, keys, oracle):
         api.Or(cts[0][g], cts[0][g], cts[1][g], st)       # ct = Or(ct, b)
     api.Synchronize()
     assert all(api.StreamQuery(s) for s in sts)
+    assert all(c.tlwedevices[0] for c in cts[0])          # tlwedevices: one device buffer per GPU
     for g in range(nst * per):
         a, b = int(bits[0, g]), int(bits[1, g])
         exp = (1 - a * b) | b
@@ -154,3 +155,77 @@ def test_batch_4096_nand_decrypts(engine, keys):
     idx = np.arange(0, count, 64)
     want = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0][idx], ins[1][idx])
     assert np.array_equal(got[idx], want)
+
+
+def test_golden_vectors_on_gpu(engine, keys):
+    """tests/golden/golden_v1.json: every op, both levels, sha256 of the output words."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(ol.ROOT, "tests", "golden", "golden_v1.json")) as f:
+        g = json.load(f)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint32).tobytes()).hexdigest()
+    if sha(keys.bk) != g["keys_sha256"]["bk"] or sha(keys.ksk) != g["keys_sha256"]["ksk"]:
+        pytest.skip("key generation is not bit-reproducible on this host (libm differences)")
+    triples = np.array(g["triples"], np.uint8)
+    for level in (0, 1):
+        ins = [keys.encrypt(triples[:, i], level, seed=5000 + 100 * level + i) for i in range(3)]
+        assert [sha(x) for x in ins] == g["levels"][str(level)]["inputs_sha256"]
+        dins = [_upload(engine, x) for x in ins]
+        dout = engine.api.DeviceBuffer(len(triples) * ol.LVL_WORDS[level])
+        for op, name in enumerate(ol.OPS):
+            engine.gate_batch(op, level, dout, dins[0], dins[1], dins[2], count=len(triples))
+            got = dout.download().reshape(len(triples), -1)
+            assert sha(got) == g["levels"][str(level)]["ops"][name]["out_sha256"], (name, level)
+
+
+def test_scheduler_hazards_and_g_gates(engine, keys, oracle):
+    """Dependences inside what would be one batch: RAW chains, WAR, shared inputs, g-gates
+    with explicit copies, StreamQuery-driven completion."""
+    api = engine.api
+    st = api.Stream()
+    st.Create()
+    a, b, c, o1, o2 = (api.Ctxt(1) for _ in range(5))
+    bits = dict(a=1, b=0, c=1)
+    for ct, name in ((a, "a"), (b, "b"), (c, "c")):
+        ct.tlwehost[:] = keys.encrypt([bits[name]], 1, seed=hash(name) % 1000)[0]
+    api.And(o1, a, b, st)            # o1 = a & b = 0
+    api.Or(o2, o1, c, st)            # RAW on o1: o2 = 0 | 1 = 1
+    api.Xor(a, a, c, st)             # WAR/RAW on a: a = 1 ^ 1 = 0   (And above must have read the old a)
+    api.Nand(o1, o2, a, st)          # WAW on o1: o1 = !(1 & 0) = 1
+    while not api.StreamQuery(st):
+        pass
+    assert [int(keys.decrypt(x.tlwehost, 1)[0]) for x in (o1, o2, a)] == [1, 1, 0]
+    # device-resident chain with explicit copies
+    api.CtxtCopyH2D(b, st); api.CtxtCopyH2D(c, st)
+    api.gOr(o1, b, c, st)            # 0 | 1 = 1
+    api.gAndNY(o2, o1, c, st)        # !1 & 1 = 0
+    api.CtxtCopyD2H(o2, st); api.CtxtCopyD2H(o1, st)
+    api.Synchronize()
+    assert [int(keys.decrypt(x.tlwehost, 1)[0]) for x in (o1, o2)] == [1, 0]
+    st.Destroy()
+
+
+def test_cpp_gate_api_mirror(engine):
+    """tests/cpp/test_gate_api.cpp: the reference's own test programs (test_gate_gpu.cc,
+    test_gate_gpu_multi.cc, test_intensive.cc, test_api_gpu.cu) against include/cufhe_amd.hpp,
+    compiled with plain g++ (host code stays C++)."""
+    import os
+    import subprocess
+    src = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api.cpp")
+    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src,
+                           "-L" + os.path.join(ol.ROOT, "cufhe_amd"), "-lcufhe_amd",
+                           "-L" + os.path.join(ol.ROOT, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(ol.ROOT, "cufhe_amd"),
+                           "-Wl,-rpath," + os.path.join(ol.ROOT, "oracle")])
+    engine.CleanUp()                      # the C++ program owns the device state while it runs
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
