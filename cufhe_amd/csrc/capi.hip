@@ -216,6 +216,11 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
+        lds_opt_in = true;
+    }
     const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
     hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
                        s.bk_ntt, s.tables, steps, acc_dump);
@@ -429,8 +434,8 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
         HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.ksk, ksk, want_ksk * sizeof(uint32_t), hipMemcpyHostToDevice));
         const size_t polys = want_bk / kN;
-        const unsigned blocks = (unsigned)((polys + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
-        hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, 0, s.bk_ntt, d_bk,
+        const unsigned blocks = (unsigned)((polys + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+        hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, 0, s.bk_ntt, d_bk,
                            polys, s.tables, n_inverse_balanced());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
@@ -630,8 +635,8 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
         if (int rc = ensure_ntt(device)) return rc;
     }
     if (count == 0) return 0;
-    const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
-    hipLaunchKernelGGL(polymul_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, (hipStream_t)stream, res, a, b,
+    const unsigned blocks = (unsigned)((count + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(polymul_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, (hipStream_t)stream, res, a, b,
                        (int)count, g_dev[device].tables, n_inverse_balanced());
     HIP_TRY(hipGetLastError());
     return 0;

@@ -49,12 +49,22 @@ struct LinDesc {
     uint32_t pad;
 };
 
-#ifndef CUFHE_AMD_BR_OCC
-#define CUFHE_AMD_BR_OCC 2          // blind-rotate waves per SIMD the register budget is sized for
-#endif
-constexpr int kBrWavesPerBlock = 4;
-constexpr int kBrThreads = 64 * kBrWavesPerBlock;
-constexpr int kBrLdsBytes = kLdsTableBytes + kBrWavesPerBlock * kTileBytes;   // 49920
+// NTT-only kernels (key conversion, product check): 4 waves per workgroup
+constexpr int kNttWavesPerBlock = 4;
+constexpr int kNttThreads = 64 * kNttWavesPerBlock;
+constexpr int kNttLdsBytes = kLdsTableBytes + kNttWavesPerBlock * kTileBytes;   // 49920
+
+// Blind rotate: ONE 8-wave workgroup per CU (2 waves per SIMD).  Its LDS holds the twiddle
+// tables, one transpose tile per wave, the abar list of every wave and a double-buffered
+// 16 KiB TRGSW row shared by the 8 waves (the BK tile staged in LDS).
+constexpr int kBrWavesPerBlock = 8;
+constexpr int kBrThreads = 64 * kBrWavesPerBlock;                               // 512
+constexpr int kBkRowBytes = 2 * kN * 8;                                         // 16384: one TRGSW row (2 polys)
+constexpr int kAbarBytes = 1280;                                                // 630 x u16, padded
+constexpr int kBrLdsTiles = kLdsTableBytes;
+constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
+constexpr int kBrLdsBk = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;
+constexpr int kBrLdsBytes = kBrLdsBk + 2 * kBkRowBytes;                          // 126720
 
 // gadget decomposition constants, include/gatebootstrapping_gpu.cuh:18-27,145-150
 __host__ __device__ constexpr uint32_t decomp_offset()
@@ -69,7 +79,7 @@ __host__ __device__ constexpr uint32_t decomp_offset()
 // (see fpfield.h), transformed, scaled by N^-1 (so the inverse transform needs no
 // scaling) and stored centred, in layout C order: [poly][q = reg/2][lane][reg & 1].
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBrThreads) void bk_to_ntt_kernel(
+__global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
     double* __restrict__ bk_ntt, const uint32_t* __restrict__ bk, size_t polys,
     const NttTables* __restrict__ gt, double n_inverse)
 {
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(kBrThreads) void bk_to_ntt_kernel(
     load_tables_to_lds(tabs, gt);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t poly = (size_t)blockIdx.x * kBrWavesPerBlock + wave;
+    const size_t poly = (size_t)blockIdx.x * kNttWavesPerBlock + wave;
     if (poly >= polys) return;
     const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
     double x[kRegs];
@@ -98,14 +108,6 @@ __global__ __launch_bounds__(kBrThreads) void bk_to_ntt_kernel(
 // ----------------------------------------------------------------------------------
 // Blind rotate + sample extract, one wave per rotation.
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t uniform_select10(const uint32_t (&v)[10], int idx)
-{
-    uint32_t s = v[0];
-#pragma unroll
-    for (int k = 1; k < 10; k++) s = (idx == k) ? v[k] : s;
-    return s;
-}
-
 // acc_j -> digits of ((X^abar - 1) acc_j), include/gatebootstrapping_gpu.cuh:157-181.
 // The rotation goes through the wave's LDS tile: the polynomial is written twice
 // (e and e + N) so the rotated read is base + 256*r with no wrap-around arithmetic.
@@ -129,31 +131,75 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
     }
 }
 
+// x (spectrum of one digit polynomial, layout C) times the two polynomials of one TRGSW row,
+// read from the row buffer the workgroup staged in LDS: [out<2][q<8][lane<64][2] doubles
 __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double (&A1)[kRegs],
-                                                     const double (&x)[kRegs],
-                                                     const double2* __restrict__ row, int lane)
+                                                     const double (&x)[kRegs], const char* row_lane)
 {
-    // row: two NTT-domain polynomials (out = 0, 1) of one TRGSW row, layout C
+#ifdef CUFHE_AMD_ABL_NO_BK
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const double2 b0 = row[q * 64 + lane];
+        A0[2 * q] += fpf::mulmod_wide(x[2 * q], 1234567.0 + q);
+        A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], 7654321.0 + q);
+        A1[2 * q] += fpf::mulmod_wide(x[2 * q], 2234567.0 + q);
+        A1[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], 8654321.0 + q);
+    }
+    (void)row_lane;
+    return;
+#endif
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const double2 b0 = *(const double2*)(row_lane + q * 1024);
         A0[2 * q] += fpf::mulmod_wide(x[2 * q], b0.x);
         A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b0.y);
     }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const double2 b1 = row[512 + q * 64 + lane];
+        const double2 b1 = *(const double2*)(row_lane + 8192 + q * 1024);
         A1[2 * q] += fpf::mulmod_wide(x[2 * q], b1.x);
         A1[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b1.y);
     }
 }
+
+// The workgroup's row pipeline.  Row R (0 .. 6*steps-1) of the bootstrapping key is the
+// 16 KiB block bk_ntt[R * 2048 ..]; it is copied by LDS-DMA into buffer R & 1, two 1 KiB
+// pieces per wave.  Protocol per row R (every wave):
+//     ... forward NTT of row R's digit polynomial ...
+//     s_waitcnt vmcnt(0)     this wave's pieces of row R have landed (issued a row ago)
+//     s_barrier              => every wave's pieces have landed, and every wave has finished
+//                               reading row R-1 (its pointwise precedes this barrier)
+//     issue row R+1 into buffer (R+1) & 1   (the buffer row R-1 was read from)
+//     pointwise on buffer R & 1
+struct RowPipe {
+    const char* bk;          // NTT-domain key, bytes
+    char* buf;               // LDS: 2 x kBkRowBytes
+    int wave, lane, total_rows;
+    __device__ __forceinline__ void issue(int R) const
+    {
+        if (R >= total_rows) return;
+        const char* src = bk + (size_t)R * kBkRowBytes + lane * 16;
+        char* dst = buf + (R & 1) * kBkRowBytes;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int piece = 2 * wave + c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ const char* acquire(int R) const
+    {
+        __syncthreads();     // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+        issue(R + 1);
+        return buf + (R & 1) * kBkRowBytes + lane * 16;
+    }
+};
 
 // one component j: rotate/subtract/decompose, then l forward NTTs, each multiplied into
 // both accumulators (include/gatebootstrapping_gpu.cuh:153-224)
 __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)[kRegs],
                                                const uint32_t (&accj)[kRegs], const WaveCtx& ctx,
                                                char* tile, int lane, uint32_t abar,
-                                               const double2* __restrict__ rows)
+                                               const RowPipe& pipe, int first_row)
 {
     uint32_t temp[kRegs];
     rotate_sub(temp, accj, tile, lane, abar);
@@ -165,7 +211,8 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)((int32_t)((temp[r] >> shift) & ((1u << kBgbit) - 1)) - (1 << (kBgbit - 1)));
         ntt_forward(x, ctx);
-        pointwise_accumulate(A0, A1, x, rows + (size_t)d * kN, lane);
+        const char* row_lane = pipe.acquire(first_row + d);
+        pointwise_accumulate(A0, A1, x, row_lane);
     }
 }
 
@@ -180,25 +227,29 @@ __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&a
 
 // descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at
 // index 0).  steps < n is only used by the parity tests; acc_dump (optional) receives the
-// raw accumulator (2N words per rotation) instead of nothing.
-__global__ __launch_bounds__(kBrThreads, CUFHE_AMD_BR_OCC) void blind_rotate_kernel(
+// raw accumulator (2N words per rotation).  All 8 waves of a workgroup walk the key in
+// lock-step (one barrier per TRGSW row); waves past `count` run a clamped duplicate and
+// store nothing.
+__global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tabs = (double*)smem;
     load_tables_to_lds(tabs, gt);
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * kBrWavesPerBlock + wave;
-    if (g >= count) return;
-    char* tile = smem + kLdsTableBytes + wave * kTileBytes;
+    int g = blockIdx.x * kBrWavesPerBlock + wave;
+    const bool live = g < count;
+    if (!live) g = count - 1;
+    char* tile = smem + kBrLdsTiles + wave * kTileBytes;
+    uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
     const WaveCtx ctx = make_wave_ctx(tile, tabs, gt, lane);
+    const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows};
+    pipe.issue(0);
 
     const LinDesc d = descs[g];
     // pre-add (gate linear part) and modulus switch, :316-345
-    uint32_t ab[10];
     uint32_t bword = 0;
 #pragma unroll
     for (int rr = 0; rr < 10; rr++) {
@@ -206,7 +257,7 @@ __global__ __launch_bounds__(kBrThreads, CUFHE_AMD_BR_OCC) void blind_rotate_ker
         uint32_t c = 0;
         if (i <= kLvl0N) c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
         if (rr == 9) bword = c;
-        ab[rr] = (c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit);
+        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit));
     }
     bword = __builtin_amdgcn_readlane(bword, kLvl0N - 64 * 9) + d.off;
     const uint32_t bbar = 2 * kN - (bword >> (32 - 1 - kNbit));
@@ -220,24 +271,24 @@ __global__ __launch_bounds__(kBrThreads, CUFHE_AMD_BR_OCC) void blind_rotate_ker
         const bool neg = (bbar != 2 * kN) && ((e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
         acc1[r] = neg ? 0u - kMu : kMu;
     }
+    __syncthreads();          // tables staged; abar list visible (own wave only, but cheap)
 
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
-        const uint32_t sel = uniform_select10(ab, i >> 6);
-        const uint32_t abar = __builtin_amdgcn_readlane(sel, i & 63);
-        if (abar == 0) continue;                   // (X^0 - 1) acc = 0: all digits are zero
-        const double2* bk_i = (const double2*)(bk_ntt + (size_t)i * kBkStepDoubles);
+        // abar = 0 needs no special case: all digits are zero and the step adds nothing
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
         double A0[kRegs], A1[kRegs];
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
-        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, bk_i);
+        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows);
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = fpf::reduce(A0[r]); A1[r] = fpf::reduce(A1[r]); }
-        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, bk_i + (size_t)kL * kN);
+        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL);
         inverse_and_add(A0, acc0, ctx);
         inverse_and_add(A1, acc1, ctx);
     }
 
+    if (!live) return;
     if (acc_dump) {
         uint32_t* o = acc_dump + (size_t)g * 2 * kN;
 #pragma unroll
@@ -335,7 +386,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const LinDesc* __restrict_
 // device-side mirror of test/test_polynomial_mult_1024.cu (ForwardNTT, PointwiseMultiply,
 // InverseNTT kernels).  Also exposes the raw forward+inverse round trip.
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBrThreads) void polymul_kernel(
+__global__ __launch_bounds__(kNttThreads) void polymul_kernel(
     uint32_t* __restrict__ res, const int32_t* __restrict__ a, const uint32_t* __restrict__ b,
     int count, const NttTables* __restrict__ gt, double n_inverse)
 {
@@ -344,7 +395,7 @@ __global__ __launch_bounds__(kBrThreads) void polymul_kernel(
     load_tables_to_lds(tabs, gt);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * kBrWavesPerBlock + wave;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
     if (g >= count) return;
     const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
     double x[kRegs], y[kRegs];

@@ -94,7 +94,11 @@ __device__ __forceinline__ WaveCtx make_wave_ctx(char* tile, const double* lds_t
     return c;
 }
 
+#ifdef CUFHE_AMD_ABL_NO_TW
+__device__ __forceinline__ double lds_ld(const char* p, int off) { return 12345678.0 + (double)off + (double)(uintptr_t)p * 1e-30; }
+#else
 __device__ __forceinline__ double lds_ld(const char* p, int off) { return *(const double*)(p + off); }
+#endif
 __device__ __forceinline__ void lds_st(char* p, int off, double v) { *(double*)(p + off) = v; }
 
 // ---- butterflies -----------------------------------------------------------------
@@ -177,11 +181,18 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
 // ---- layout changes through the wave-private LDS tile -----------------------------
 // DS operations of one wave execute in issue order, so a wave may reuse its own tile
 // without any barrier.
+// Ablation switches (timing-only diagnostic builds, results are wrong when set):
+//   CUFHE_AMD_ABL_NO_XPOSE  skip the LDS transposes     CUFHE_AMD_ABL_NO_TW  constant twiddles
+//   CUFHE_AMD_ABL_NO_BK     (kernels.hip.h) no bootstrapping-key loads
+#ifdef CUFHE_AMD_ABL_NO_XPOSE
+#define CUFHE_AMD_XPOSE(WBASE, WSTRIDE, RBASE, RSTRIDE) { asm volatile("" ::: "memory"); }
+#else
 #define CUFHE_AMD_XPOSE(WBASE, WSTRIDE, RBASE, RSTRIDE)                              \
     {                                                                                \
         _Pragma("unroll") for (int r = 0; r < kRegs; r++) lds_st(WBASE, (WSTRIDE) * r, x[r]); \
         _Pragma("unroll") for (int r = 0; r < kRegs; r++) x[r] = lds_ld(RBASE, (RSTRIDE) * r); \
     }
+#endif
 
 // forward: x in layout A (natural order), out in layout C (spectrum order)
 __device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
