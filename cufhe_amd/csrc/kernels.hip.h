@@ -64,7 +64,8 @@ constexpr int kAbarBytes = 1280;                                                
 constexpr int kBrLdsTiles = kLdsTableBytes;
 constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
 constexpr int kBrLdsBk = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;
-constexpr int kBrLdsBytes = kBrLdsBk + 2 * kBkRowBytes;                          // 126720
+constexpr int kBkRowBuffers = 3;
+constexpr int kBrLdsBytes = kBrLdsBk + kBkRowBuffers * kBkRowBytes;              // 143104
 
 // gadget decomposition constants, include/gatebootstrapping_gpu.cuh:18-27,145-150
 __host__ __device__ constexpr uint32_t decomp_offset()
@@ -162,23 +163,30 @@ __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double
 }
 
 // The workgroup's row pipeline.  Row R (0 .. 6*steps-1) of the bootstrapping key is the
-// 16 KiB block bk_ntt[R * 2048 ..]; it is copied by LDS-DMA into buffer R & 1, two 1 KiB
-// pieces per wave.  Protocol per row R (every wave):
-//     ... forward NTT of row R's digit polynomial ...
+// 16 KiB block bk_ntt[R * 2048 ..]; it is copied by LDS-DMA into buffer R % 3, two 1 KiB
+// pieces per wave, one row ahead of its use.  Every wave passes exactly one barrier per row:
 //     s_waitcnt vmcnt(0)     this wave's pieces of row R have landed (issued a row ago)
-//     s_barrier              => every wave's pieces have landed, and every wave has finished
-//                               reading row R-1 (its pointwise precedes this barrier)
-//     issue row R+1 into buffer (R+1) & 1   (the buffer row R-1 was read from)
-//     pointwise on buffer R & 1
+//     s_barrier              => every wave's pieces of row R have landed
+//     issue row R+1 into buffer (R+1) % 3
+// Waves 0-3 ("early") take that barrier between the forward NTT of row R and its pointwise
+// product; waves 4-7 ("late") take the SAME barrier two phases earlier in their own
+// program, between stages 0-3 and the first transpose of the NTT of row R.  The late half
+// therefore trails the early half by half a row for the whole kernel: on every SIMD (wave
+// w and w+4 share one) a wave that waits on an LDS transpose sits beside a wave in a pure
+// FP64 phase, instead of two waves in lock-step waiting together (measured: transposes
+// cost 21 % of the kernel in lock-step).  Three buffers make this safe: buffer (R+1) % 3
+// last held row R-2, whose last reader (a late wave's pointwise) precedes that wave's
+// barrier R-1.
 struct RowPipe {
     const char* bk;          // NTT-domain key, bytes
-    char* buf;               // LDS: 2 x kBkRowBytes
+    char* buf;               // LDS: kBkRowBuffers x kBkRowBytes
     int wave, lane, total_rows;
+    bool late;
     __device__ __forceinline__ void issue(int R) const
     {
         if (R >= total_rows) return;
         const char* src = bk + (size_t)R * kBkRowBytes + lane * 16;
-        char* dst = buf + (R & 1) * kBkRowBytes;
+        char* dst = buf + (R % kBkRowBuffers) * kBkRowBytes;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const int piece = 2 * wave + c;
@@ -186,11 +194,14 @@ struct RowPipe {
                                              (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
         }
     }
-    __device__ __forceinline__ const char* acquire(int R) const
+    __device__ __forceinline__ void sync(int R) const
     {
         __syncthreads();     // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
         issue(R + 1);
-        return buf + (R & 1) * kBkRowBytes + lane * 16;
+    }
+    __device__ __forceinline__ const char* row(int R) const
+    {
+        return buf + (R % kBkRowBuffers) * kBkRowBytes + lane * 16;
     }
 };
 
@@ -210,9 +221,11 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)((int32_t)((temp[r] >> shift) & ((1u << kBgbit) - 1)) - (1 << (kBgbit - 1)));
-        ntt_forward(x, ctx);
-        const char* row_lane = pipe.acquire(first_row + d);
-        pointwise_accumulate(A0, A1, x, row_lane);
+        ntt_forward_a(x, ctx);
+        if (pipe.late) pipe.sync(first_row + d);
+        ntt_forward_bc(x, ctx);
+        if (!pipe.late) pipe.sync(first_row + d);
+        pointwise_accumulate(A0, A1, x, pipe.row(first_row + d));
     }
 }
 
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     char* tile = smem + kBrLdsTiles + wave * kTileBytes;
     uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
     const WaveCtx ctx = make_wave_ctx(tile, tabs, gt, lane);
-    const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows};
+    const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows, wave >= kBrWavesPerBlock / 2};
     pipe.issue(0);
 
     const LinDesc d = descs[g];

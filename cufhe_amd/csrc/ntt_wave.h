@@ -194,37 +194,68 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
     }
 #endif
 
-// forward: x in layout A (natural order), out in layout C (spectrum order)
-__device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
+struct TwArr {                       // twiddles already in registers
+    const double* t;
+    __device__ __forceinline__ double operator()(int k) const { return t[k]; }
+};
+
+// The per-lane twiddles of a phase are fetched into registers BEFORE the transpose that
+// precedes the phase: their LDS latency then overlaps the transpose instead of being paid
+// butterfly by butterfly (measured: twiddle fetches placed at their use cost 38 % of the
+// kernel, profiles/r01_ablation.md).
+
+// forward, phase A: stages 0-3 in layout A (natural order in)
+__device__ __forceinline__ void ntt_forward_a(double (&x)[kRegs], const WaveCtx& c)
 {
     ct_four_stages(x, TwUniform{c.gt->tu_fwd});
+}
+// forward, phases B and C: out in layout C (spectrum order)
+__device__ __forceinline__ void ntt_forward_bc(double (&x)[kRegs], const WaveCtx& c)
+{
+    double twb[kTbCount];
+#pragma unroll
+    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_fwd, 128 * k);
     CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
-    ct_four_stages(x, TwLane{c.tb_fwd});
+    ct_four_stages(x, TwArr{twb});
+    double twc[kTcCount];
+#pragma unroll
+    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
     CUFHE_AMD_XPOSE(c.b65, 32, c.c65, 8)             // B -> C
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        const double w = lds_ld(c.tc_fwd, 512 * g);
 #pragma unroll
-        for (int r = 0; r < 2; r++) ct_bfly<true>(x[4 * g + r], x[4 * g + r + 2], w);
+        for (int r = 0; r < 2; r++) ct_bfly<true>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
     }
 #pragma unroll
-    for (int g = 0; g < 8; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], lds_ld(c.tc_fwd, 512 * (4 + g)));
+    for (int g = 0; g < 8; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], twc[4 + g]);
+}
+__device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
+{
+    ntt_forward_a(x, c);
+    ntt_forward_bc(x, c);
 }
 
 // inverse: x in layout C with |x| <= p/2, out in layout A with |x| <= 2p, NOT scaled by
 // 1/N (N^-1 is folded into the NTT-domain bootstrapping key)
 __device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c)
 {
+    {
+        double twc[kTcCount];
 #pragma unroll
-    for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], lds_ld(c.tc_inv, 512 * (4 + g)));
+        for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const double w = lds_ld(c.tc_inv, 512 * g);
+        for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], twc[4 + g]);
 #pragma unroll
-        for (int r = 0; r < 2; r++) gs_bfly<false>(x[4 * g + r], x[4 * g + r + 2], w);
+        for (int g = 0; g < 4; g++) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) gs_bfly<false>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
+        }
     }
+    double twb[kTbCount];
+#pragma unroll
+    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_inv, 128 * k);
     CUFHE_AMD_XPOSE(c.c66, 8, c.b66, 32)             // C -> B
-    gs_four_stages(x, TwLane{c.tb_inv});
+    gs_four_stages(x, TwArr{twb});
     CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
     gs_four_stages(x, TwUniform{c.gt->tu_inv});
 }
