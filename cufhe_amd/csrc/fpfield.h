@@ -10,14 +10,21 @@
 // Bound: digits are in [-Bg/2, Bg/2) and the bootstrapping key is taken as SIGNED
 // 32-bit torus words (congruent mod 2^32 to the reference's unsigned reading,
 // include/ntt_gpu/ntt_gpuntt.cuh:495-496, and the result is only used mod 2^32), so
-// |sum| <= (k+1) l N (Bg/2) 2^31 = 6144 * 32 * 2^31 = 2^48.585 < p/2 = 2^48.628.
+// |sum| <= (k+1) l N (Bg/2) 2^31 = 6144 * 32 * 2^31 = 2^48.585 < p/2 = 2^48.638.
+//
+// The prime has the form p = zeta^4 + 1 (zeta = 5440): zeta is then a primitive 8th root
+// of unity of 13 bits and I = zeta^2 a 4th root of 25 bits, and psi (the 2048-th root) is
+// chosen with psi^256 = zeta.  The twiddles of the first forward stage (I) and of half of
+// the second (zeta) are so small that their products with gadget digits are exact in a
+// double without any reduction: 3 FP64 operations per butterfly instead of 8.
 //
 // Representation: a residue is ANY integer-valued double x with |x| < 2^53 that is
 // congruent to the value mod p ("lazy, balanced").  Additions never reduce; the
 // multiplications below reduce as a side effect.  Every intermediate is an exact
 // integer, so results do not depend on evaluation order.  In units of p:
-//   2^53 / p = 10.356   (any value, additive headroom)
-//   2^52 / p =  5.178   (largest |a| mulmod() accepts)
+//   2^53 / p = 10.285   (any value, additive headroom)
+//   2^52 / p =  5.142   (largest |a| mulmod() accepts)
+//   p / 2^53 = 0.09723  (growth of a multiplication result per unit of input)
 #pragma once
 #include <stdint.h>
 
@@ -29,14 +36,17 @@
 
 namespace fpf {
 
-constexpr uint64_t P_U64 = 869757679894529ull;   // prime, = 1 (mod 2^16), 2^49.63
-constexpr uint64_t PSI_2048 = 594421426086543ull; // primitive 2048-th root of unity (3^((p-1)/2048))
-constexpr double P = 869757679894529.0;
-constexpr double PINV = 0x1.4b643eeb017dep-50;    // fl(1/p)
+constexpr uint64_t ZETA8 = 5440ull;               // primitive 8th root of unity
+constexpr uint64_t P_U64 = 875781160960001ull;    // zeta^4 + 1, prime, = 1 (mod 2^12), 2^49.64
+constexpr uint64_t PSI_2048 = 423584205157050ull; // primitive 2048-th root of unity with psi^256 = zeta
+constexpr double P = 875781160960001.0;
+constexpr double PINV = 0x1.491cc17c934a8p-50;    // fl(1/p)
+constexpr double ROOT4 = 29593600.0;              // I = zeta^2 = psi^512
+constexpr double ROOT8 = 5440.0;                  // zeta = psi^256
 constexpr double MAGIC0 = 6755399441055744.0;     // 1.5 * 2^52: adding it rounds to an integer
 constexpr double MAGIC1 = 13510798882111488.0;    // 1.5 * 2^53: rounds to an even integer
 
-// a*w mod p for |a| < 2^52 (5.178 p), |w| <= p/2.  |result| <= (0.5 + 0.097 |a|/p) p.
+// a*w mod p for |a| < 2^52 (5.142 p), |w| <= p/2.  |result| <= (0.5 + 0.0973 |a|/p) p.
 FPF_HD double mulmod(double a, double w)
 {
     const double h = a * w;
@@ -45,8 +55,8 @@ FPF_HD double mulmod(double a, double w)
     const double r = __builtin_fma(-q, P, h);            // exact: |h - q p| < 2^53, integer
     return r + l;
 }
-// Same for |a| < 2^53 (10.356 p): q is rounded to an even integer, so
-// |result| <= (1 + 0.097 |a|/p) p.
+// Same for |a| < 2^53 (10.285 p): q is rounded to an even integer, so
+// |result| <= (1 + 0.0973 |a|/p) p.
 FPF_HD double mulmod_wide(double a, double w)
 {
     const double h = a * w;

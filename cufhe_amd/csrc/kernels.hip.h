@@ -74,6 +74,14 @@ __host__ __device__ constexpr uint32_t decomp_offset()
     for (int i = 1; i <= kL; i++) o += (1u << (kBgbit - 1)) << (32 - i * kBgbit);
     return o + (1u << (32 - kL * kBgbit - 1));     // + roundoffset
 }
+// digit_d = field_d(t) - Bg/2 = sign-extended field_d(t ^ mask): flipping the top bit of each
+// Bgbit-wide field adds Bg/2 modulo Bg without carrying into the next digit
+__host__ __device__ constexpr uint32_t decomp_signmask()
+{
+    uint32_t m = 0;
+    for (int i = 1; i <= kL; i++) m |= (1u << (kBgbit - 1)) << (32 - i * kBgbit);
+    return m;
+}
 
 // ----------------------------------------------------------------------------------
 // BK -> NTT domain.  One wave per torus polynomial.  Values are read as SIGNED words
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
     double x[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) x[r] = (double)(int32_t)bk[poly * kN + lane + 64 * r];
-    ntt_forward(x, ctx);
+    ntt_forward<false>(x, ctx);
     double2* dst = (double2*)(bk_ntt + poly * kN);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -128,7 +136,7 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
     for (int r = 0; r < kRegs; r++) {
         const uint32_t v = *(const uint32_t*)(rbase + 256 * r);
         const bool neg = (lane < alo - 64 * r) != ahi;      // (e < abar mod N) xor (abar >= N)
-        temp[r] = (neg ? 0u - v : v) - acc[r] + decomp_offset();
+        temp[r] = ((neg ? 0u - v : v) - acc[r] + decomp_offset()) ^ decomp_signmask();
     }
 }
 
@@ -216,14 +224,14 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
     rotate_sub(temp, accj, tile, lane, abar);
 #pragma unroll 1
     for (int d = 0; d < kL; d++) {
-        const int shift = 32 - (d + 1) * kBgbit;
+        const int lsh = d * kBgbit;                 // bring digit d to the top, then arithmetic shift
         double x[kRegs];
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
-            x[r] = (double)((int32_t)((temp[r] >> shift) & ((1u << kBgbit) - 1)) - (1 << (kBgbit - 1)));
-        ntt_forward_a(x, ctx);
+            x[r] = (double)((int32_t)(temp[r] << lsh) >> (32 - kBgbit));
+        ntt_forward_a<true>(x, ctx);
         if (pipe.late) pipe.sync(first_row + d);
-        ntt_forward_bc(x, ctx);
+        ntt_forward_bc<false>(x, ctx);
         if (!pipe.late) pipe.sync(first_row + d);
         pointwise_accumulate(A0, A1, x, pipe.row(first_row + d));
     }
@@ -293,9 +301,8 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
         double A0[kRegs], A1[kRegs];
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
+        // six wide products of at most 1.702 p each: 10.21 p < 2^53, no reduction in between
         cmux_component(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows);
-#pragma unroll
-        for (int r = 0; r < kRegs; r++) { A0[r] = fpf::reduce(A0[r]); A1[r] = fpf::reduce(A1[r]); }
         cmux_component(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL);
         inverse_and_add(A0, acc0, ctx);
         inverse_and_add(A1, acc1, ctx);
@@ -417,8 +424,8 @@ __global__ __launch_bounds__(kNttThreads) void polymul_kernel(
         x[r] = (double)a[(size_t)g * kN + lane + 64 * r];
         y[r] = (double)(int32_t)b[(size_t)g * kN + lane + 64 * r];
     }
-    ntt_forward(x, ctx);
-    ntt_forward(y, ctx);
+    ntt_forward<false>(x, ctx);
+    ntt_forward<false>(y, ctx);
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {
         y[r] = fpf::reduce(fpf::mulmod_wide(y[r], n_inverse));

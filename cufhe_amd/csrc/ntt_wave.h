@@ -22,11 +22,16 @@
 //   conflicts on ds_write_b64, which the store's own issue time covers.
 //
 // Lazy-reduction schedule (bounds in units of p, see fpfield.h; checked on the host by
-// tests/host_model.cpp through tests/test_fpfield.py):
-//   forward  in <= 2^-18      after s0..s9: .5 1.05 1.65 2.31 3.04 3.83 4.70 5.66 7.2 8.9
-//            (stages 8,9 use mulmod_wide because their inputs exceed 5.178)
+// tests/host/host_model.cpp through tests/test_fpfield.py):
+//   forward, gadget digits in (|x| <= 32): stage 0 and the zeta half of stage 1 multiply by
+//            25- and 13-bit roots without reducing (values stay below 2^43); then
+//            after s1..s9: .5 1.05 1.66 2.32 3.04 3.84 4.71 5.67 7.22
+//            (only stage 9 needs mulmod_wide: its input 5.67 exceeds 5.142)
+//   forward, 32-bit words in (key conversion): every stage reduces; .5 1.05 ... 5.67 7.22 8.92
+//            with stages 8 and 9 wide
 //   inverse  in <= .5         s9 1.0  s8 2.0  s7 4.0  s6 8.0(wide) reduce  s5 1.0  s4 2.0
 //            s3 4.0  s2 8.0(wide) reduce  s1 1.0  s0 2.0
+//   pointwise: digits spectrum <= 7.22 -> each wide product <= 1.702, six of them 10.21 < 10.285
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fpfield.h"
@@ -129,19 +134,38 @@ struct TwLane {                      // stages 4-7: tb[k][lambda] from LDS
 
 // Four radix-2 stages on register strides 8,4,2,1 with twiddles tw(0..14)
 // (tw(0) | tw(1..2) | tw(3..6) | tw(7..14)); identical in layouts A and B.
-template <class TW>
+// multiplication by a root so small that the product is exact: no reduction
+__device__ __forceinline__ void ct_bfly_exact(double& a, double& b, double w)
+{
+    const double t = b * w;
+    const double u = a;
+    a = u + t;
+    b = u - t;
+}
+
+// SMALL_IN: |x| <= 32 on entry and the twiddles are those of stages 0-3 (tw(0) = I,
+// tw(1) = zeta): stage 0 and the first group of stage 1 use ct_bfly_exact.
+template <bool SMALL_IN, class TW>
 __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
 {
-    {
-        const double w = tw(0);
+    if (SMALL_IN) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) ct_bfly<false>(x[r], x[r + 8], w);
-    }
+        for (int r = 0; r < 8; r++) ct_bfly_exact(x[r], x[r + 8], fpf::ROOT4);
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        const double w = tw(1 + g);
+        for (int r = 0; r < 4; r++) ct_bfly_exact(x[r], x[r + 4], fpf::ROOT8);
+        const double w = tw(2);
 #pragma unroll
-        for (int r = 0; r < 4; r++) ct_bfly<false>(x[8 * g + r], x[8 * g + r + 4], w);
+        for (int r = 0; r < 4; r++) ct_bfly<false>(x[8 + r], x[8 + r + 4], w);
+    } else {
+        const double w0 = tw(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ct_bfly<false>(x[r], x[r + 8], w0);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const double w = tw(1 + g);
+#pragma unroll
+            for (int r = 0; r < 4; r++) ct_bfly<false>(x[8 * g + r], x[8 * g + r + 4], w);
+        }
     }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -205,18 +229,21 @@ struct TwArr {                       // twiddles already in registers
 // kernel, profiles/r01_ablation.md).
 
 // forward, phase A: stages 0-3 in layout A (natural order in)
+template <bool SMALL_IN>
 __device__ __forceinline__ void ntt_forward_a(double (&x)[kRegs], const WaveCtx& c)
 {
-    ct_four_stages(x, TwUniform{c.gt->tu_fwd});
+    ct_four_stages<SMALL_IN>(x, TwUniform{c.gt->tu_fwd});
 }
-// forward, phases B and C: out in layout C (spectrum order)
+// forward, phases B and C: out in layout C (spectrum order).  WIDE8: stage 8 inputs may
+// exceed 5.142 p (true for 32-bit inputs, not for gadget digits).
+template <bool WIDE8>
 __device__ __forceinline__ void ntt_forward_bc(double (&x)[kRegs], const WaveCtx& c)
 {
     double twb[kTbCount];
 #pragma unroll
     for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_fwd, 128 * k);
     CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
-    ct_four_stages(x, TwArr{twb});
+    ct_four_stages<false>(x, TwArr{twb});
     double twc[kTcCount];
 #pragma unroll
     for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
@@ -224,15 +251,17 @@ __device__ __forceinline__ void ntt_forward_bc(double (&x)[kRegs], const WaveCtx
 #pragma unroll
     for (int g = 0; g < 4; g++) {
 #pragma unroll
-        for (int r = 0; r < 2; r++) ct_bfly<true>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
+        for (int r = 0; r < 2; r++) ct_bfly<WIDE8>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
     }
 #pragma unroll
     for (int g = 0; g < 8; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], twc[4 + g]);
 }
+// SMALL_IN: the input is a gadget-digit polynomial (|x| <= 32); otherwise 32-bit words
+template <bool SMALL_IN>
 __device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
 {
-    ntt_forward_a(x, c);
-    ntt_forward_bc(x, c);
+    ntt_forward_a<SMALL_IN>(x, c);
+    ntt_forward_bc<!SMALL_IN>(x, c);
 }
 
 // inverse: x in layout C with |x| <= p/2, out in layout A with |x| <= 2p, NOT scaled by
