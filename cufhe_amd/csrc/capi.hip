@@ -428,11 +428,15 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
             s.keys_ready = false;
         }
         HIP_TRY(hipMalloc((void**)&s.bk_ntt, want_bk * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&s.ksk, want_ksk * sizeof(uint32_t)));
+        const size_t ksk_rows = want_ksk / kKsRowWords;
+        HIP_TRY(hipMalloc((void**)&s.ksk, ksk_rows * kKsRowPad * sizeof(uint32_t)));
         uint32_t* d_bk = nullptr;
         HIP_TRY(hipMalloc((void**)&d_bk, want_bk * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s.ksk, ksk, want_ksk * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // KeySwitchingKeyToDevice (src/keyswitch_gpu.cu:6-16), rows padded 631 -> 640 words
+        HIP_TRY(hipMemset(s.ksk, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy2D(s.ksk, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
+                            kKsRowWords * sizeof(uint32_t), ksk_rows, hipMemcpyHostToDevice));
         const size_t polys = want_bk / kN;
         const unsigned blocks = (unsigned)((polys + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
         hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, 0, s.bk_ntt, d_bk,

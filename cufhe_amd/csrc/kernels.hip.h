@@ -330,21 +330,31 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 }
 
 // ----------------------------------------------------------------------------------
-// Key switch lvl1 -> lvl0 with the linear pre-add fused (IdentityKeySwitchPreAdd).
-// One block per ciphertext, thread i owns output words i, i+128, ...  The digit of
-// a'_j is wave-uniform, so the row choice is a scalar branch.
+// Key switch lvl1 -> lvl0 with the linear pre-add fused (IdentityKeySwitchPreAdd,
+// include/keyswitch_gpu.cuh:136-188; KeySwitchFromTLWE :83-134 is the ca=1, cb=0 case).
+//
+// One wavefront per ciphertext.  The device copy of the key has its rows padded from n+1 =
+// 631 to 640 words so that a row is 160 aligned 16-byte pieces: lane L owns pieces L, L+64
+// and (L < 32) L+128, i.e. output words 4*piece .. 4*piece+3.  For one a'_j all t = 8 rows are
+// requested before any is consumed (24 global_load_dwordx4 in flight per wave) and then
+// added or subtracted under a wave-uniform branch on the digit -- the reference's dependent
+// load-add chain of 8192 steps (its thread i walks ksk[j][k][|val|-1][i] one at a time)
+// becomes 1024 batches.  A zero digit still requests row 0 (never used): one in four loads
+// is wasted to keep the issue loop branch-free.
 // ----------------------------------------------------------------------------------
-constexpr int kKsThreads = 128;
-constexpr int kKsCols = (kLvl0Words + kKsThreads - 1) / kKsThreads;   // 5
+constexpr int kKsThreads = 64;
+constexpr int kKsRowPad = 640;                                   // words per padded row
+constexpr int kKsPieces = 3;                                     // 16-byte pieces per lane
 
 __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
-    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk)
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
 {
-    __shared__ uint32_t tl[kLvl1Words];
+    __shared__ uint32_t tl[kLvl1Words + 3];
     const int g = blockIdx.x;
     if (g >= count) return;
+    const int lane = threadIdx.x;
     const LinDesc d = descs[g];
-    for (int j = threadIdx.x; j < kLvl1Words; j += kKsThreads) {
+    for (int j = lane; j < kLvl1Words; j += kKsThreads) {
         uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
         if (j == kN) v += d.off;
         tl[j] = v;
@@ -355,36 +365,53 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
     for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
 
-    uint32_t res[kKsCols];
-    int col[kKsCols];
+    int piece[kKsPieces];
+    piece[0] = lane; piece[1] = lane + 64; piece[2] = lane < 32 ? lane + 128 : 159;   // 159: in-bounds dummy
+    uint4 res[kKsPieces];
 #pragma unroll
-    for (int c = 0; c < kKsCols; c++) {
-        col[c] = threadIdx.x + c * kKsThreads;
-        res[c] = (col[c] == kLvl0N) ? tl[kN] : 0u;
-        if (col[c] > kLvl0N) col[c] = kLvl0N;      // clamp: harmless duplicate read, never stored
-    }
+    for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
+    if (lane == 29) res[2].z = tl[kN];          // word 630 = 4 * (29 + 128) + 2 starts from b'
+
+    const uint4* base = (const uint4*)ksk_padded;
+    constexpr int kRowPieces = kKsRowPad / 4;                    // 160
+    uint32_t cur = tl[0];
+#pragma unroll 1
     for (int j = 0; j < kN; j++) {
-        const uint32_t tmp = __builtin_amdgcn_readfirstlane(tl[j]) + koff;
-        const uint32_t* rowj = ksk + (size_t)j * kKsT * kKsNumBase * kKsRowWords;
+        const uint32_t tmp = __builtin_amdgcn_readfirstlane(cur) + koff;
+        cur = tl[j + 1];                                          // next a'_j (tl has slack)
+        int val[kKsT];
+        uint4 row[kKsT][kKsPieces];
 #pragma unroll
         for (int k = 0; k < kKsT; k++) {
-            const int val = (int)((tmp >> (32 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
-            if (val != 0) {
-                const uint32_t* row = rowj + (size_t)(k * kKsNumBase + (val > 0 ? val : -val) - 1) * kKsRowWords;
-                if (val > 0) {
+            val[k] = (int)((tmp >> (32 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
+            const int v = val[k] > 0 ? val[k] : -val[k];
+            const uint4* r = base + ((size_t)(j * kKsT + k) * kKsNumBase + (v ? v - 1 : 0)) * kRowPieces;
 #pragma unroll
-                    for (int c = 0; c < kKsCols; c++) res[c] -= row[col[c]];
-                } else {
+            for (int m = 0; m < kKsPieces; m++) row[k][m] = r[piece[m]];
+        }
 #pragma unroll
-                    for (int c = 0; c < kKsCols; c++) res[c] += row[col[c]];
+        for (int k = 0; k < kKsT; k++) {
+            if (val[k] > 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) {
+                    res[m].x -= row[k][m].x; res[m].y -= row[k][m].y; res[m].z -= row[k][m].z; res[m].w -= row[k][m].w;
+                }
+            } else if (val[k] < 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) {
+                    res[m].x += row[k][m].x; res[m].y += row[k][m].y; res[m].z += row[k][m].z; res[m].w += row[k][m].w;
                 }
             }
         }
     }
 #pragma unroll
-    for (int c = 0; c < kKsCols; c++) {
-        const int i = threadIdx.x + c * kKsThreads;
-        if (i <= kLvl0N) d.out[i] = res[c];
+    for (int m = 0; m < kKsPieces; m++) {
+        if (m == 2 && lane >= 32) break;
+        const int i = 4 * piece[m];
+        if (i + 0 <= kLvl0N) d.out[i + 0] = res[m].x;
+        if (i + 1 <= kLvl0N) d.out[i + 1] = res[m].y;
+        if (i + 2 <= kLvl0N) d.out[i + 2] = res[m].z;
+        if (i + 3 <= kLvl0N) d.out[i + 3] = res[m].w;
     }
 }
 
