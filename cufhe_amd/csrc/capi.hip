@@ -51,6 +51,7 @@ struct DeviceState {
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
     bool profiling = false;
+    bool br_lds_opt_in = false, ks_lds_opt_in = false;
     std::vector<EventPair> br_events, ks_events;
     cufhe_amd_profile prof{};
     std::deque<PinnedBlock> staging;
@@ -216,10 +217,9 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
+    if (!s.br_lds_opt_in) {      // > 64 KiB of dynamic LDS needs an opt-in, per device
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
-        lds_opt_in = true;
+        s.br_lds_opt_in = true;
     }
     const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
     hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
@@ -241,7 +241,12 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
+    if (!s.ks_lds_opt_in) {
+        HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
+        s.ks_lds_opt_in = true;
+    }
+    const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
+    hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk);
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
@@ -473,6 +478,7 @@ int cufhe_amd_cleanup(void)
         for (auto& kv : s.workspaces) (void)hipFree(kv.second.base);
         s.workspaces.clear();
         s.ntt_ready = s.keys_ready = false;
+        s.br_lds_opt_in = s.ks_lds_opt_in = false;
         s.tables = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
         s.prof = cufhe_amd_profile{};
     }

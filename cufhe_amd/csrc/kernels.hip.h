@@ -333,81 +333,112 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 // Key switch lvl1 -> lvl0 with the linear pre-add fused (IdentityKeySwitchPreAdd,
 // include/keyswitch_gpu.cuh:136-188; KeySwitchFromTLWE :83-134 is the ca=1, cb=0 case).
 //
-// One wavefront per ciphertext.  The device copy of the key has its rows padded from n+1 =
-// 631 to 640 words so that a row is 160 aligned 16-byte pieces: lane L owns pieces L, L+64
-// and (L < 32) L+128, i.e. output words 4*piece .. 4*piece+3.  For one a'_j all t = 8 rows are
-// requested before any is consumed (24 global_load_dwordx4 in flight per wave) and then
-// added or subtracted under a wave-uniform branch on the digit -- the reference's dependent
-// load-add chain of 8192 steps (its thread i walks ksk[j][k][|val|-1][i] one at a time)
-// becomes 1024 batches.  A zero digit still requests row 0 (never used): one in four loads
-// is wasted to keep the issue loop branch-free.
+// The reference gives every ciphertext its own pass over the key (thread i walks
+// ksk[j][k][|val|-1][i] for all j, k): ~15.5 MB of table per ciphertext.  A first version of
+// this kernel (one wave per ciphertext reading the rows straight from L2) ran at 27 TB/s of
+// L2 traffic -- the L2 bandwidth limit -- and still took 3.1 ms for 4096 ciphertexts.
+// So the table is shared instead: a workgroup of 16 waves handles 16 ciphertexts and
+// walks j in lock-step; the 16 candidate rows of one j (t = 8 levels x 2 values, contiguous
+// 40 KiB in the padded device layout [j][k][v][640]) are copied ONCE into LDS by LDS-DMA,
+// two steps ahead (3 buffers), and every wave adds or subtracts the 8 rows its own digits
+// select (wave-uniform branch per digit, rows read with ds_read_b128).  L2 traffic drops 16x.
+// Lane L owns 16-byte pieces L, L+64 and (L < 32) L+128 of the 160-piece row, i.e. output
+// words 4*piece .. 4*piece+3.
 // ----------------------------------------------------------------------------------
-constexpr int kKsThreads = 64;
+constexpr int kKsWaves = 16;
+constexpr int kKsThreads = 64 * kKsWaves;                        // 1024
 constexpr int kKsRowPad = 640;                                   // words per padded row
 constexpr int kKsPieces = 3;                                     // 16-byte pieces per lane
+constexpr int kKsStepBytes = kKsT * kKsNumBase * kKsRowPad * 4;  // 40960: all rows of one j
+constexpr int kKsBuffers = 3;
+constexpr int kKsLdsDigits = kKsWaves * kN * 2;                  // u16 digit words: 32768
+constexpr int kKsLdsBytes = kKsLdsDigits + kKsBuffers * kKsStepBytes;   // 155648
 
 __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
 {
-    __shared__ uint32_t tl[kLvl1Words + 3];
-    const int g = blockIdx.x;
-    if (g >= count) return;
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int g = blockIdx.x * kKsWaves + wave;
+    const bool live = g < count;
+    if (!live) g = count - 1;
     const LinDesc d = descs[g];
-    for (int j = lane; j < kLvl1Words; j += kKsThreads) {
-        uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
-        if (j == kN) v += d.off;
-        tl[j] = v;
-    }
-    __syncthreads();
+    uint16_t* dig = (uint16_t*)smem + wave * kN;
+    char* bufs = smem + kKsLdsDigits;
 
-    // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98
+    // LDS-DMA of step j: 40 pieces of 1 KiB; waves 0-7 move 3, waves 8-15 move 2
+    auto issue = [&](int j) {
+        if (j >= kN) return;
+        const char* src = (const char*)ksk_padded + (size_t)j * kKsStepBytes + lane * 16;
+        char* dst = bufs + (j % kKsBuffers) * kKsStepBytes;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int piece = wave < 8 ? 3 * wave + c : 24 + 2 * (wave - 8) + c;
+            if (c == 2 && wave >= 8) break;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue(0);
+    issue(1);
+
+    // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98; only the top
+    // t*basebit = 16 bits of a'_j + offset carry digits
     uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
     for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
+    uint32_t bprime = 0;
+    for (int j = lane; j < kLvl1Words; j += 64) {
+        uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
+        if (j == kN) bprime = v + d.off;
+        else dig[j] = (uint16_t)((v + koff) >> 16);
+    }
+    bprime = __builtin_amdgcn_readlane(bprime, 0);    // j = 1024 is handled by lane 0
 
-    int piece[kKsPieces];
-    piece[0] = lane; piece[1] = lane + 64; piece[2] = lane < 32 ? lane + 128 : 159;   // 159: in-bounds dummy
     uint4 res[kKsPieces];
 #pragma unroll
     for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
-    if (lane == 29) res[2].z = tl[kN];          // word 630 = 4 * (29 + 128) + 2 starts from b'
+    if (lane == 29) res[2].z = bprime;           // word 630 = 4 * (29 + 128) + 2 starts from b'
+    int off[kKsPieces];
+    off[0] = lane * 16; off[1] = (lane + 64) * 16; off[2] = (lane < 32 ? lane + 128 : 159) * 16;
 
-    const uint4* base = (const uint4*)ksk_padded;
-    constexpr int kRowPieces = kKsRowPad / 4;                    // 160
-    uint32_t cur = tl[0];
+    __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
 #pragma unroll 1
     for (int j = 0; j < kN; j++) {
-        const uint32_t tmp = __builtin_amdgcn_readfirstlane(cur) + koff;
-        cur = tl[j + 1];                                          // next a'_j (tl has slack)
-        int val[kKsT];
-        uint4 row[kKsT][kKsPieces];
+        // Counted wait: the pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight
+        // across the barrier, only step j must have landed.  lgkmcnt(0): this wave has
+        // finished reading step j-1, whose buffer step j+2 is about to overwrite.
+        if (j + 1 >= kN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (wave < 8) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        issue(j + 2);
+        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+        const char* buf = bufs + (j % kKsBuffers) * kKsStepBytes;
 #pragma unroll
         for (int k = 0; k < kKsT; k++) {
-            val[k] = (int)((tmp >> (32 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
-            const int v = val[k] > 0 ? val[k] : -val[k];
-            const uint4* r = base + ((size_t)(j * kKsT + k) * kKsNumBase + (v ? v - 1 : 0)) * kRowPieces;
+            const int val = (int)((dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
+            if (val != 0) {
+                const int v = val > 0 ? val : -val;
+                const char* row = buf + (k * kKsNumBase + (v - 1)) * (kKsRowPad * 4);
+                uint4 r[kKsPieces];
 #pragma unroll
-            for (int m = 0; m < kKsPieces; m++) row[k][m] = r[piece[m]];
-        }
+                for (int m = 0; m < kKsPieces; m++) r[m] = *(const uint4*)(row + off[m]);
+                if (val > 0) {
 #pragma unroll
-        for (int k = 0; k < kKsT; k++) {
-            if (val[k] > 0) {
+                    for (int m = 0; m < kKsPieces; m++) { res[m].x -= r[m].x; res[m].y -= r[m].y; res[m].z -= r[m].z; res[m].w -= r[m].w; }
+                } else {
 #pragma unroll
-                for (int m = 0; m < kKsPieces; m++) {
-                    res[m].x -= row[k][m].x; res[m].y -= row[k][m].y; res[m].z -= row[k][m].z; res[m].w -= row[k][m].w;
-                }
-            } else if (val[k] < 0) {
-#pragma unroll
-                for (int m = 0; m < kKsPieces; m++) {
-                    res[m].x += row[k][m].x; res[m].y += row[k][m].y; res[m].z += row[k][m].z; res[m].w += row[k][m].w;
+                    for (int m = 0; m < kKsPieces; m++) { res[m].x += r[m].x; res[m].y += r[m].y; res[m].z += r[m].z; res[m].w += r[m].w; }
                 }
             }
         }
     }
+    if (!live) return;
 #pragma unroll
     for (int m = 0; m < kKsPieces; m++) {
         if (m == 2 && lane >= 32) break;
-        const int i = 4 * piece[m];
+        const int i = off[m] / 4;
         if (i + 0 <= kLvl0N) d.out[i + 0] = res[m].x;
         if (i + 1 <= kLvl0N) d.out[i + 1] = res[m].y;
         if (i + 2 <= kLvl0N) d.out[i + 2] = res[m].z;
