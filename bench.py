@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["nand", "mux", "mixed"], default="nand",
+                    help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix")
     args = ap.parse_args()
     if args.gpus != WORLD:
         if WORLD == 1 and args.gpus > 1:
@@ -113,12 +115,21 @@ def main():
     eng.Initialize(bk, ksk)
     d0 = eng.api.DeviceBuffer(in0.size).upload(in0)
     d1 = eng.api.DeviceBuffer(in1.size).upload(in1)
+    in2 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+    d2 = eng.api.DeviceBuffer(in2.size).upload(in2)
     dout = eng.api.DeviceBuffer(count * (ol.n + 1))
+    if args.workload == "nand":
+        ops, rot_per_gate = eng.api.NAND, 1
+    elif args.workload == "mux":
+        ops, rot_per_gate = eng.api.MUX, 2
+    else:   # configs[2]: op[i] = {AND, OR, XOR, NAND}[i mod 4]
+        ops = np.array([[eng.api.AND, eng.api.OR, eng.api.XOR, eng.api.NAND][g % 4] for g in range(count)], np.int32)
+        rot_per_gate = 1
     st = eng.Stream(0)
     st.Create()
 
     def step():
-        eng.gate_batch(eng.api.NAND, 0, dout, d0, d1, count=count, device=0, stream=st.st())
+        eng.gate_batch(ops, 0, dout, d0, d1, d2, count=count, device=0, stream=st.st())
 
     def barrier():
         if WORLD > 1:
@@ -139,13 +150,26 @@ def main():
     eng.profile_enable(False)
     elapsed = distutil.max_over_ranks(elapsed, dist)
 
+    latency_ms = None
+    if RANK == 0:
+        # ms/gate latency: one gate alone on the idle device, enqueue -> result on the stream
+        one = np.array([eng.api.NAND], np.int32)
+        lat = []
+        for _ in range(5):
+            eng.Synchronize()
+            t1 = time.perf_counter()
+            eng.gate_batch(eng.api.NAND, 0, dout, d0, d1, count=1, device=0, stream=st.st())
+            eng.Synchronize()
+            lat.append(1e3 * (time.perf_counter() - t1))
+        latency_ms = sorted(lat)[len(lat) // 2]
     if RANK == 0:
         total_gates = count * args.steps * WORLD
         br_ms = prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1)
         ks_ms = prof.keyswitch_ms / max(prof.keyswitch_launches, 1)
-        achieved = BK_BYTES_PER_ROTATION * count / (br_ms * 1e-3) / 1e9
+        rotations = count * rot_per_gate
+        achieved = BK_BYTES_PER_ROTATION * rotations / (br_ms * 1e-3) / 1e9
         res = {
-            "metric": "nand_gate_bootstraps_per_sec",
+            "metric": "nand_gate_bootstraps_per_sec" if args.workload == "nand" else f"{args.workload}_gates_per_sec",
             "value": total_gates / elapsed,
             "unit": "gate-bootstraps/s",
             "n_gpus": WORLD,
@@ -158,22 +182,24 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{count} independent NAND gates per GPU per step (BASELINE configs[1]), "
+                "workload": f"{count} independent {args.workload.upper()} gates per GPU per step "
+                            f"(BASELINE configs[{dict(nand=1, mux=3, mixed=2)[args.workload]}]), "
                             "TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2, lvl0 ciphertexts resident in HBM",
                 "gates_per_gpu": count,
                 "sharding": "gates split across ranks, per-GPU BK/KSK replica, no collective",
             },
             "ms_per_gate_throughput": 1e3 * elapsed / (count * args.steps),
+            "ms_per_gate_latency_single_gate": latency_ms,
             "roofline": {
                 "bound": "hbm", "kernel": "blind_rotate_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "launch_ms": br_ms, "rotations_per_launch": count,
+                "launch_ms": br_ms, "rotations_per_launch": rotations,
                 "algorithmic_bytes_per_rotation": BK_BYTES_PER_ROTATION,
                 "keyswitch_launch_ms": ks_ms,
             },
         }
-        if not args.no_cpu_baseline and WORLD == 1:
+        if not args.no_cpu_baseline and WORLD == 1 and args.workload == "nand":
             gpu_out = dout.download().reshape(count, ol.n + 1)
             res["cpu_baseline"] = cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out)
         print(json.dumps(res), flush=True)

@@ -249,8 +249,7 @@ __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&a
 // descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at
 // index 0).  steps < n is only used by the parity tests; acc_dump (optional) receives the
 // raw accumulator (2N words per rotation).  All 8 waves of a workgroup walk the key in
-// lock-step (one barrier per TRGSW row); waves past `count` run a clamped duplicate and
-// store nothing.
+// lock-step (one barrier per TRGSW row); waves past `count` only serve the row pipeline.
 __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
@@ -260,14 +259,20 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     load_tables_to_lds(tabs, gt);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int g = blockIdx.x * kBrWavesPerBlock + wave;
-    const bool live = g < count;
-    if (!live) g = count - 1;
+    const int g = blockIdx.x * kBrWavesPerBlock + wave;
     char* tile = smem + kBrLdsTiles + wave * kTileBytes;
     uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
     const WaveCtx ctx = make_wave_ctx(tile, tabs, gt, lane);
     const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows, wave >= kBrWavesPerBlock / 2};
     pipe.issue(0);
+    if (g >= count) {
+        // no rotation for this wave (tail of the batch): it only keeps its share of the row
+        // pipeline going -- one barrier and two LDS-DMA pieces per row -- and computes nothing
+        __syncthreads();
+#pragma unroll 1
+        for (int R = 0; R < pipe.total_rows; R++) pipe.sync(R);
+        return;
+    }
 
     const LinDesc d = descs[g];
     // pre-add (gate linear part) and modulus switch, :316-345
@@ -308,7 +313,6 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
         inverse_and_add(A1, acc1, ctx);
     }
 
-    if (!live) return;
     if (acc_dump) {
         uint32_t* o = acc_dump + (size_t)g * 2 * kN;
 #pragma unroll
