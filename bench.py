@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency", action="store_true",
+                    help="also time one gate alone on the idle device (adds 1-gate launches to a profile)")
     ap.add_argument("--workload", choices=["nand", "mux", "mixed"], default="nand",
                     help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix")
     args = ap.parse_args()
@@ -151,7 +153,7 @@ def main():
     elapsed = distutil.max_over_ranks(elapsed, dist)
 
     latency_ms = None
-    if RANK == 0:
+    if RANK == 0 and args.latency:
         # ms/gate latency: one gate alone on the idle device, enqueue -> result on the stream
         one = np.array([eng.api.NAND], np.int32)
         lat = []
