@@ -61,11 +61,14 @@ constexpr int kBrWavesPerBlock = 8;
 constexpr int kBrThreads = 64 * kBrWavesPerBlock;                               // 512
 constexpr int kBkRowBytes = 2 * kN * 8;                                         // 16384: one TRGSW row (2 polys)
 constexpr int kAbarBytes = 1280;                                                // 630 x u16, padded
-constexpr int kBrLdsTiles = kLdsTableBytes;
-constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
-constexpr int kBrLdsBk = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;
 constexpr int kBkRowBuffers = 3;
-constexpr int kBrLdsBytes = kBrLdsBk + kBkRowBuffers * kBkRowBytes;              // 143104
+// LDS map: [row buffers][twiddle tables][tiles][abar lists].  The row buffers come first so
+// that "buffer + piece" offsets (< 64 KiB) fold into the DS instructions' offset field.
+constexpr int kBrLdsBk = 0;
+constexpr int kBrLdsTables = kBrLdsBk + kBkRowBuffers * kBkRowBytes;            // 49152
+constexpr int kBrLdsTiles = kBrLdsTables + kLdsTableBytes;
+constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
+constexpr int kBrLdsBytes = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;         // 143104
 
 // gadget decomposition constants, include/gatebootstrapping_gpu.cuh:18-27,145-150
 __host__ __device__ constexpr uint32_t decomp_offset()
@@ -156,17 +159,24 @@ __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double
     (void)row_lane;
     return;
 #endif
+    // Software pipeline, pinned: the ds_read_b128 of piece q+2 is issued before the products of
+    // piece q (hipcc otherwise sinks every read to its use and waits for it there).  The
+    // sched_barrier lets VALU/SALU instructions float but keeps DS reads on their side.
+    double2 b[16];
+    b[0] = *(const double2*)(row_lane);
+    b[1] = *(const double2*)(row_lane + 1024);
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const double2 b0 = *(const double2*)(row_lane + q * 1024);
-        A0[2 * q] += fpf::mulmod_wide(x[2 * q], b0.x);
-        A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b0.y);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const double2 b1 = *(const double2*)(row_lane + 8192 + q * 1024);
-        A1[2 * q] += fpf::mulmod_wide(x[2 * q], b1.x);
-        A1[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b1.y);
+    for (int q = 0; q < 16; q++) {
+        if (q + 2 < 16) b[q + 2] = *(const double2*)(row_lane + (q + 2) * 1024);
+        __builtin_amdgcn_sched_barrier(0x0006);
+        if (q < 8) {
+            A0[2 * q] += fpf::mulmod_wide(x[2 * q], b[q].x);
+            A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b[q].y);
+        } else {
+            A1[2 * (q - 8)] += fpf::mulmod_wide(x[2 * (q - 8)], b[q].x);
+            A1[2 * (q - 8) + 1] += fpf::mulmod_wide(x[2 * (q - 8) + 1], b[q].y);
+        }
+        __builtin_amdgcn_sched_barrier(0x0006);
     }
 }
 
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* tabs = (double*)smem;
+    double* tabs = (double*)(smem + kBrLdsTables);
     load_tables_to_lds(tabs, gt);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
