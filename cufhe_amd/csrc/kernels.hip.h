@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t poly = (size_t)blockIdx.x * kNttWavesPerBlock + wave;
     if (poly >= polys) return;
-    const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
+    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
     double x[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) x[r] = (double)(int32_t)bk[poly * kN + lane + 64 * r];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
 __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32_t (&acc)[kRegs],
                                            char* tile, int lane, uint32_t abar)
 {
-    char* wbase = tile + 4 * lane;
+    char* wbase = tile + opaque(4 * lane);
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {
         *(uint32_t*)(wbase + 256 * r) = acc[r];
@@ -134,7 +134,7 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
     }
     const int alo = (int)(abar & (kN - 1));
     const bool ahi = (abar >> kNbit) != 0;
-    const char* rbase = tile + 4 * ((lane - alo) & (kN - 1));
+    const char* rbase = tile + opaque(4 * ((lane - alo) & (kN - 1)));
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {
         const uint32_t v = *(const uint32_t*)(rbase + 256 * r);
@@ -219,7 +219,7 @@ struct RowPipe {
     }
     __device__ __forceinline__ const char* row(int R) const
     {
-        return buf + (R % kBkRowBuffers) * kBkRowBytes + lane * 16;
+        return buf + opaque((R % kBkRowBuffers) * kBkRowBytes + lane * 16);
     }
 };
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     const int g = blockIdx.x * kBrWavesPerBlock + wave;
     char* tile = smem + kBrLdsTiles + wave * kTileBytes;
     uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
-    const WaveCtx ctx = make_wave_ctx(tile, tabs, gt, lane);
+    const WaveCtx ctx = make_wave_ctx(smem, kBrLdsTiles + wave * kTileBytes, kBrLdsTables, gt, lane);
     const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows, wave >= kBrWavesPerBlock / 2};
     pipe.issue(0);
     if (g >= count) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kNttThreads) void polymul_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x * kNttWavesPerBlock + wave;
     if (g >= count) return;
-    const WaveCtx ctx = make_wave_ctx(smem + kLdsTableBytes + wave * kTileBytes, tabs, gt, lane);
+    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
     double x[kRegs], y[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {

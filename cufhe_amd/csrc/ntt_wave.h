@@ -79,22 +79,32 @@ struct WaveCtx {
     const NttTables* gt;  // global tables (uniform scalars)
 };
 
-__device__ __forceinline__ WaveCtx make_wave_ctx(char* tile, const double* lds_tables,
+// A byte offset the compiler cannot see through: `lds + opaque(off)` keeps the full per-lane
+// address in ONE VGPR, so every access is "VGPR + small immediate".  Without it hipcc folds
+// the wave's tile base into the 16-bit DS offset field and, once that base exceeds 64 KiB,
+// spends a v_add per access to rebuild the address.
+__device__ __forceinline__ int opaque(int off)
+{
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
+// lds: start of the workgroup's dynamic LDS; tile_off / tables_off: byte offsets in it
+__device__ __forceinline__ WaveCtx make_wave_ctx(char* lds, int tile_off, int tables_off,
                                                  const NttTables* gt, int lane)
 {
     const int lam = lane & 15, hi = lane >> 4;
     WaveCtx c;
-    c.a65 = tile + 8 * lane;
+    c.a65 = lds + opaque(tile_off + 8 * lane);
     c.a66 = c.a65;
-    c.b65 = tile + 8 * (65 * lam + hi);
-    c.b66 = tile + 8 * (66 * lam + hi);
-    c.c65 = tile + 8 * (65 * lam + 16 * hi);
-    c.c66 = tile + 8 * (66 * lam + 16 * hi);
-    const char* t = (const char*)lds_tables;
-    c.tb_fwd = t + 8 * lam;
-    c.tb_inv = t + 8 * (kTbCount * 16) + 8 * lam;
-    c.tc_fwd = t + 8 * (2 * kTbCount * 16) + 8 * lane;
-    c.tc_inv = t + 8 * (2 * kTbCount * 16 + kTcCount * 64) + 8 * lane;
+    c.b65 = lds + opaque(tile_off + 8 * (65 * lam + hi));
+    c.b66 = lds + opaque(tile_off + 8 * (66 * lam + hi));
+    c.c65 = lds + opaque(tile_off + 8 * (65 * lam + 16 * hi));
+    c.c66 = lds + opaque(tile_off + 8 * (66 * lam + 16 * hi));
+    c.tb_fwd = lds + opaque(tables_off + 8 * lam);
+    c.tb_inv = c.tb_fwd + 8 * (kTbCount * 16);
+    c.tc_fwd = lds + opaque(tables_off + 8 * (2 * kTbCount * 16) + 8 * lane);
+    c.tc_inv = c.tc_fwd + 8 * (kTcCount * 64);
     c.gt = gt;
     return c;
 }
