@@ -162,12 +162,16 @@ __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double
     // Software pipeline, pinned: the ds_read_b128 of piece q+2 is issued before the products of
     // piece q (hipcc otherwise sinks every read to its use and waits for it there).  The
     // sched_barrier lets VALU/SALU instructions float but keeps DS reads on their side.
+#ifndef CUFHE_AMD_BK_DEPTH
+#define CUFHE_AMD_BK_DEPTH 3
+#endif
+    constexpr int D = CUFHE_AMD_BK_DEPTH;
     double2 b[16];
-    b[0] = *(const double2*)(row_lane);
-    b[1] = *(const double2*)(row_lane + 1024);
+#pragma unroll
+    for (int q = 0; q < D; q++) b[q] = *(const double2*)(row_lane + q * 1024);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        if (q + 2 < 16) b[q + 2] = *(const double2*)(row_lane + (q + 2) * 1024);
+        if (q + D < 16) b[q + D] = *(const double2*)(row_lane + (q + D) * 1024);
         __builtin_amdgcn_sched_barrier(0x0006);
         if (q < 8) {
             A0[2 * q] += fpf::mulmod_wide(x[2 * q], b[q].x);
