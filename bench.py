@@ -155,7 +155,7 @@ def main():
     latency_ms = None
     if RANK == 0 and args.latency:
         # ms/gate latency: one gate alone on the idle device, enqueue -> result on the stream
-        one = np.array([eng.api.NAND], np.int32)
+        # (a 1-gate launch takes the workgroup-per-rotation kernel)
         lat = []
         for _ in range(5):
             eng.Synchronize()

@@ -237,6 +237,10 @@ def polymul_batch(a, b, res, count, device=0, stream=None):
     check(lib.cufhe_amd_polymul_batch(device, stream, count, a.ptr, b.ptr, res.ptr))
 
 
+def set_option(key, value):
+    check(lib.cufhe_amd_set_option(key.encode(), int(value)))
+
+
 def profile_enable(on=True, device=0):
     check(lib.cufhe_amd_profile_enable(device, 1 if on else 0))
 

@@ -63,6 +63,8 @@ struct DeviceState {
 };
 
 int g_gpu_num = 1;
+long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
+long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 std::vector<DeviceState> g_dev(1);   // resized only while no device is initialised
 std::mutex g_mu;
 
@@ -219,11 +221,18 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     }
     if (!s.br_lds_opt_in) {      // > 64 KiB of dynamic LDS needs an opt-in, per device
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
         s.br_lds_opt_in = true;
     }
-    const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
-    hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
-                       s.bk_ntt, s.tables, steps, acc_dump);
+    if ((long)count <= g_wg_threshold) {
+        // small batch: one workgroup per rotation (latency), see kernels.hip.h
+        hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)count), dim3(kWgThreads), kWgLdsBytes, st, d, (int)count,
+                           s.bk_ntt, s.tables, steps, acc_dump);
+    } else {
+        const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
+        hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
+                           s.bk_ntt, s.tables, steps, acc_dump);
+    }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
@@ -245,8 +254,12 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
         s.ks_lds_opt_in = true;
     }
-    const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
-    hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk);
+    if ((long)count <= g_ks_wg_threshold) {
+        hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
+    } else {
+        const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk);
+    }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
@@ -650,6 +663,14 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
                        (int)count, g_dev[device].tables, n_inverse_balanced());
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int cufhe_amd_set_option(const char* key, long value)
+{
+    if (!key) return fail(-1, "null key");
+    if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
+    if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
+    return fail(-1, std::string("unknown option ") + key);
 }
 
 int cufhe_amd_profile_enable(int device, int on)

@@ -348,6 +348,139 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 }
 
 // ----------------------------------------------------------------------------------
+// Low-latency blind rotate: ONE WORKGROUP per rotation (small batches, ms/gate latency).
+//
+// The batch kernel above gives a rotation one wave, i.e. one SIMD's worth of FP64 issue:
+// 13 ms per gate however idle the chip is.  Here the 8 NTTs of a CMux step are spread over
+// the CU: waves 0-5 each take one TRGSW row (digit polynomial -> forward NTT -> products with
+// the row's two key polynomials, which the wave prefetches straight from L2 into registers
+// one step ahead), and add their products into two shared NTT-domain sums in LDS with
+// ds_add_f64 -- exact integer additions, so the result does not depend on arrival order.
+// After a barrier waves 0 and 1 run the two inverse NTTs and update the accumulator, which
+// lives in LDS (stored twice, e and e+N, so the rotated read needs no wrap-around).  Two
+// barriers per step; same arithmetic, same words as the batch kernel.
+// ----------------------------------------------------------------------------------
+constexpr int kWgThreads = 512;
+constexpr int kWgRowWaves = kBkRows;                                          // 6
+constexpr int kWgLdsTables = 0;
+constexpr int kWgLdsTiles = kWgLdsTables + kLdsTableBytes;                    // 16128
+constexpr int kWgLdsAcc = kWgLdsTiles + kWgRowWaves * kTileBytes;             // + 50688
+constexpr int kWgLdsSum = kWgLdsAcc + 2 * 2 * kN * 4;                         // + 16384
+constexpr int kWgLdsAbar = kWgLdsSum + 2 * kN * 8;                            // + 16384
+constexpr int kWgLdsBytes = kWgLdsAbar + kAbarBytes + 16;                     // 100880
+
+__global__ __launch_bounds__(kWgThreads, 2) void blind_rotate_wg_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    load_tables_to_lds((double*)(smem + kWgLdsTables), gt);
+    uint32_t* accL = (uint32_t*)(smem + kWgLdsAcc);          // [j][copy][N]
+    double* sumL = (double*)(smem + kWgLdsSum);               // [out][reg][lane]
+    uint16_t* abar_lds = (uint16_t*)(smem + kWgLdsAbar);
+    uint32_t* bbar_slot = (uint32_t*)(smem + kWgLdsAbar + kAbarBytes);
+
+    const LinDesc d = descs[g];
+    for (int i = tid; i <= kLvl0N; i += kWgThreads) {
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit));
+        else *bbar_slot = 2 * kN - ((c + d.off) >> (32 - 1 - kNbit));
+    }
+    for (int i = tid; i < 2 * kN; i += kWgThreads) sumL[i] = 0.0;
+    __syncthreads();
+    {   // RotatedTestVector, include/gatebootstrapping_gpu.cuh:29-52
+        const uint32_t bbar = *bbar_slot;
+        for (int e = tid; e < kN; e += kWgThreads) {
+            const bool neg = (bbar != 2 * kN) && (((uint32_t)e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
+            const uint32_t v = neg ? 0u - kMu : kMu;
+            accL[e] = 0; accL[kN + e] = 0;
+            accL[2 * kN + e] = v; accL[3 * kN + e] = v;
+        }
+    }
+    __syncthreads();
+
+    const bool row_wave = wave < kWgRowWaves;
+    const int wj = wave / kL, wd = wave % kL;                 // this wave's TRGSW row = wj * l + wd
+    const WaveCtx ctx = make_wave_ctx(smem, kWgLdsTiles + (row_wave ? wave : 0) * kTileBytes, kWgLdsTables, gt, lane);
+    double2 b[16];
+    if (row_wave && steps > 0) {
+        const double2* row = (const double2*)(bk_ntt + ((size_t)0 * kBkRows + wave) * (2 * kN));
+#pragma unroll
+        for (int q = 0; q < 16; q++) b[q] = row[q * 64 + lane];
+    }
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        if (row_wave) {
+            const char* accj = (const char*)(accL + wj * 2 * kN);
+            const int alo = (int)(abar & (kN - 1));
+            const bool ahi = (abar >> kNbit) != 0;
+            const char* rbase = accj + opaque(4 * ((lane - alo) & (kN - 1)));
+            const char* cbase = accj + opaque(4 * lane);
+            uint32_t rot[kRegs], cur[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) { rot[r] = *(const uint32_t*)(rbase + 256 * r); cur[r] = *(const uint32_t*)(cbase + 256 * r); }
+            const int lsh = wd * kBgbit;
+            double x[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                const bool neg = (lane < alo - 64 * r) != ahi;
+                const uint32_t t = ((neg ? 0u - rot[r] : rot[r]) - cur[r] + decomp_offset()) ^ decomp_signmask();
+                x[r] = (double)((int32_t)(t << lsh) >> (32 - kBgbit));
+            }
+            ntt_forward<true>(x, ctx);
+            double* s0 = sumL + lane;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                __hip_atomic_fetch_add(s0 + (2 * q) * 64, fpf::mulmod_wide(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s0 + (2 * q + 1) * 64, fpf::mulmod_wide(x[2 * q + 1], b[q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s0 + kN + (2 * q) * 64, fpf::mulmod_wide(x[2 * q], b[q + 8].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s0 + kN + (2 * q + 1) * 64, fpf::mulmod_wide(x[2 * q + 1], b[q + 8].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        if (row_wave && i + 1 < steps) {         // next step's row, in flight during the inverse NTTs
+            const double2* row = (const double2*)(bk_ntt + ((size_t)(i + 1) * kBkRows + wave) * (2 * kN));
+#pragma unroll
+            for (int q = 0; q < 16; q++) b[q] = row[q * 64 + lane];
+        }
+        if (wave < 2) {
+            double* s = sumL + wave * kN + lane;
+            double A[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
+            ntt_inverse(A, ctx);
+            char* acck = (char*)(accL + wave * 2 * kN) + opaque(4 * lane);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                const uint32_t v = *(const uint32_t*)(acck + 256 * r) + fpf::lift_u32(A[r]);
+                *(uint32_t*)(acck + 256 * r) = v;
+                *(uint32_t*)(acck + 256 * r + 4096) = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
+        for (int e = tid; e < kN; e += kWgThreads) { o[e] = accL[e]; o[kN + e] = accL[2 * kN + e]; }
+    }
+    if (d.out) {
+        uint32_t* o = d.out;      // __SampleExtractIndex__<P,0>
+        for (int e = tid; e < kN; e += kWgThreads) {
+            if (e == 0) { o[0] = accL[0]; o[kN] = accL[2 * kN]; }
+            else o[kN - e] = 0u - accL[e];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // Key switch lvl1 -> lvl0 with the linear pre-add fused (IdentityKeySwitchPreAdd,
 // include/keyswitch_gpu.cuh:136-188; KeySwitchFromTLWE :83-134 is the ca=1, cb=0 case).
 //
@@ -461,6 +594,77 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         if (i + 1 <= kLvl0N) d.out[i + 1] = res[m].y;
         if (i + 2 <= kLvl0N) d.out[i + 2] = res[m].z;
         if (i + 3 <= kLvl0N) d.out[i + 3] = res[m].w;
+    }
+}
+
+// Low-latency key switch: one workgroup (16 waves) per ciphertext, wave w takes the 64 values
+// a'_j, j in [64 w, 64 w + 64), reads its rows straight from L2 (eight rows in flight) and the
+// 16 partial sums are added through LDS.  Same words as keyswitch_kernel; used for small
+// launches, where sharing the table between ciphertexts buys nothing.
+__global__ __launch_bounds__(kKsThreads) void keyswitch_wg_kernel(
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
+{
+    __shared__ uint32_t part[kKsWaves][kKsRowPad];
+    __shared__ uint16_t dig[kN];
+    __shared__ uint32_t bprime_s;
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const LinDesc d = descs[g];
+    uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
+    for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
+    for (int j = tid; j < kLvl1Words; j += kKsThreads) {
+        const uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
+        if (j == kN) bprime_s = v + d.off;
+        else dig[j] = (uint16_t)((v + koff) >> 16);
+    }
+    __syncthreads();
+
+    int piece[kKsPieces];
+    piece[0] = lane; piece[1] = lane + 64; piece[2] = lane < 32 ? lane + 128 : 159;
+    uint4 res[kKsPieces];
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
+    const uint4* base = (const uint4*)ksk_padded;
+    constexpr int kRowPieces = kKsRowPad / 4;
+#pragma unroll 1
+    for (int jj = 0; jj < kN / kKsWaves; jj++) {
+        const int j = wave * (kN / kKsWaves) + jj;
+        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+        int val[kKsT];
+        uint4 row[kKsT][kKsPieces];
+#pragma unroll
+        for (int k = 0; k < kKsT; k++) {
+            val[k] = (int)((dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
+            const int v = val[k] > 0 ? val[k] : -val[k];
+            const uint4* r = base + ((size_t)(j * kKsT + k) * kKsNumBase + (v ? v - 1 : 0)) * kRowPieces;
+#pragma unroll
+            for (int m = 0; m < kKsPieces; m++) row[k][m] = r[piece[m]];
+        }
+#pragma unroll
+        for (int k = 0; k < kKsT; k++) {
+            if (val[k] > 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x -= row[k][m].x; res[m].y -= row[k][m].y; res[m].z -= row[k][m].z; res[m].w -= row[k][m].w; }
+            } else if (val[k] < 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x += row[k][m].x; res[m].y += row[k][m].y; res[m].z += row[k][m].z; res[m].w += row[k][m].w; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) {
+        if (m == 2 && lane >= 32) break;
+        *(uint4*)&part[wave][4 * piece[m]] = res[m];
+    }
+    __syncthreads();
+    for (int i = tid; i <= kLvl0N; i += kKsThreads) {
+        uint32_t v = (i == kLvl0N) ? bprime_s : 0u;
+#pragma unroll
+        for (int w = 0; w < kKsWaves; w++) v += part[w][i];
+        d.out[i] = v;
     }
 }
 

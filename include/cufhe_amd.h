@@ -127,6 +127,12 @@ int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint
 int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a,
                             const uint32_t* b, uint32_t* res);
 
+/* ---- tuning ----
+ * "wg_threshold": launches of at most this many blind rotations use the workgroup-per-rotation
+ * kernel (lowest latency); larger ones the wave-per-rotation batch kernel (highest throughput).
+ * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words. */
+int cufhe_amd_set_option(const char* key, long value);
+
 /* ---- measurement ----
  * When enabled, every blind-rotate / key-switch launch is bracketed by HIP events on the
  * stream it runs on; get_profile synchronises and returns accumulated kernel time. */

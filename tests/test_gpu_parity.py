@@ -13,6 +13,17 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["batch", "wg"])
+def br_kernel(request, engine):
+    """Run a test once per blind-rotate kernel: wave-per-rotation (batch) and
+    workgroup-per-rotation (low latency).  Both must give the oracle's words."""
+    engine.api.set_option("wg_threshold", 0 if request.param == "batch" else 1 << 30)
+    engine.api.set_option("ks_wg_threshold", 0 if request.param == "batch" else 1 << 30)
+    yield request.param
+    engine.api.set_option("wg_threshold", 1024)
+    engine.api.set_option("ks_wg_threshold", 128)
+
+
 def _upload(eng, arr):
     arr = np.ascontiguousarray(arr, dtype=np.uint32)
     return eng.api.DeviceBuffer(arr.size).upload(arr)
@@ -40,7 +51,7 @@ def test_polymul_matches_schoolbook_and_oracle_ntt(engine, oracle):
 
 
 @pytest.mark.parametrize("steps", [0, 1, 2, 3, 64, 65, 630])
-def test_blind_rotate_accumulator_words(engine, keys, oracle, steps):
+def test_blind_rotate_accumulator_words(engine, keys, oracle, steps, br_kernel):
     count = 6 if steps == 630 else 10
     rng = np.random.default_rng(100 + steps)
     tl = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
@@ -59,7 +70,7 @@ def test_blind_rotate_accumulator_words(engine, keys, oracle, steps):
         assert np.array_equal(got[g], want), f"accumulator of rotation {g} differs after {steps} steps"
 
 
-def test_keyswitch_words(engine, keys, oracle):
+def test_keyswitch_words(engine, keys, oracle, br_kernel):
     count = 16
     rng = np.random.default_rng(5)
     t1 = rng.integers(0, 2**32, size=(count, ol.N + 1), dtype=np.uint64).astype(np.uint32)
@@ -76,7 +87,7 @@ def test_keyswitch_words(engine, keys, oracle):
 
 
 @pytest.mark.parametrize("level", [0, 1])
-def test_every_gate_words_and_truth_table(engine, keys, oracle, level):
+def test_every_gate_words_and_truth_table(engine, keys, oracle, level, br_kernel):
     """All 14 ops on all input combinations: words == oracle, decrypt == truth table."""
     combos = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.uint8)
     count = len(combos)
@@ -93,7 +104,7 @@ def test_every_gate_words_and_truth_table(engine, keys, oracle, level):
         assert list(bits) == exp, f"{ol.OPS[op]} level {level}: decrypt != truth table"
 
 
-def test_mixed_batch_and_aliasing(engine, keys, oracle):
+def test_mixed_batch_and_aliasing(engine, keys, oracle, br_kernel):
     """Mixed op codes in one launch (BASELINE config 3 shape) with out aliasing in0."""
     count = 64
     rng = np.random.default_rng(11)
