@@ -68,6 +68,10 @@ SIGNATURES = {
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),
     "cufhe_amd_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_sample_extract_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_refresh_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_trgsw_to_ntt_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_cmux_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void, c_void]),
     "cufhe_amd_polymul_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
     "cufhe_amd_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),
     "cufhe_amd_profile_enable": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

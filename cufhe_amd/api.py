@@ -233,6 +233,22 @@ def keyswitch_batch(tlwe1, tlwe0, count, device=0, stream=None):
     check(lib.cufhe_amd_keyswitch_batch(device, stream, count, tlwe1.ptr, tlwe0.ptr))
 
 
+def sample_extract_keyswitch_batch(trlwe, tlwe0, count, device=0, stream=None):
+    check(lib.cufhe_amd_sample_extract_keyswitch_batch(device, stream, count, trlwe.ptr, tlwe0.ptr))
+
+
+def refresh_batch(trlwe_in, trlwe_out, count, device=0, stream=None):
+    check(lib.cufhe_amd_refresh_batch(device, stream, count, trlwe_in.ptr, trlwe_out.ptr))
+
+
+def trgsw_to_ntt_batch(trgsw, trgsw_ntt, count, device=0, stream=None):
+    check(lib.cufhe_amd_trgsw_to_ntt_batch(device, stream, count, trgsw.ptr, trgsw_ntt.ptr))
+
+
+def cmux_batch(trgsw_ntt, c1, c0, res, count, device=0, stream=None):
+    check(lib.cufhe_amd_cmux_batch(device, stream, count, trgsw_ntt.ptr, c1.ptr, c0.ptr, res.ptr))
+
+
 def polymul_batch(a, b, res, count, device=0, stream=None):
     check(lib.cufhe_amd_polymul_batch(device, stream, count, a.ptr, b.ptr, res.ptr))
 

@@ -650,6 +650,89 @@ int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint
     return launch_keyswitch(s, st, d, count);
 }
 
+int cufhe_amd_trgsw_to_ntt_batch(int device, void* stream, size_t count, const uint32_t* trgsw, double* trgsw_ntt)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (!trgsw || !trgsw_ntt) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    const size_t polys = count * kBkPolysPerStep;
+    const unsigned blocks = (unsigned)((polys + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, (hipStream_t)stream, trgsw_ntt,
+                       trgsw, polys, g_dev[device].tables, n_inverse_balanced());
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* trgsw_ntt, const uint32_t* c1,
+                         const uint32_t* c0, uint32_t* res)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (!trgsw_ntt || !c1 || !c0 || !res) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    const unsigned blocks = (unsigned)((count + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(cmux_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, (hipStream_t)stream, res, trgsw_ntt,
+                       c1, c0, (int)count, g_dev[device].tables);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cufhe_amd_sample_extract_keyswitch_batch(int device, void* stream, size_t count, const uint32_t* trlwe, uint32_t* tlwe0)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!trlwe || !tlwe0) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    if (int rc = open_scratch(s, st, count * (kLvl1Words * sizeof(uint32_t) + sizeof(LinDesc)) + 8192, &sc)) return rc;
+    uint32_t* t1;
+    if (int rc = sc.alloc((void**)&t1, count * kLvl1Words * sizeof(uint32_t))) return rc;
+    hipLaunchKernelGGL(sample_extract_kernel, dim3((unsigned)(count < 2048 ? count : 2048)), dim3(256), 0, st, t1, trlwe, (int)count);
+    HIP_TRY(hipGetLastError());
+    std::vector<LinDesc> ks(count);
+    for (size_t g = 0; g < count; g++)
+        ks[g] = {t1 + g * kLvl1Words, t1 + g * kLvl1Words, tlwe0 + g * kLvl0Words, 1, 0, 0u, 0u};
+    LinDesc* d;
+    if (int rc = upload_descs(s, sc, ks, &d)) return rc;
+    return launch_keyswitch(s, st, d, count);
+}
+
+int cufhe_amd_refresh_batch(int device, void* stream, size_t count, const uint32_t* trlwe_in, uint32_t* trlwe_out)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!trlwe_in || !trlwe_out) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    if (int rc = open_scratch(s, st, count * ((kLvl1Words + kLvl0Words) * sizeof(uint32_t) + 2 * sizeof(LinDesc)) + 16384, &sc)) return rc;
+    uint32_t *t1, *t0;
+    if (int rc = sc.alloc((void**)&t1, count * kLvl1Words * sizeof(uint32_t))) return rc;
+    if (int rc = sc.alloc((void**)&t0, count * kLvl0Words * sizeof(uint32_t))) return rc;
+    hipLaunchKernelGGL(sample_extract_kernel, dim3((unsigned)(count < 2048 ? count : 2048)), dim3(256), 0, st, t1, trlwe_in, (int)count);
+    HIP_TRY(hipGetLastError());
+    std::vector<LinDesc> ks(count), rot(count);
+    for (size_t g = 0; g < count; g++) {
+        ks[g] = {t1 + g * kLvl1Words, t1 + g * kLvl1Words, t0 + g * kLvl0Words, 1, 0, 0u, 0u};
+        rot[g] = {t0 + g * kLvl0Words, t0 + g * kLvl0Words, nullptr, 1, 0, 0u, 0u};
+    }
+    LinDesc *dks, *drot;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = launch_keyswitch(s, st, dks, count)) return rc;
+    return launch_blind_rotate(s, st, drot, count, kLvl0N, trlwe_out);
+}
+
 int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a, const uint32_t* b, uint32_t* res)
 {
     if (int rc = use_device(device)) return rc;

@@ -668,6 +668,78 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_wg_kernel(
     }
 }
 
+// __SampleExtractIndex__<P,0> on TRLWEs in global memory: trlwe[count][2N] -> tlwe1[count][N+1]
+__global__ __launch_bounds__(256) void sample_extract_kernel(uint32_t* __restrict__ tlwe1,
+                                                             const uint32_t* __restrict__ trlwe, int count)
+{
+    for (int g = blockIdx.x; g < count; g += gridDim.x) {
+        const uint32_t* in = trlwe + (size_t)g * 2 * kN;
+        uint32_t* o = tlwe1 + (size_t)g * kLvl1Words;
+        for (int m = threadIdx.x; m <= kN; m += blockDim.x)
+            o[m] = (m == kN) ? in[kN] : (m == 0 ? in[0] : 0u - in[kN - m]);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// CMUX against a caller-supplied TRGSW in the NTT domain (one wave per CMUX):
+// res = c0 + trgsw [x] (c1 - c0), __CMUXNTT__ src/bootstrap_gpu.cu:197-285.  trgsw_ntt holds
+// (k+1)l rows of two polynomials in the layout bk_to_ntt_kernel writes.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNttThreads) void cmux_kernel(
+    uint32_t* __restrict__ res, const double* __restrict__ trgsw_ntt,
+    const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c0, int count,
+    const NttTables* __restrict__ gt)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    load_tables_to_lds((double*)smem, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
+    if (g >= count) return;
+    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
+    const uint32_t* p1 = c1 + (size_t)g * 2 * kN;
+    const uint32_t* p0 = c0 + (size_t)g * 2 * kN;
+    const double2* key = (const double2*)(trgsw_ntt + (size_t)g * kBkStepDoubles);
+    double A0[kRegs], A1[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+        uint32_t temp[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) {
+            const int e = j * kN + lane + 64 * r;
+            temp[r] = (p1[e] - p0[e] + decomp_offset()) ^ decomp_signmask();   // TRLWESubAndDecomposition :162-195
+        }
+#pragma unroll 1
+        for (int d = 0; d < kL; d++) {
+            const int lsh = d * kBgbit;
+            double x[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) x[r] = (double)((int32_t)(temp[r] << lsh) >> (32 - kBgbit));
+            ntt_forward<true>(x, ctx);
+            const double2* row = key + (size_t)(j * kL + d) * kN;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const double2 b0 = row[q * 64 + lane], b1 = row[512 + q * 64 + lane];
+                A0[2 * q] += fpf::mulmod_wide(x[2 * q], b0.x);
+                A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b0.y);
+                A1[2 * q] += fpf::mulmod_wide(x[2 * q], b1.x);
+                A1[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b1.y);
+            }
+        }
+    }
+    uint32_t* o = res + (size_t)g * 2 * kN;
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) { A0[r] = fpf::reduce(A0[r]); A1[r] = fpf::reduce(A1[r]); }
+    ntt_inverse(A0, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) o[lane + 64 * r] = p0[lane + 64 * r] + fpf::lift_u32(A0[r]);
+    ntt_inverse(A1, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) o[kN + lane + 64 * r] = p0[kN + lane + 64 * r] + fpf::lift_u32(A1[r]);
+}
+
 // out = ca*in0 + cb*in1 + (0,..,off) over `words` words; grid-stride over ciphertexts
 __global__ __launch_bounds__(256) void lincomb_kernel(const LinDesc* __restrict__ descs, int count, int words)
 {

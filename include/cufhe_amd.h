@@ -122,6 +122,20 @@ int cufhe_amd_blind_rotate_batch(int device, void* stream, size_t count, const u
  * tlwe1[count][N+1] -> tlwe0[count][n+1] */
 int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint32_t* tlwe1,
                               uint32_t* tlwe0);
+/* SampleExtractAndKeySwitch on TRLWEs (src/cufhe_gates_gpu.cu:126-146): trlwe[count][2N] -> tlwe0 */
+int cufhe_amd_sample_extract_keyswitch_batch(int device, void* stream, size_t count,
+                                             const uint32_t* trlwe, uint32_t* tlwe0);
+/* Refresh (src/cufhe_gates_gpu.cu:106-124, SEIandBootstrap2TRLWE src/bootstrap_gpu.cu:325-364):
+ * trlwe_in[count][2N] -> sample extract -> key switch -> blind rotate -> trlwe_out[count][2N] */
+int cufhe_amd_refresh_batch(int device, void* stream, size_t count, const uint32_t* trlwe_in,
+                            uint32_t* trlwe_out);
+/* TRGSW2NTT (src/bootstrap_gpu.cu:75-94): trgsw[count][(k+1)l][k+1][N] torus words ->
+ * trgsw_ntt[count][(k+1)l][k+1][N] doubles (this library's NTT domain; opaque to callers) */
+int cufhe_amd_trgsw_to_ntt_batch(int device, void* stream, size_t count, const uint32_t* trgsw,
+                                 double* trgsw_ntt);
+/* CMUXNTT (src/bootstrap_gpu.cu:197-285): res = c0 + trgsw [x] (c1 - c0), TRLWEs [count][2N] */
+int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* trgsw_ntt,
+                         const uint32_t* c1, const uint32_t* c0, uint32_t* res);
 /* NTT product check of test/test_polynomial_mult_1024.cu: res = a * b negacyclic mod 2^32,
  * a signed with |a| <= 128 (exactness bound of the field), all [count][N], device. */
 int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a,

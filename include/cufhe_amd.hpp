@@ -47,6 +47,8 @@ struct lvl10param {
     static constexpr uint32_t t = 8, basebit = 2;
 };
 template <class P> using TLWE = std::array<typename P::T, P::k * P::n + 1>;
+template <class P> using TRLWE = std::array<std::array<typename P::T, P::n>, P::k + 1>;
+template <class P> using TRGSW = std::array<TRLWE<P>, (P::k + 1) * P::l>;
 }  // namespace TFHEpp
 #endif
 
@@ -161,6 +163,116 @@ CUFHE_AMD_GATE1(Not, CUFHE_AMD_NOT)
 CUFHE_AMD_GATE1(Copy, CUFHE_AMD_COPY)
 CUFHE_AMD_GATE3(Mux, CUFHE_AMD_MUX)
 CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
+
+// ---- TRLWE-level primitives, include/cufhe_gpu.cuh:123-146,209-216,282-285 ----
+// Same names and operands as the reference.  They complete before returning (the reference
+// returns after enqueueing and needs Synchronize(); code written for it keeps working).
+
+/// struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134
+struct cuFHETRLWElvl1 {
+    TFHEpp::TRLWE<TFHEpp::lvl1param> trlwehost;
+    std::vector<TFHEpp::lvl1param::T*> trlwedevices;
+    cuFHETRLWElvl1()
+    {
+        trlwedevices.resize(GetGPUNum());
+        for (int i = 0; i < GetGPUNum(); i++) CUFHE_AMD_CHECK(cufhe_amd_malloc(i, sizeof(trlwehost), (void**)&trlwedevices[i]));
+    }
+    ~cuFHETRLWElvl1() { for (size_t i = 0; i < trlwedevices.size(); i++) cufhe_amd_free((int)i, trlwedevices[i]); }
+    cuFHETRLWElvl1(const cuFHETRLWElvl1&) = delete;
+    cuFHETRLWElvl1& operator=(const cuFHETRLWElvl1&) = delete;
+};
+
+/// struct cuFHETRGSWNTTlvl1, :136-146.  The NTT-domain words are this library's (exact
+/// residues mod a 50-bit prime carried in doubles); like the reference's FFP words they are
+/// only meaningful to CMUXNTT.
+struct cuFHETRGSWNTTlvl1 {
+    std::array<double, (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::l * (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::n> trgswhost;
+    std::vector<double*> trgswdevices;
+    cuFHETRGSWNTTlvl1()
+    {
+        trgswdevices.resize(GetGPUNum());
+        for (int i = 0; i < GetGPUNum(); i++) CUFHE_AMD_CHECK(cufhe_amd_malloc(i, sizeof(trgswhost), (void**)&trgswdevices[i]));
+    }
+    ~cuFHETRGSWNTTlvl1() { for (size_t i = 0; i < trgswdevices.size(); i++) cufhe_amd_free((int)i, trgswdevices[i]); }
+    cuFHETRGSWNTTlvl1(const cuFHETRGSWNTTlvl1&) = delete;
+    cuFHETRGSWNTTlvl1& operator=(const cuFHETRGSWNTTlvl1&) = delete;
+};
+
+namespace detail {
+inline void h2d(Stream st, void* d, const void* h, size_t bytes) { CUFHE_AMD_CHECK(cufhe_amd_memcpy_h2d(st.device_id(), st.st(), d, h, bytes)); }
+inline void d2h_wait(Stream st, void* h, const void* d, size_t bytes)
+{
+    CUFHE_AMD_CHECK(cufhe_amd_memcpy_d2h(st.device_id(), st.st(), h, d, bytes));
+    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(st.device_id(), st.st()));
+}
+}  // namespace detail
+
+/// TRGSW2NTT, src/bootstrap_gpu.cu:75-94
+inline void TRGSW2NTT(cuFHETRGSWNTTlvl1& trgswntt, const TFHEpp::TRGSW<TFHEpp::lvl1param>& trgsw, Stream& st)
+{
+    const int dev = st.device_id();
+    void* d_trgsw = nullptr;
+    CUFHE_AMD_CHECK(cufhe_amd_malloc(dev, sizeof(trgsw), &d_trgsw));
+    detail::h2d(st, d_trgsw, trgsw.data(), sizeof(trgsw));
+    CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt_batch(dev, st.st(), 1, (const uint32_t*)d_trgsw, trgswntt.trgswdevices[dev]));
+    detail::d2h_wait(st, trgswntt.trgswhost.data(), trgswntt.trgswdevices[dev], sizeof(trgswntt.trgswhost));
+    CUFHE_AMD_CHECK(cufhe_amd_free(dev, d_trgsw));
+}
+/// gGateBootstrappingTLWE2TRLWElvl01NTT / GateBootstrappingTLWE2TRLWElvl01NTT, src/cufhe_gates_gpu.cu:86-104
+inline void gGateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
+{
+    Synchronize();      // the input may be the result of a recorded gate
+    const int dev = st.device_id();
+    CUFHE_AMD_CHECK(cufhe_amd_blind_rotate_batch(dev, st.st(), 1, in.tlwedevices[dev], out.trlwedevices[dev], -1));
+    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+}
+inline void GateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
+{
+    Synchronize();
+    const int dev = st.device_id();
+    detail::h2d(st, in.tlwedevices[dev], in.tlwehost.data(), sizeof(in.tlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_blind_rotate_batch(dev, st.st(), 1, in.tlwedevices[dev], out.trlwedevices[dev], -1));
+    detail::d2h_wait(st, out.trlwehost.data(), out.trlwedevices[dev], sizeof(out.trlwehost));
+}
+/// gRefresh / Refresh, src/cufhe_gates_gpu.cu:106-124
+inline void gRefresh(cuFHETRLWElvl1& out, cuFHETRLWElvl1& in, Stream st)
+{
+    const int dev = st.device_id();
+    CUFHE_AMD_CHECK(cufhe_amd_refresh_batch(dev, st.st(), 1, in.trlwedevices[dev], out.trlwedevices[dev]));
+    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+}
+inline void Refresh(cuFHETRLWElvl1& out, cuFHETRLWElvl1& in, Stream st)
+{
+    const int dev = st.device_id();
+    detail::h2d(st, in.trlwedevices[dev], in.trlwehost.data(), sizeof(in.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_refresh_batch(dev, st.st(), 1, in.trlwedevices[dev], out.trlwedevices[dev]));
+    detail::d2h_wait(st, out.trlwehost.data(), out.trlwedevices[dev], sizeof(out.trlwehost));
+}
+/// gSampleExtractAndKeySwitch / SampleExtractAndKeySwitch, src/cufhe_gates_gpu.cu:126-146
+/// (both upload `in.trlwehost`, as the reference does)
+inline void gSampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHETRLWElvl1& in, Stream st)
+{
+    Synchronize();
+    const int dev = st.device_id();
+    detail::h2d(st, in.trlwedevices[dev], in.trlwehost.data(), sizeof(in.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_sample_extract_keyswitch_batch(dev, st.st(), 1, in.trlwedevices[dev], out.tlwedevices[dev]));
+    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+}
+inline void SampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHETRLWElvl1& in, Stream st)
+{
+    gSampleExtractAndKeySwitch(out, in, st);
+    detail::d2h_wait(st, out.tlwehost.data(), out.tlwedevices[st.device_id()], sizeof(out.tlwehost));
+}
+/// CMUXNTT, src/cufhe_gates_gpu.cu:68-85: res = cs ? c1 : c0
+inline void CMUXNTT(cuFHETRLWElvl1& res, cuFHETRGSWNTTlvl1& cs, cuFHETRLWElvl1& c1, cuFHETRLWElvl1& c0, Stream st)
+{
+    const int dev = st.device_id();
+    detail::h2d(st, cs.trgswdevices[dev], cs.trgswhost.data(), sizeof(cs.trgswhost));
+    detail::h2d(st, c1.trlwedevices[dev], c1.trlwehost.data(), sizeof(c1.trlwehost));
+    detail::h2d(st, c0.trlwedevices[dev], c0.trlwehost.data(), sizeof(c0.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_cmux_batch(dev, st.st(), 1, cs.trgswdevices[dev], c1.trlwedevices[dev], c0.trlwedevices[dev], res.trlwedevices[dev]));
+    detail::d2h_wait(st, res.trlwehost.data(), res.trlwedevices[dev], sizeof(res.trlwehost));
+}
 
 #undef CUFHE_AMD_GATE1
 #undef CUFHE_AMD_GATE2

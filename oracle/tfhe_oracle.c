@@ -463,6 +463,56 @@ void orc_keyswitch(const orc_evalkey* ek, uint32_t* lwe, const uint32_t* tlwe)
 }
 
 /* ------------------------------------------------------------------ */
+/* TRLWE-level primitives                                             */
+/* ------------------------------------------------------------------ */
+/* __CMUXNTT__ with TRLWESubAndDecomposition, src/bootstrap_gpu.cu:162-285 */
+void orc_cmux(uint32_t* res, const uint32_t* trgsw, const uint32_t* c1, const uint32_t* c0)
+{
+    const uint32_t decomp_mask = (1u << ORC_BGBIT) - 1;
+    const int32_t decomp_half = 1 << (ORC_BGBIT - 1);
+    uint32_t decomp_offset = 0;
+    for (int i = 1; i <= ORC_L; i++) decomp_offset += (uint32_t)(1u << (ORC_BGBIT - 1)) << (32 - i * ORC_BGBIT);
+    const uint32_t roundoffset = 1u << (32 - ORC_L * ORC_BGBIT - 1);
+    ntt_tables();
+    uint64_t accum[(ORC_K + 1) * ORC_N], work[ORC_N], key[ORC_N];
+    memset(accum, 0, sizeof(accum));
+    for (int j = 0; j <= ORC_K; j++)
+        for (int digit = 0; digit < ORC_L; digit++) {
+            for (int i = 0; i < ORC_N; i++) {
+                const uint32_t temp = c1[j * ORC_N + i] - c0[j * ORC_N + i] + decomp_offset + roundoffset;
+                work[i] = ffp_from_i32((int32_t)((temp >> (32 - (digit + 1) * ORC_BGBIT)) & decomp_mask) - decomp_half);
+            }
+            orc_ntt_forward(work);
+            for (int out_k = 0; out_k <= ORC_K; out_k++) {
+                const uint32_t* row = trgsw + ((size_t)(j * ORC_L + digit) * (ORC_K + 1) + out_k) * ORC_N;
+                for (int i = 0; i < ORC_N; i++) key[i] = row[i];
+                orc_ntt_forward(key);                    /* TRGSW2NTT, src/bootstrap_gpu.cu:75-94 */
+                uint64_t* ac = accum + out_k * ORC_N;
+                for (int i = 0; i < ORC_N; i++) ac[i] = mod_add(ac[i], barrett_mult(work[i], key[i]));
+            }
+        }
+    for (int k = 0; k <= ORC_K; k++) {
+        uint64_t* ac = accum + k * ORC_N;
+        orc_ntt_inverse(ac);
+        for (int i = 0; i < ORC_N; i++) res[k * ORC_N + i] = c0[k * ORC_N + i] + ffp_lift_u32(ac[i]);
+    }
+}
+
+void orc_sample_extract_keyswitch(const orc_evalkey* ek, uint32_t* tlwe0, const uint32_t* trlwe)
+{
+    uint32_t t1[ORC_LVL1_WORDS];
+    orc_sample_extract0(t1, trlwe);
+    orc_keyswitch(ek, tlwe0, t1);
+}
+
+void orc_refresh(const orc_evalkey* ek, uint32_t* trlwe_out, const uint32_t* trlwe_in)
+{
+    uint32_t t0[ORC_LVL0_WORDS];
+    orc_sample_extract_keyswitch(ek, t0, trlwe_in);
+    orc_blind_rotate(ek, trlwe_out, t0, -1);
+}
+
+/* ------------------------------------------------------------------ */
 /* Gates                                                              */
 /* ------------------------------------------------------------------ */
 /* (ca, cb, offset/mu): src/bootstrap_gpu.cu:424-512 (br->iks) and :591-679 (iks->br) */

@@ -110,6 +110,16 @@ void orc_blind_rotate(const orc_evalkey* ek, uint32_t* acc /*[2N]*/,
 void orc_sample_extract0(uint32_t* tlwe1 /*[N+1]*/, const uint32_t* acc /*[2N]*/);
 void orc_keyswitch(const orc_evalkey* ek, uint32_t* tlwe0 /*[n+1]*/, const uint32_t* tlwe1 /*[N+1]*/);
 
+/* ---- TRLWE-level primitives (src/cufhe_gates_gpu.cu:69-146) ---- */
+/* CMUXNTT (src/bootstrap_gpu.cu:162-285): res = c0 + trgsw [x] (c1 - c0); trgsw is a torus-domain
+ * TRGSW [(k+1)l][k+1][N], trlwe operands are [(k+1)N] words */
+void orc_cmux(uint32_t* res, const uint32_t* trgsw, const uint32_t* c1, const uint32_t* c0);
+/* SEIandKS (src/keyswitch_gpu.cu:26-40): sample extract at 0, then key switch */
+void orc_sample_extract_keyswitch(const orc_evalkey* ek, uint32_t* tlwe0, const uint32_t* trlwe);
+/* Refresh / SEIandBootstrap2TRLWE (src/bootstrap_gpu.cu:325-364) with the test vector taken
+ * from the key-switched ciphertext (the reference reads an uninitialised buffer there) */
+void orc_refresh(const orc_evalkey* ek, uint32_t* trlwe_out, const uint32_t* trlwe_in);
+
 /* whole gates.  level 0: ctxts are lvl0 TLWEs (blind rotate -> key switch);
  * level 1: ctxts are lvl1 TLWEs (key switch -> blind rotate).
  * in2 is only read by MUX/NMUX (out = in0 ? in1 : in2), in1 unused for NOT/COPY. */

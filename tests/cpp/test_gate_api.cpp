@@ -152,6 +152,48 @@ void DeviceResident(std::mt19937& eng)
     st.Destroy();
 }
 
+// test/test_perf.cc:36-87 (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt coefficient 0)
+// and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch.
+void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
+{
+    using namespace TFHEpp;
+    Stream st;
+    st.Create();
+    int bad = 0, total = 0;
+    auto coeff0 = [&](cuFHETRLWElvl1& t) {
+        uint32_t tl[ORC_LVL1_WORDS];
+        orc_sample_extract0(tl, t.trlwehost[0].data());
+        return orc_tlwe_decrypt(1, g_s1.data(), tl);
+    };
+    for (int rep = 0; rep < 8; rep++) {
+        const int bit = eng() & 1;
+        Ctxt<lvl0param> in, out0;
+        encrypt(in, bit);
+        cuFHETRLWElvl1 t, r;
+        GateBootstrappingTLWE2TRLWElvl01NTT(t, in, st);
+        bad += coeff0(t) != bit; total++;
+        Refresh(r, t, st);
+        bad += coeff0(r) != bit; total++;
+        SampleExtractAndKeySwitch(out0, r, st);
+        bad += decrypt(out0) != bit; total++;
+        // CMUX: the bootstrapping key row i is a TRGSW encryption of s0[i]
+        const int i = eng() % ORC_n;
+        TRGSW<lvl1param> trgsw;
+        std::memcpy(trgsw.data(), bk.data() + (size_t)i * ORC_BK_ROWS * 2 * ORC_N, sizeof(trgsw));
+        cuFHETRGSWNTTlvl1 cs;
+        TRGSW2NTT(cs, trgsw, st);
+        Ctxt<lvl0param> other;
+        encrypt(other, 1 - bit);
+        cuFHETRLWElvl1 t_other, res;
+        GateBootstrappingTLWE2TRLWElvl01NTT(t_other, other, st);
+        CMUXNTT(res, cs, t, t_other, st);          // s0[i] ? t : t_other
+        bad += coeff0(res) != (g_s0[i] ? bit : 1 - bit); total++;
+    }
+    std::printf("TRLWE-level primitives: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, total);
+    g_failures += bad;
+    st.Destroy();
+}
+
 int main(int argc, char** argv)
 {
     const int gpus = argc > 1 ? atoi(argv[1]) : 1;
@@ -170,6 +212,7 @@ int main(int argc, char** argv)
     Chained(eng);
     Intensive(eng);
     DeviceResident(eng);
+    TrlwePrimitives(eng, bk);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
     return g_failures ? 1 : 0;

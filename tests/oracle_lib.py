@@ -55,6 +55,9 @@ def load():
     L.orc_gate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _u32, _u32, _u32, _u32]
     L.orc_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                  _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.orc_cmux.argtypes = [_u32, _u32, _u32, _u32]
+    L.orc_sample_extract_keyswitch.argtypes = [ctypes.c_void_p, _u32, _u32]
+    L.orc_refresh.argtypes = [ctypes.c_void_p, _u32, _u32]
     L.orc_truth.argtypes = [ctypes.c_int] * 4
     L.orc_gate_coeffs.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
     return L

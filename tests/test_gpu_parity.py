@@ -240,3 +240,53 @@ def test_cpp_gate_api_mirror(engine):
         k = oracle_lib.Keys(oracle_lib.load(), seed=1)
         engine.SetGPUNum(1)
         engine.Initialize(k.bk, k.ksk)
+
+
+def test_trlwe_level_primitives(engine, keys, oracle):
+    """SampleExtractAndKeySwitch, Refresh, TRGSW2NTT + CMUXNTT (src/cufhe_gates_gpu.cu:69-146):
+    words identical to the oracle; Refresh keeps the plaintext (test/test_perf.cc:83-87)."""
+    count = 6
+    rng = np.random.default_rng(21)
+    # TRLWEs produced by real blind rotations of encryptions of known bits
+    bits = np.array([0, 1, 1, 0, 1, 0], np.uint8)
+    cts = keys.encrypt(bits, 0, seed=333)
+    trl = np.zeros((count, 2 * ol.N), np.uint32)
+    for g in range(count):
+        oracle.orc_blind_rotate(keys.ek, trl[g], np.ascontiguousarray(cts[g]), -1)
+    dtrl = _upload(engine, trl)
+    # SEI + KS
+    d0 = engine.api.DeviceBuffer(count * (ol.n + 1))
+    engine.api.sample_extract_keyswitch_batch(dtrl, d0, count)
+    got = d0.download().reshape(count, -1)
+    for g in range(count):
+        want = np.zeros(ol.n + 1, np.uint32)
+        oracle.orc_sample_extract_keyswitch(keys.ek, want, np.ascontiguousarray(trl[g]))
+        assert np.array_equal(got[g], want)
+    assert list(keys.decrypt(got, 0)) == list(bits)
+    # Refresh
+    dout = engine.api.DeviceBuffer(count * 2 * ol.N)
+    engine.api.refresh_batch(dtrl, dout, count)
+    got = dout.download().reshape(count, -1)
+    for g in range(count):
+        want = np.zeros(2 * ol.N, np.uint32)
+        oracle.orc_refresh(keys.ek, want, np.ascontiguousarray(trl[g]))
+        assert np.array_equal(got[g], want)
+        t1 = np.zeros(ol.N + 1, np.uint32)
+        oracle.orc_sample_extract0(t1, np.ascontiguousarray(got[g]))
+        assert keys.decrypt(t1, 1)[0] == bits[g]
+    # CMUX with random TRGSW words (exactness does not depend on the key being valid)
+    trgsw = rng.integers(0, 2**32, size=(count, 6, 2, ol.N), dtype=np.uint64).astype(np.uint32)
+    c1 = rng.integers(0, 2**32, size=(count, 2 * ol.N), dtype=np.uint64).astype(np.uint32)
+    c0 = rng.integers(0, 2**32, size=(count, 2 * ol.N), dtype=np.uint64).astype(np.uint32)
+    c1[0] = c0[0]                                   # zero difference: res = c0
+    dtg, dc1, dc0 = _upload(engine, trgsw), _upload(engine, c1), _upload(engine, c0)
+    dntt = engine.api.DeviceBuffer(count * 12 * ol.N * 2)        # doubles = 2 words each
+    engine.api.trgsw_to_ntt_batch(dtg, dntt, count)
+    dres = engine.api.DeviceBuffer(count * 2 * ol.N)
+    engine.api.cmux_batch(dntt, dc1, dc0, dres, count)
+    got = dres.download().reshape(count, -1)
+    assert np.array_equal(got[0], c0[0])
+    for g in range(count):
+        want = np.zeros(2 * ol.N, np.uint32)
+        oracle.orc_cmux(want, np.ascontiguousarray(trgsw[g]).ravel(), np.ascontiguousarray(c1[g]), np.ascontiguousarray(c0[g]))
+        assert np.array_equal(got[g], want)
