@@ -212,7 +212,7 @@ NMux, gNMux = _make3(NMUX, True), _make3(NMUX, False)
 def gate_batch(ops, level, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
     """ops: one op code or an int array of `count` codes; operands are DeviceBuffers holding
     `count` contiguous ciphertexts."""
-    words = LVL_WORDS[level]
+    words = LVL_WORDS[level] if level in (0, 1) else 1     # a bad level is rejected by the library
     if count is None:
         count = out.words // words
     if np.isscalar(ops):

@@ -290,3 +290,59 @@ def test_trlwe_level_primitives(engine, keys, oracle):
         want = np.zeros(2 * ol.N, np.uint32)
         oracle.orc_cmux(want, np.ascontiguousarray(trgsw[g]).ravel(), np.ascontiguousarray(c1[g]), np.ascontiguousarray(c0[g]))
         assert np.array_equal(got[g], want)
+
+
+@pytest.mark.parametrize("count", [1, 7, 9, 17, 129, 300, 1031])
+def test_ragged_batch_sizes(engine, keys, count):
+    """Batch sizes that are not multiples of the 8-rotation / 16-ciphertext workgroups, on both
+    sides of the kernel-selection thresholds; every output must decrypt correctly and a
+    sample is compared word for word with the oracle."""
+    rng = np.random.default_rng(count)
+    bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=7000 + count + i) for i in range(2)]
+    dins = [_upload(engine, x) for x in ins]
+    dout = engine.api.DeviceBuffer(count * (ol.n + 1))
+    for thr in (0, 1 << 30):            # batch kernels, then low-latency kernels
+        if thr and count > 300:
+            continue                     # one workgroup per rotation: keep the test short
+        engine.api.set_option("wg_threshold", thr)
+        engine.api.set_option("ks_wg_threshold", thr)
+        try:
+            dout.upload(np.zeros(count * (ol.n + 1), np.uint32))
+            engine.gate_batch(ol.OPS.index("XOR"), 0, dout, dins[0], dins[1], count=count)
+            got = dout.download().reshape(count, -1)
+        finally:
+            engine.api.set_option("wg_threshold", 1024)
+            engine.api.set_option("ks_wg_threshold", 128)
+        assert np.array_equal(keys.decrypt(got, 0), bits[0] ^ bits[1])
+        idx = np.unique(np.array([0, count // 2, count - 1]))
+        want = keys.gate_batch(ol.OPS.index("XOR"), 0, ins[0][idx], ins[1][idx])
+        assert np.array_equal(got[idx], want)
+
+
+def test_empty_batch_and_errors(engine):
+    api = engine.api
+    buf = api.DeviceBuffer(ol.n + 1)
+    api.gate_batch(0, 0, buf, buf, buf, count=0)          # no-op
+    with pytest.raises(engine.CufheAmdError):
+        api.gate_batch(99, 0, buf, buf, buf, count=1)      # unknown op
+    with pytest.raises(engine.CufheAmdError):
+        api.gate_batch(0, 2, buf, buf, buf, count=1)       # bad level
+    with pytest.raises(engine.CufheAmdError):
+        api.gate_batch(0, 0, buf, buf, None, count=1)      # missing operand
+
+
+def test_two_levels_in_one_scheduler_batch(engine, keys):
+    """lvl0 and lvl1 gates recorded together are launched in one flush (two launch sequences)."""
+    api = engine.api
+    st = api.Stream()
+    st.Create()
+    a0, b0, o0 = api.Ctxt(0), api.Ctxt(0), api.Ctxt(0)
+    a1, b1, o1 = api.Ctxt(1), api.Ctxt(1), api.Ctxt(1)
+    a0.tlwehost[:] = keys.encrypt([1], 0, seed=1)[0]; b0.tlwehost[:] = keys.encrypt([1], 0, seed=2)[0]
+    a1.tlwehost[:] = keys.encrypt([0], 1, seed=3)[0]; b1.tlwehost[:] = keys.encrypt([1], 1, seed=4)[0]
+    api.And(o0, a0, b0, st)
+    api.OrNY(o1, a1, b1, st)
+    api.Synchronize()
+    assert keys.decrypt(o0.tlwehost, 0)[0] == 1 and keys.decrypt(o1.tlwehost, 1)[0] == 1
+    st.Destroy()
