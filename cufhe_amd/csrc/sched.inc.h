@@ -159,10 +159,12 @@ int sched_flush(int device)
     }
     HIP_TRY(hipEventCreateWithFlags(&b->done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->done, s.st));
+    const size_t in_cap = b->in_words.capacity();
     std::vector<uint32_t>().swap(b->in_words);
     s.inflight.push_back(b);
     s.cur = new Batch();
     s.cur->id = s.next_id++;
+    s.cur->in_words.reserve(in_cap);          // batches of one program tend to repeat in size
     return 0;
 }
 
