@@ -23,14 +23,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# one process per GPU: make this rank's GPU the only visible device (before any HIP call).
+# one process per GPU: rank r drives physical device r of the node (device_base option below).
 # cufhe_amd/dist.py is pure Python; it is loaded by path so that the package (and with it the
 # HIP library) is imported only after torch.
 import importlib.util  # noqa: E402
 _spec = importlib.util.spec_from_file_location("cufhe_amd_dist", os.path.join(ROOT, "cufhe_amd", "dist.py"))
 distutil = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(distutil)
-RANK, LOCAL_RANK, WORLD = distutil.pin_gpu()
+RANK, LOCAL_RANK, WORLD = distutil.rank_env()
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its bundled HIP runtime is the one the process uses)
@@ -99,10 +100,12 @@ def main():
     if WORLD > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=RANK, world_size=WORLD)
-    torch.cuda.set_device(0)
+    DEV = distutil.device_for_rank(LOCAL_RANK, torch.cuda.device_count()) if WORLD > 1 else 0
+    torch.cuda.set_device(DEV)
     torch.cuda.init()
 
     import cufhe_amd as eng                  # fails loudly if the HIP library is missing
+    eng.api.set_option("device_base", DEV)   # logical device 0 of this process = this rank's GPU
     import oracle_lib as ol                   # sizes only, until the cpu_baseline leg
 
     count = args.gates

@@ -63,6 +63,7 @@ struct DeviceState {
 };
 
 int g_gpu_num = 1;
+int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 std::vector<DeviceState> g_dev(1);   // resized only while no device is initialised
@@ -129,7 +130,7 @@ int check_device(int device)
 int use_device(int device)
 {
     if (int rc = check_device(device)) return rc;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(device + g_device_base));
     return 0;
 }
 
@@ -137,7 +138,7 @@ int ensure_ntt(int device)
 {
     DeviceState& s = g_dev[device];
     if (s.ntt_ready) return 0;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipSetDevice(device + g_device_base));
     NttTables host;
     build_tables(host);
     HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
@@ -413,7 +414,7 @@ int cufhe_amd_set_gpu_num(int gpu_num)
     for (auto& d : g_dev)
         if (d.ntt_ready || d.keys_ready) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
     int have = cufhe_amd_device_count();
-    if (gpu_num > have) return fail(-1, "gpu_num exceeds the visible device count");
+    if (gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
     g_gpu_num = gpu_num;
     g_dev = std::vector<DeviceState>(gpu_num);
     return 0;
@@ -439,7 +440,7 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
     for (int i = 0; i < g_gpu_num; i++) {
         if (int rc = ensure_ntt(i)) return rc;
         DeviceState& s = g_dev[i];
-        HIP_TRY(hipSetDevice(i));
+        HIP_TRY(hipSetDevice(i + g_device_base));
         if (s.keys_ready) {
             HIP_TRY(hipFree(s.bk_ntt));
             HIP_TRY(hipFree(s.ksk));
@@ -478,7 +479,7 @@ int cufhe_amd_cleanup(void)
     for (int i = 0; i < g_gpu_num; i++) {
         DeviceState& s = g_dev[i];
         if (!s.ntt_ready && !s.keys_ready) continue;
-        HIP_TRY(hipSetDevice(i));
+        HIP_TRY(hipSetDevice(i + g_device_base));
         HIP_TRY(hipDeviceSynchronize());
         for (auto* v : {&s.br_events, &s.ks_events}) {
             for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -505,7 +506,7 @@ int cufhe_amd_synchronize(void)
         if (int rc = sched_synchronize_all()) return rc;
     }
     for (int i = 0; i < g_gpu_num; i++) {
-        HIP_TRY(hipSetDevice(i));
+        HIP_TRY(hipSetDevice(i + g_device_base));
         HIP_TRY(hipDeviceSynchronize());
     }
     return 0;
@@ -751,6 +752,13 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
 int cufhe_amd_set_option(const char* key, long value)
 {
     if (!key) return fail(-1, "null key");
+    if (!strcmp(key, "device_base")) {
+        for (auto& d : g_dev)
+            if (d.ntt_ready || d.keys_ready) return fail(-1, "device_base must be set before Initialize");
+        if (value < 0 || value + g_gpu_num > cufhe_amd_device_count()) return fail(-1, "device_base out of range");
+        g_device_base = (int)value;
+        return 0;
+    }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     return fail(-1, std::string("unknown option ") + key);

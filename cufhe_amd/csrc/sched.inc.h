@@ -218,7 +218,7 @@ void sched_destroy_all()
     for (int d = 0; d < (int)g_sched.size(); d++) {
         Sched& s = g_sched[d];
         if (!s.st) continue;
-        (void)hipSetDevice(d);
+        (void)hipSetDevice(d + g_device_base);
         (void)hipStreamSynchronize(s.st);
         for (Batch* b : s.inflight) { sched_finalize(d, s, b); delete b; }
         s.inflight.clear();
@@ -268,7 +268,7 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
     for (size_t d = 0; d < c->dev.size(); d++) busy = busy || c->write_batch[d] || c->read_batch[d];
     if (busy && sched_active()) (void)sched_synchronize_all();
     for (size_t d = 0; d < c->dev.size(); d++)
-        if (c->dev[d]) { (void)hipSetDevice((int)d); (void)hipFree(c->dev[d]); }
+        if (c->dev[d]) { (void)hipSetDevice((int)d + g_device_base); (void)hipFree(c->dev[d]); }
     if (c->registered) (void)hipHostUnregister(c->host);
     delete c;
     return 0;

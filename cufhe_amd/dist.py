@@ -19,13 +19,22 @@ def visible_device_for(local_rank, current=None):
 
 
 def pin_gpu(env=None):
-    """Set HIP_VISIBLE_DEVICES for this rank (call before anything touches HIP)."""
+    """Set HIP_VISIBLE_DEVICES for this rank (call before anything touches HIP).  Alternative to
+    device_for_rank() for launchers that prefer each rank to see a single device."""
     env = os.environ if env is None else env
     rank, local_rank, world = rank_env(env)
     if world > 1:
         env["HIP_VISIBLE_DEVICES"] = visible_device_for(local_rank, env.get("HIP_VISIBLE_DEVICES"))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return rank, local_rank, world
+
+
+def device_for_rank(local_rank, visible_count):
+    """Physical device index for this rank when all of the node's GPUs are visible to every
+    rank (what torch.distributed.run gives): local_rank, wrapped if fewer devices are visible."""
+    if visible_count <= 0:
+        raise RuntimeError("no GPU visible")
+    return local_rank % visible_count
 
 
 def shard(count, rank, world):

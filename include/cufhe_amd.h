@@ -142,6 +142,8 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
                             const uint32_t* b, uint32_t* res);
 
 /* ---- tuning ----
+ * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process
+ * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
  * "wg_threshold": launches of at most this many blind rotations use the workgroup-per-rotation
  * kernel (lowest latency); larger ones the wave-per-rotation batch kernel (highest throughput).
  * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words. */

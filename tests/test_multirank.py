@@ -20,7 +20,9 @@ import os, sys, time, importlib.util
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
 d = importlib.util.module_from_spec(spec); spec.loader.exec_module(d)
-rank, local_rank, world = d.pin_gpu()
+rank, local_rank, world = d.rank_env()
+assert d.device_for_rank(local_rank, 8) == local_rank and d.device_for_rank(local_rank, 1) == 0
+d.pin_gpu()
 assert os.environ["HIP_VISIBLE_DEVICES"] == str(local_rank)
 import numpy as np, torch, torch.distributed as dist
 import oracle_lib as ol
