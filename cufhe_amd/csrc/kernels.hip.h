@@ -8,14 +8,19 @@
 //                                                   include/keyswitch_gpu.cuh:83-188
 //   lincomb_kernel         __NotBootstrap__/__CopyBootstrap__ and the Mux/NMux sums
 //                                                   src/bootstrap_gpu.cu:681-703,728-740
+//   blind_rotate_wg_kernel / keyswitch_wg_kernel   the same two, one workgroup per ciphertext
+//                                                   (small launches: lowest latency)
+//   sample_extract_kernel, cmux_kernel             SEIandKS / Refresh / CMUXNTT pieces
+//                                                   src/keyswitch_gpu.cu:26-40, src/bootstrap_gpu.cu:197-285
 //   polymul_kernel         the NTT product check of test/test_polynomial_mult_1024.cu:76-99
 //
 // Execution model (not the reference's one-block-per-gate/one-launch-per-gate): a launch
 // covers a whole batch; ONE WAVEFRONT owns one blind rotation from the first CMux to the
 // sample extract.  Its accumulator (2 x 1024 torus words) and the two NTT-domain sums
-// (2 x 1024 residues) stay in VGPRs for all n = 630 steps, so the only global traffic of
-// the hot loop is the read of the bootstrapping key.  Waves never synchronise with each
-// other after the twiddle tables are staged in LDS.
+// (2 x 1024 residues) stay in VGPRs for all n = 630 steps.  The 8 waves of a workgroup walk
+// the bootstrapping key together: each 16 KiB TRGSW row is brought into LDS once per
+// workgroup by LDS-DMA and read from there by all 8; the row barrier is the only
+// synchronisation, the NTTs themselves need none.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,8 +60,8 @@ constexpr int kNttThreads = 64 * kNttWavesPerBlock;
 constexpr int kNttLdsBytes = kLdsTableBytes + kNttWavesPerBlock * kTileBytes;   // 49920
 
 // Blind rotate: ONE 8-wave workgroup per CU (2 waves per SIMD).  Its LDS holds the twiddle
-// tables, one transpose tile per wave, the abar list of every wave and a double-buffered
-// 16 KiB TRGSW row shared by the 8 waves (the BK tile staged in LDS).
+// tables, one transpose tile per wave, the abar list of every wave and three 16 KiB
+// buffers for the TRGSW row shared by the 8 waves (the BK tile staged in LDS).
 constexpr int kBrWavesPerBlock = 8;
 constexpr int kBrThreads = 64 * kBrWavesPerBlock;                               // 512
 constexpr int kBkRowBytes = 2 * kN * 8;                                         // 16384: one TRGSW row (2 polys)
