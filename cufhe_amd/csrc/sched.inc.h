@@ -61,7 +61,9 @@ struct Sched {
     std::vector<std::pair<uint32_t*, size_t>> dev_cache;
 };
 
-constexpr size_t kSchedMaxGates = 16384;
+// A batch is launched as soon as it holds one full round of the blind-rotate grid (256 CUs x 8
+// rotations): the GPU then works on it while the host records the next one.
+constexpr size_t kSchedMaxGates = 2048;
 std::vector<Sched> g_sched;
 std::mutex g_sched_mu;     // the reference API is single-issuer; this only guards against misuse
 

@@ -104,7 +104,7 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
 /* Nand(out, in0, in1, st) ... NMux, Not, Copy (copying != 0: src/cufhe_gates_gpu.cu:148-158,
  * inputs taken from tlwehost, result delivered to out's tlwehost) and gNand ... (copying == 0:
  * :160-167, device buffers only).  The gate is recorded; recorded gates of a device run as
- * one batch at Synchronize / StreamQuery / dependence / 16384 gates.  Stream order, output
+ * one batch at Synchronize / StreamQuery / dependence / 2048 gates.  Stream order, output
  * aliasing and completion semantics are those of the reference (see csrc/sched.inc.h). */
 int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
                            cufhe_amd_ctxt* in0, cufhe_amd_ctxt* in1, cufhe_amd_ctxt* in2);
