@@ -41,6 +41,29 @@ BK_BYTES_PER_ROTATION = 61931520          # n (k+1)^2 l N 8, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def recorded_hbm_traffic(rotations):
+    """HBM bytes per blind-rotate launch from the committed rocprofv3 PMC passes (separate
+    --pmc runs of this same command, profiles/r01_final_pmc_*): FETCH_SIZE is in KB and reads
+    half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.
+    Only meaningful for the launch shape it was recorded on (4096 rotations); else None."""
+    import csv
+    if rotations != 4096:
+        return None, None
+    try:
+        vals = {}
+        for name, f in (("FETCH_SIZE", "r01_final_pmc_fetch_counter_collection.csv"),
+                        ("WRITE_SIZE", "r01_final_pmc_tcc_counter_collection.csv")):
+            path = os.path.join(ROOT, "profiles", f)
+            best = 0.0
+            for r in csv.DictReader(open(path)):
+                if "blind_rotate_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                    best = max(best, float(r["Counter_Value"]))
+            vals[name] = best
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01_final_pmc_{fetch,tcc}_counter_collection.csv"
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
     """Time the CPU oracle on a bounded sample of the same workload; verify GPU words."""
     import ctypes
@@ -173,6 +196,7 @@ def main():
         ks_ms = prof.keyswitch_ms / max(prof.keyswitch_launches, 1)
         rotations = count * rot_per_gate
         achieved = BK_BYTES_PER_ROTATION * rotations / (br_ms * 1e-3) / 1e9
+        traffic, traffic_src = recorded_hbm_traffic(rotations)
         res = {
             "metric": "nand_gate_bootstraps_per_sec" if args.workload == "nand" else f"{args.workload}_gates_per_sec",
             "value": total_gates / elapsed,
@@ -198,7 +222,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "blind_rotate_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src,
                 "launch_ms": br_ms, "rotations_per_launch": rotations,
                 "algorithmic_bytes_per_rotation": BK_BYTES_PER_ROTATION,
                 "keyswitch_launch_ms": ks_ms,
