@@ -557,30 +557,35 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     if (lane == 29) res[2].z = bprime;           // word 630 = 4 * (29 + 128) + 2 starts from b'
     int off[kKsPieces];
     off[0] = lane * 16; off[1] = (lane + 64) * 16; off[2] = (lane < 32 ? lane + 128 : 159) * 16;
+    // per-buffer, per-piece LDS addresses kept in VGPRs: a row is then "VGPR + immediate"
+    const char* pbase[kKsBuffers][kKsPieces];
+#pragma unroll
+    for (int bi = 0; bi < kKsBuffers; bi++)
+#pragma unroll
+        for (int m = 0; m < kKsPieces; m++) pbase[bi][m] = smem + opaque(kKsLdsDigits + bi * kKsStepBytes + off[m]);
 
     __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
-#pragma unroll 1
-    for (int j = 0; j < kN; j++) {
-        // Counted wait: the pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight
-        // across the barrier, only step j must have landed.  lgkmcnt(0): this wave has
-        // finished reading step j-1, whose buffer step j+2 is about to overwrite.
+    // one step j: counted wait + barrier, issue step j+2, apply the 8 digits of a'_j
+    auto step = [&](int j, const char* const (&pb)[kKsPieces]) {
+        // The pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight across the
+        // barrier, only step j must have landed.  lgkmcnt(0): this wave has finished reading
+        // step j-1, whose buffer step j+2 is about to overwrite.
         if (j + 1 >= kN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if (wave < 8) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         issue(j + 2);
         const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
-        const char* buf = bufs + (j % kKsBuffers) * kKsStepBytes;
 #pragma unroll
         for (int k = 0; k < kKsT; k++) {
-            const int val = (int)((dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
-            if (val != 0) {
-                const int v = val > 0 ? val : -val;
-                const char* row = buf + (k * kKsNumBase + (v - 1)) * (kKsRowPad * 4);
+            // field f = val + 2: 0 -> +row(v=2), 1 -> +row(v=1), 2 -> nothing, 3 -> -row(v=1)
+            const uint32_t f = (dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1);
+            if (f != 2) {
+                const int roff = (k * kKsNumBase + (f == 0 ? 1 : 0)) * (kKsRowPad * 4);
                 uint4 r[kKsPieces];
 #pragma unroll
-                for (int m = 0; m < kKsPieces; m++) r[m] = *(const uint4*)(row + off[m]);
-                if (val > 0) {
+                for (int m = 0; m < kKsPieces; m++) r[m] = *(const uint4*)(pb[m] + roff);
+                if (f == 3) {
 #pragma unroll
                     for (int m = 0; m < kKsPieces; m++) { res[m].x -= r[m].x; res[m].y -= r[m].y; res[m].z -= r[m].z; res[m].w -= r[m].w; }
                 } else {
@@ -589,7 +594,15 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
                 }
             }
         }
+    };
+    static_assert(kKsBuffers == 3, "the j loop is unrolled by the number of buffers");
+#pragma unroll 1
+    for (int j = 0; j + 2 < kN; j += 3) {
+        step(j, pbase[0]);
+        step(j + 1, pbase[1]);
+        step(j + 2, pbase[2]);
     }
+    step(kN - 1, pbase[(kN - 1) % kKsBuffers]);   // 1024 = 3 * 341 + 1
     if (!live) return;
 #pragma unroll
     for (int m = 0; m < kKsPieces; m++) {
