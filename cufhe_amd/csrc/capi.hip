@@ -57,16 +57,13 @@ struct DeviceState {
     std::deque<PinnedBlock> staging;
     std::map<hipStream_t, Workspace> workspaces;
     std::mutex staging_mu;
-    DeviceState() = default;
-    DeviceState(const DeviceState&) {}
-    DeviceState& operator=(const DeviceState&) { return *this; }
 };
 
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
-std::vector<DeviceState> g_dev(1);   // resized only while no device is initialised
+std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
 std::mutex g_mu;
 
 // ---- exact host arithmetic for the tables ----
@@ -416,7 +413,8 @@ int cufhe_amd_set_gpu_num(int gpu_num)
     int have = cufhe_amd_device_count();
     if (gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
     g_gpu_num = gpu_num;
-    g_dev = std::vector<DeviceState>(gpu_num);
+    g_dev.clear();
+    g_dev.resize(gpu_num);
     return 0;
 }
 int cufhe_amd_get_gpu_num(void) { return g_gpu_num; }
