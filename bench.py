@@ -129,7 +129,10 @@ def main():
 
     import cufhe_amd as eng                  # fails loudly if the HIP library is missing
     eng.api.set_option("device_base", DEV)   # logical device 0 of this process = this rank's GPU
-    import oracle_lib as ol                   # sizes only, until the cpu_baseline leg
+
+    class ol:                                 # sizes come from the library, not from the oracle
+        n, N = int(eng.PARAMS.n), int(eng.PARAMS.N)
+        BK_WORDS, KSK_WORDS = int(eng.PARAMS.bk_words), int(eng.PARAMS.ksk_words)
 
     count = args.gates
     rng = np.random.default_rng(42 + RANK)
@@ -231,7 +234,8 @@ def main():
         }
         if not args.no_cpu_baseline and WORLD == 1 and args.workload == "nand":
             gpu_out = dout.download().reshape(count, ol.n + 1)
-            res["cpu_baseline"] = cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out)
+            import oracle_lib                 # the only leg that touches the CPU oracle
+            res["cpu_baseline"] = cpu_baseline(eng, oracle_lib, bk, ksk, in0, in1, gpu_out)
         print(json.dumps(res), flush=True)
 
     st.Destroy()
