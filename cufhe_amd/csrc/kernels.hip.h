@@ -243,11 +243,11 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
     rotate_sub(temp, accj, tile, lane, abar);
 #pragma unroll 1
     for (int d = 0; d < kL; d++) {
-        const int lsh = d * kBgbit;                 // bring digit d to the top, then arithmetic shift
+        const uint32_t pos = 32 - (d + 1) * kBgbit;  // v_bfe_i32: the sign-extended Bgbit-wide field at pos
         double x[kRegs];
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
-            x[r] = (double)((int32_t)(temp[r] << lsh) >> (32 - kBgbit));
+            x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
         ntt_forward_a<true>(x, ctx);
         if (pipe.late) pipe.sync(first_row + d);
         ntt_forward_bc<false>(x, ctx);
@@ -431,13 +431,13 @@ __global__ __launch_bounds__(kWgThreads, 2) void blind_rotate_wg_kernel(
             uint32_t rot[kRegs], cur[kRegs];
 #pragma unroll
             for (int r = 0; r < kRegs; r++) { rot[r] = *(const uint32_t*)(rbase + 256 * r); cur[r] = *(const uint32_t*)(cbase + 256 * r); }
-            const int lsh = wd * kBgbit;
+            const uint32_t pos = 32 - (wd + 1) * kBgbit;
             double x[kRegs];
 #pragma unroll
             for (int r = 0; r < kRegs; r++) {
                 const bool neg = (lane < alo - 64 * r) != ahi;
                 const uint32_t t = ((neg ? 0u - rot[r] : rot[r]) - cur[r] + decomp_offset()) ^ decomp_signmask();
-                x[r] = (double)((int32_t)(t << lsh) >> (32 - kBgbit));
+                x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, pos, (uint32_t)kBgbit);
             }
             ntt_forward<true>(x, ctx);
             double* s0 = sumL + lane;
@@ -731,10 +731,10 @@ __global__ __launch_bounds__(kNttThreads) void cmux_kernel(
         }
 #pragma unroll 1
         for (int d = 0; d < kL; d++) {
-            const int lsh = d * kBgbit;
+            const uint32_t pos = 32 - (d + 1) * kBgbit;
             double x[kRegs];
 #pragma unroll
-            for (int r = 0; r < kRegs; r++) x[r] = (double)((int32_t)(temp[r] << lsh) >> (32 - kBgbit));
+            for (int r = 0; r < kRegs; r++) x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
             ntt_forward<true>(x, ctx);
             const double2* row = key + (size_t)(j * kL + d) * kN;
 #pragma unroll
