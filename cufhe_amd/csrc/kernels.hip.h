@@ -125,27 +125,29 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
 // ----------------------------------------------------------------------------------
 // Blind rotate + sample extract, one wave per rotation.
 // ----------------------------------------------------------------------------------
-// acc_j -> digits of ((X^abar - 1) acc_j), include/gatebootstrapping_gpu.cuh:157-181.
-// The rotation goes through the wave's LDS tile: the polynomial is written twice
-// (e and e + N) so the rotated read is base + 256*r with no wrap-around arithmetic.
+// acc_j -> (X^abar - 1) acc_j + gadget offset, include/gatebootstrapping_gpu.cuh:157-181.
+// The rotation goes through the wave's LDS tile, and so does its sign: the tile receives
+// B[0..N) = -s acc, B[N..2N) = +s acc with s = -1 if abar >= N else +1.  Coefficient e of
+// X^abar acc is then simply B[e - (abar mod N) + N]: no wrap-around arithmetic, no compare,
+// no per-element negation (the reference selects the sign per element, :165-168).
 __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32_t (&acc)[kRegs],
                                            char* tile, int lane, uint32_t abar)
 {
-    char* wbase = tile + opaque(4 * lane);
-#pragma unroll
-    for (int r = 0; r < kRegs; r++) {
-        *(uint32_t*)(wbase + 256 * r) = acc[r];
-        *(uint32_t*)(wbase + 256 * r + 4096) = acc[r];
-    }
     const int alo = (int)(abar & (kN - 1));
     const bool ahi = (abar >> kNbit) != 0;
-    const char* rbase = tile + opaque(4 * ((lane - alo) & (kN - 1)));
+    char* wpos = tile + opaque(4 * lane + (ahi ? 0 : 4 * kN));      // where +acc goes
+    char* wneg = tile + opaque(4 * lane + (ahi ? 4 * kN : 0));      // where -acc goes
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {
-        const uint32_t v = *(const uint32_t*)(rbase + 256 * r);
-        const bool neg = (lane < alo - 64 * r) != ahi;      // (e < abar mod N) xor (abar >= N)
-        temp[r] = ((neg ? 0u - v : v) - acc[r] + decomp_offset()) ^ decomp_signmask();
+        *(uint32_t*)(wpos + 256 * r) = acc[r];
+        *(uint32_t*)(wneg + 256 * r) = 0u - acc[r];
     }
+    const char* rbase = tile + opaque(4 * (lane - alo + kN));
+    uint32_t rot[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);   // all reads in flight together
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) temp[r] = (rot[r] - acc[r] + decomp_offset()) ^ decomp_signmask();
 }
 
 // x (spectrum of one digit polynomial, layout C) times the two polynomials of one TRGSW row,
