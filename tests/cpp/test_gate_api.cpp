@@ -152,6 +152,45 @@ void DeviceResident(std::mt19937& eng)
     st.Destroy();
 }
 
+// A real circuit through the per-gate API: 16 independent 8-bit ripple-carry adders, one per
+// stream, every gate depending on earlier ones (the scheduler must cut the recorded gates into
+// dependence levels and still batch across the 16 adders).
+void RippleAdders(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl0param;
+    const int kAdders = 16, kBits = 8;
+    std::vector<Ctxt<P>> a(kAdders * kBits), b(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);
+    std::vector<unsigned> va(kAdders), vb(kAdders);
+    Stream* st = new Stream[kAdders];
+    for (int i = 0; i < kAdders; i++) st[i].Create();
+    for (int i = 0; i < kAdders; i++) {
+        va[i] = eng() & 0xff; vb[i] = eng() & 0xff;
+        for (int k = 0; k < kBits; k++) { encrypt(a[i * kBits + k], (va[i] >> k) & 1); encrypt(b[i * kBits + k], (vb[i] >> k) & 1); }
+        encrypt(carry[i], 0);
+    }
+    for (int k = 0; k < kBits; k++)
+        for (int i = 0; i < kAdders; i++) {
+            Ctxt<P>&x = a[i * kBits + k], &y = b[i * kBits + k], &s = sum[i * kBits + k], &c = carry[i];
+            Xor(t1[i], x, y, st[i]);          // t1 = x ^ y
+            Xor(s, t1[i], c, st[i]);          // s  = t1 ^ c
+            And(t2[i], t1[i], c, st[i]);      // t2 = t1 & c
+            And(t1[i], x, y, st[i]);          // t1 = x & y       (overwrites t1 after its readers)
+            Or(c, t1[i], t2[i], st[i]);       // c  = t1 | t2     (in place on the carry)
+        }
+    Synchronize();
+    int bad = 0;
+    for (int i = 0; i < kAdders; i++) {
+        unsigned got = 0;
+        for (int k = 0; k < kBits; k++) got |= (unsigned)decrypt(sum[i * kBits + k]) << k;
+        got |= (unsigned)decrypt(carry[i]) << kBits;
+        bad += got != va[i] + vb[i];
+    }
+    std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums)\n", bad ? "FAIL" : "PASS", bad, kAdders);
+    g_failures += bad;
+    for (int i = 0; i < kAdders; i++) st[i].Destroy();
+    delete[] st;
+}
+
 // test/test_perf.cc:36-87 (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt coefficient 0)
 // and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch.
 void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
@@ -213,6 +252,7 @@ int main(int argc, char** argv)
     Intensive(eng);
     DeviceResident(eng);
     TrlwePrimitives(eng, bk);
+    RippleAdders(eng);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
     return g_failures ? 1 : 0;
