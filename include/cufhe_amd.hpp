@@ -35,11 +35,13 @@ struct lvl0param {
     using T = uint32_t;
     static constexpr uint32_t n = 630, k = 1;
     static constexpr T mu = 1u << 29;
+    static constexpr T μ = mu;             // TFHEpp's spelling
 };
 struct lvl1param {
     using T = uint32_t;
     static constexpr uint32_t nbit = 10, n = 1u << nbit, k = 1, l = 3, Bgbit = 6, Bg = 1u << Bgbit;
     static constexpr T mu = 1u << 29;
+    static constexpr T μ = mu;
 };
 struct lvl01param { using domainP = lvl0param; using targetP = lvl1param; };
 struct lvl10param {
