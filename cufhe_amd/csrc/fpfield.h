@@ -81,5 +81,15 @@ FPF_HD uint32_t low32(double a)
 }
 // torus word of a lazy residue whose true value c satisfies |c| < p/2
 FPF_HD uint32_t lift_u32(double a) { return low32(reduce(a)); }
+// Same for |a| < 2^51 (2.57 p) with one FP64 operation less: a = c + q p with a small
+// integer q, so c mod 2^32 = low32(a) - q * (p mod 2^32).  q is read from the low mantissa
+// bits of the rounding sum (two's complement), low32(a) from those of a + MAGIC0.
+FPF_HD uint32_t lift_u32_small(double a)
+{
+    const double t = __builtin_fma(a, PINV, MAGIC0);     // mantissa = 2^51 + q
+    uint64_t tb;
+    __builtin_memcpy(&tb, &t, 8);
+    return low32(a) - (uint32_t)tb * (uint32_t)P_U64;
+}
 
 }  // namespace fpf

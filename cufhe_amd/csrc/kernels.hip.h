@@ -264,7 +264,7 @@ __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&a
     for (int r = 0; r < kRegs; r++) A[r] = fpf::reduce(A[r]);
     ntt_inverse(A, ctx);
 #pragma unroll
-    for (int r = 0; r < kRegs; r++) accj[r] += fpf::lift_u32(A[r]);   // centred lift, :258-281
+    for (int r = 0; r < kRegs; r++) accj[r] += fpf::lift_u32_small(A[r]);   // centred lift, :258-281 (|A| <= 2 p here)
 }
 
 // descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at

@@ -143,10 +143,9 @@ struct TwLane {                      // stages 4-7: tb[k][lambda] from LDS
 // multiplication by a root so small that the product is exact: no reduction
 __device__ __forceinline__ void ct_bfly_exact(double& a, double& b, double w)
 {
-    const double t = b * w;
-    const double u = a;
-    a = u + t;
-    b = u - t;
+    const double u = a, v = b;
+    a = __builtin_fma(v, w, u);       // exact: an integer below 2^53
+    b = __builtin_fma(-v, w, u);
 }
 
 // SMALL_IN: |x| <= 32 on entry and the twiddles are those of stages 0-3 (tw(0) = I,

@@ -150,6 +150,7 @@ int hm_check_reduce_lift(const double* a, int count)
         int64_t c = (int64_t)r;
         if (fpf::low32(r) != (uint32_t)(uint64_t)c) bad++;
         if (fpf::lift_u32(a[i]) != (uint32_t)(uint64_t)c) bad++;
+        if (std::fabs(a[i]) < 2251799813685248.0 && fpf::lift_u32_small(a[i]) != (uint32_t)(uint64_t)c) bad++;
     }
     return bad;
 }
