@@ -24,7 +24,8 @@ _u64 = np.ctypeslib.ndpointer(np.uint64, flags="C")
 
 
 def build():
-    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ORACLE_DIR, "tfhe_oracle.c")):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tfhe_oracle.c", "tfhe_oracle.h", "tfhe_oracle_lvl2.c", "tfhe_oracle_lvl2.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     if not os.path.exists(REF_LIB) and os.path.exists("/root/reference/test/plain.h"):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
@@ -60,6 +61,22 @@ def load():
     L.orc_refresh.argtypes = [ctypes.c_void_p, _u32, _u32]
     L.orc_truth.argtypes = [ctypes.c_int] * 4
     L.orc_gate_coeffs.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
+    # N = 2048 / 64-bit torus (oracle/tfhe_oracle_lvl2.h)
+    L.orc2_keygen.argtypes = [ctypes.c_uint64, _u32]
+    L.orc2_bkgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u64]
+    L.orc2_kskgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u32]
+    L.orc2_polymul_schoolbook.argtypes = [_u64, _i32, _u64]
+    L.orc2_polymul_ntt.argtypes = [_u64, _i32, _u64]
+    L.orc2_tlwe_phase.restype = ctypes.c_uint64
+    L.orc2_tlwe_phase.argtypes = [_u32, _u64]
+    L.orc2_evalkey_create.restype = ctypes.c_void_p
+    L.orc2_evalkey_create.argtypes = [_u64, _u32]
+    L.orc2_evalkey_destroy.argtypes = [ctypes.c_void_p]
+    L.orc2_blind_rotate.argtypes = [ctypes.c_void_p, _u64, _u32, ctypes.c_int]
+    L.orc2_sample_extract0.argtypes = [_u64, _u64]
+    L.orc2_keyswitch.argtypes = [ctypes.c_void_p, _u32, _u64]
+    L.orc2_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_size_t,
+                                  _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     return L
 
 
@@ -111,6 +128,64 @@ class Keys:
             threads = self.L.orc_max_threads()
         self.L.orc_gate_batch(self.ek, ops_arr, stride, level, count, out, in0.ravel(), p1, p2, threads)
         return out.reshape(count, LVL_WORDS[level])
+
+
+N2 = 2048
+LVL2_WORDS = N2 + 1
+BK2_WORDS = n * 8 * 2 * N2          # uint64
+KSK2_WORDS = N2 * 7 * 2 * (n + 1)   # uint32
+MU2 = 1 << 61
+
+
+class KeysLvl2:
+    """lvl02 bootstrapping key and lvl20 key-switching key over the SAME lvl0 key as `base`."""
+
+    def __init__(self, L, base, seed=1):
+        self.L, self.base = L, base
+        self.s0 = base.s0
+        self.s2 = np.zeros(N2, np.uint32)
+        L.orc2_keygen(seed, self.s2)
+        self.bk = np.zeros(BK2_WORDS, np.uint64)
+        self.ksk = np.zeros(KSK2_WORDS, np.uint32)
+        L.orc2_bkgen(seed + 3000, self.s0, self.s2, self.bk)
+        L.orc2_kskgen(seed + 4000, self.s0, self.s2, self.ksk)
+        self.ek = L.orc2_evalkey_create(self.bk, self.ksk)
+
+    def blind_rotate(self, tlwe0, steps=-1):
+        acc = np.zeros(2 * N2, np.uint64)
+        self.L.orc2_blind_rotate(self.ek, acc, np.ascontiguousarray(tlwe0, np.uint32), steps)
+        return acc
+
+    def sample_extract(self, acc):
+        out = np.zeros(LVL2_WORDS, np.uint64)
+        self.L.orc2_sample_extract0(out, np.ascontiguousarray(acc, np.uint64))
+        return out
+
+    def keyswitch(self, tlwe2):
+        out = np.zeros(n + 1, np.uint32)
+        self.L.orc2_keyswitch(self.ek, out, np.ascontiguousarray(tlwe2, np.uint64))
+        return out
+
+    def phase2(self, tlwe2):
+        return self.L.orc2_tlwe_phase(self.s2, np.ascontiguousarray(tlwe2, np.uint64))
+
+    def gate_batch(self, ops, in0, in1=None, in2=None, threads=None):
+        in0 = np.ascontiguousarray(in0, dtype=np.uint32)
+        count = in0.reshape(-1, n + 1).shape[0]
+        if np.isscalar(ops):
+            ops_arr, stride = np.array([ops], np.int32), 0
+        else:
+            ops_arr, stride = np.ascontiguousarray(ops, np.int32), 1
+        out = np.zeros(count * (n + 1), np.uint32)
+        p1 = p2 = None
+        if in1 is not None:
+            in1 = np.ascontiguousarray(in1, np.uint32); p1 = in1.ctypes.data
+        if in2 is not None:
+            in2 = np.ascontiguousarray(in2, np.uint32); p2 = in2.ctypes.data
+        if threads is None:
+            threads = self.L.orc_max_threads()
+        self.L.orc2_gate_batch(self.ek, ops_arr, stride, count, out, in0.ravel(), p1, p2, threads)
+        return out.reshape(count, n + 1)
 
 
 def truth(L, op, a, b=0, c=0):
