@@ -27,6 +27,12 @@ class Params(ctypes.Structure):
                [(n, ctypes.c_uint64) for n in ("bk_words", "ksk_words", "bk_ntt_bytes")]
 
 
+class Lvl2Params(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in ("n", "N", "nbit", "k", "l", "Bgbit", "t", "basebit",
+                                               "lvl0_words", "lvl2_words")] + \
+               [(k, ctypes.c_uint64) for k in ("mu", "bk_words", "ksk_words", "bk_ntt_bytes")]
+
+
 class Profile(ctypes.Structure):
     _fields_ = [("blind_rotate_ms", ctypes.c_double), ("blind_rotate_launches", ctypes.c_uint64),
                 ("blind_rotations", ctypes.c_uint64), ("keyswitch_ms", ctypes.c_double),
@@ -76,6 +82,12 @@ SIGNATURES = {
     "cufhe_amd_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),
     "cufhe_amd_profile_enable": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cufhe_amd_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(Profile), ctypes.c_int]),
+    "cufhe_amd_lvl2_get_params": (ctypes.c_int, [ctypes.POINTER(Lvl2Params)]),
+    "cufhe_amd_lvl2_initialize": (ctypes.c_int, [c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
+    "cufhe_amd_lvl2_gate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_int,
+                                                 c_void, c_void, c_void, c_void, ctypes.c_size_t]),
+    "cufhe_amd_lvl2_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
+    "cufhe_amd_lvl2_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

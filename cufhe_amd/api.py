@@ -10,7 +10,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import lib, check, Params, Profile
+from ._lib import lib, check, Params, Profile, Lvl2Params
 
 # op codes (include/cufhe_amd.h)
 NAND, NOR, XNOR, AND, OR, XOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NMUX, NOT, COPY = range(14)
@@ -251,6 +251,42 @@ def cmux_batch(trgsw_ntt, c1, c0, res, count, device=0, stream=None):
 
 def polymul_batch(a, b, res, count, device=0, stream=None):
     check(lib.cufhe_amd_polymul_batch(device, stream, count, a.ptr, b.ptr, res.ptr))
+
+
+# ---- N = 2048 ring / 64-bit torus (configs[4]); gates on lvl0 ciphertexts ----
+def lvl2_params():
+    p = Lvl2Params()
+    check(lib.cufhe_amd_lvl2_get_params(ctypes.byref(p)))
+    return p
+
+
+def lvl2_initialize(bk, ksk):
+    """bk: the lvl02 bootstrapping key as uint64 torus words, ksk: the lvl20 key-switching key (uint32)."""
+    bk = np.ascontiguousarray(bk, dtype=np.uint64).ravel()
+    ksk = np.ascontiguousarray(ksk, dtype=np.uint32).ravel()
+    check(lib.cufhe_amd_lvl2_initialize(_ptr(bk), bk.size, _ptr(ksk), ksk.size))
+
+
+def lvl2_gate_batch(ops, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
+    words = LVL_WORDS[0]
+    if count is None:
+        count = out.words // words
+    if np.isscalar(ops):
+        ops_arr, stride = np.array([ops], dtype=np.int32), 0
+    else:
+        ops_arr, stride = np.ascontiguousarray(ops, dtype=np.int32), 1
+        assert ops_arr.size >= count
+    check(lib.cufhe_amd_lvl2_gate_batch(device, stream, count, _ptr(ops_arr), stride, out.ptr, in0.ptr,
+                                        in1.ptr if in1 is not None else None,
+                                        in2.ptr if in2 is not None else None, words))
+
+
+def lvl2_blind_rotate_batch(tlwe0, acc, count, steps=-1, device=0, stream=None):
+    check(lib.cufhe_amd_lvl2_blind_rotate_batch(device, stream, count, tlwe0.ptr, acc.ptr, steps))
+
+
+def lvl2_keyswitch_batch(tlwe2, tlwe0, count, device=0, stream=None):
+    check(lib.cufhe_amd_lvl2_keyswitch_batch(device, stream, count, tlwe2.ptr, tlwe0.ptr))
 
 
 def set_option(key, value):

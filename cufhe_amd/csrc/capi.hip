@@ -14,6 +14,7 @@
 
 #include "../../include/cufhe_amd.h"
 #include "kernels.hip.h"
+#include "kernels_lvl2.hip.h"
 
 using namespace cufhe_amd;
 
@@ -52,6 +53,11 @@ struct DeviceState {
     uint32_t* ksk = nullptr;
     bool profiling = false;
     bool br_lds_opt_in = false, ks_lds_opt_in = false;
+    // N = 2048 / 64-bit torus (lvl2.inc.h)
+    bool keys2_ready = false, br2_lds_opt_in = false;
+    NttTables* tables2 = nullptr;      // [2]: the two half transforms
+    double* bk2_ntt = nullptr;
+    uint32_t* ksk2 = nullptr;
     std::vector<EventPair> br_events, ks_events;
     cufhe_amd_profile prof{};
     std::deque<PinnedBlock> staging;
@@ -80,23 +86,18 @@ uint64_t powmod_u64(uint64_t a, uint64_t e)
     return r;
 }
 double balanced(uint64_t v) { return v > fpf::P_U64 / 2 ? -(double)(fpf::P_U64 - v) : (double)v; }
-uint32_t bitrev10(uint32_t x)
+uint32_t bitrev(uint32_t x, int bits)
 {
     uint32_t r = 0;
-    for (int i = 0; i < 10; i++) r |= ((x >> i) & 1u) << (9 - i);
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
     return r;
 }
 double n_inverse_balanced() { return balanced(powmod_u64(kN, fpf::P_U64 - 2)); }
 
-// root[i] = psi^bitrev(i): the reference's table order, src/ntt_gpu/ntt_gpuntt.cu:88-111
-void build_tables(NttTables& t)
+// Device tables of one 1024-point transform from its root arrays, fwd[m + g] / inv[m + g]
+// being the twiddle of group g at the stage with m groups.
+void fill_tables(NttTables& t, const std::vector<double>& fwd, const std::vector<double>& inv)
 {
-    std::vector<double> fwd(kN), inv(kN);
-    const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
-    for (uint32_t i = 0; i < (uint32_t)kN; i++) {
-        fwd[i] = balanced(powmod_u64(psi, bitrev10(i)));
-        inv[i] = balanced(powmod_u64(psi_inv, bitrev10(i)));
-    }
     memset(&t, 0, sizeof(t));
     for (int k = 0; k < 15; k++) {
         int lvl = 0;
@@ -117,6 +118,18 @@ void build_tables(NttTables& t)
             t.tc_fwd[k * 64 + lane] = fwd[idx];
             t.tc_inv[k * 64 + lane] = inv[idx];
         }
+}
+
+// root[i] = psi^bitrev(i): the reference's table order, src/ntt_gpu/ntt_gpuntt.cu:88-111
+void build_tables(NttTables& t)
+{
+    std::vector<double> fwd(kN), inv(kN);
+    const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
+    for (uint32_t i = 0; i < (uint32_t)kN; i++) {
+        fwd[i] = balanced(powmod_u64(psi, bitrev(i, 10)));
+        inv[i] = balanced(powmod_u64(psi_inv, bitrev(i, 10)));
+    }
+    fill_tables(t, fwd, inv);
 }
 
 int check_device(int device)
@@ -194,11 +207,12 @@ int acquire_staging(DeviceState& s, size_t bytes, PinnedBlock** out)
     return 0;
 }
 
-int upload_descs(DeviceState& s, Scratch& sc, const std::vector<LinDesc>& h, LinDesc** d)
+template <class Desc>
+int upload_descs(DeviceState& s, Scratch& sc, const std::vector<Desc>& h, Desc** d)
 {
     *d = nullptr;
     if (h.empty()) return 0;
-    const size_t bytes = h.size() * sizeof(LinDesc);
+    const size_t bytes = h.size() * sizeof(Desc);
     if (int rc = sc.alloc((void**)d, bytes)) return rc;
     PinnedBlock* blk = nullptr;
     if (int rc = acquire_staging(s, bytes, &blk)) return rc;
@@ -380,6 +394,7 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 }  // namespace
 
 #include "sched.inc.h"
+#include "lvl2.inc.h"
 
 extern "C" {
 
@@ -409,7 +424,7 @@ int cufhe_amd_set_gpu_num(int gpu_num)
     std::lock_guard<std::mutex> lk(g_mu);
     if (gpu_num < 1) return fail(-1, "gpu_num must be >= 1");
     for (auto& d : g_dev)
-        if (d.ntt_ready || d.keys_ready) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
+        if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
     int have = cufhe_amd_device_count();
     if (gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
     g_gpu_num = gpu_num;
@@ -476,7 +491,7 @@ int cufhe_amd_cleanup(void)
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < g_gpu_num; i++) {
         DeviceState& s = g_dev[i];
-        if (!s.ntt_ready && !s.keys_ready) continue;
+        if (!s.ntt_ready && !s.keys_ready && !s.tables2) continue;
         HIP_TRY(hipSetDevice(i + g_device_base));
         HIP_TRY(hipDeviceSynchronize());
         for (auto* v : {&s.br_events, &s.ks_events}) {
@@ -484,6 +499,10 @@ int cufhe_amd_cleanup(void)
             v->clear();
         }
         if (s.keys_ready) { HIP_TRY(hipFree(s.bk_ntt)); HIP_TRY(hipFree(s.ksk)); }
+        if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.ksk2)); }
+        if (s.tables2) HIP_TRY(hipFree(s.tables2));
+        s.keys2_ready = s.br2_lds_opt_in = false;
+        s.tables2 = nullptr; s.bk2_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) HIP_TRY(hipFree(s.tables));
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
         s.staging.clear();
@@ -752,7 +771,7 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!key) return fail(-1, "null key");
     if (!strcmp(key, "device_base")) {
         for (auto& d : g_dev)
-            if (d.ntt_ready || d.keys_ready) return fail(-1, "device_base must be set before Initialize");
+            if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "device_base must be set before Initialize");
         if (value < 0 || value + g_gpu_num > cufhe_amd_device_count()) return fail(-1, "device_base out of range");
         g_device_base = (int)value;
         return 0;

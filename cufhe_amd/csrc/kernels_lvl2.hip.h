@@ -1,0 +1,393 @@
+// kernels_lvl2.hip.h -- the gate path over the N = 2048 ring with a 64-bit torus
+// (BASELINE.json configs[4]; parameter set lvl2 / lvl02 / lvl20 of SURVEY.md appendix C).
+//
+// The reference has no N = 2048 code and no 64-bit accumulate: what is
+// built here is what its gate templates compute when instantiated at brP = lvl02,
+// iksP = lvl20 (include/gatebootstrapping_gpu.cuh:10-52,115-345, src/bootstrap_gpu.cu:366-421,
+// include/keyswitch_gpu.cuh:83-134), with 64-bit decomposition constants.
+//
+// Exactness.  The external product is an exact integer sum mod 2^64.  A key word w (signed
+// 64 bit) is split into three balanced limbs w = w0 + 2^22 w1 + 2^44 w2, |w0|,|w1| <= 2^21,
+// |w2| <= 2^19, and the product is taken limb by limb over the FP64 prime of fpfield.h:
+// |sum| <= (k+1) l N (Bg/2) 2^21 = 8 * 2048 * 256 * 2^21 = 2^43 < p/2.  The three exact sums
+// are recombined with shifts mod 2^64.  The gadget digits are transformed once and shared
+// by the three limbs.
+//
+// Transform.  X^2048 + 1 = (X^1024 - I)(X^1024 + I) with I = psi^1024 the 25-bit fourth
+// root: the first forward stage (a, b) -> (a + I b, a - I b) is exact in FP64 for gadget
+// digits and for key limbs, and leaves two independent 1024-point transforms that differ
+// from the lvl1 transform of ntt_wave.h only in their twiddle tables (root_h[m + g] =
+// root[2m + h m + g]).  One wave therefore runs a half with the lvl1 code and 16 registers
+// per lane; the two halves of a row are processed one after the other.
+//
+// Work split.  One 8-wave workgroup per blind rotation.  Wave w owns TRGSW row w = (j, d):
+// it decomposes digit d of (X^abar - 1) acc_j, transforms it, multiplies by its 6 key
+// polynomials (2 outputs x 3 limbs) and adds the products into six LDS sums with ds_add_f64;
+// waves 0-5 then each inverse-transform one sum and add their limb of the result into the
+// 64-bit accumulator in LDS with ds_add_u64.  Four workgroup barriers per CMux step.
+// LDS: 8 transpose tiles (66 KiB), accumulator 2 x 2048 x u64 (32 KiB), sums 6 x 1024 x f64
+// (48 KiB), abar list.  The twiddle tables of the two halves do not fit beside that and are
+// read from global memory (L1/L2 resident, fetched ahead of the transposes as in lvl1).
+#pragma once
+#include "kernels.hip.h"
+
+namespace cufhe_amd {
+
+constexpr int k2Nbit = 11;
+constexpr int k2N = 2048;              // lvl2param::n
+constexpr int k2L = 4;                 // lvl2param::l
+constexpr int k2Bgbit = 9;             // lvl2param::Bgbit
+constexpr int k2KsT = 7;               // lvl20param::t
+constexpr int k2KsBasebit = 2;         // lvl20param::basebit
+constexpr uint64_t k2Mu = 1ull << 61;  // lvl2param::mu
+constexpr int k2Words = k2N + 1;       // words of a lvl2 TLWE
+constexpr int k2BkRows = 2 * k2L;      // 8
+constexpr int k2Limbs = 3;
+constexpr int k2LimbBits = 22;
+constexpr int k2Prods = 2 * k2Limbs;   // key polynomials per row: (out, limb)
+constexpr int k2Half = k2N / 2;        // 1024 = kN: a half transform is a lvl1-sized transform
+static_assert(k2Half == kN, "the half transforms reuse ntt_wave.h");
+// NTT-domain key: [step][half][row][out * 3 + limb][1024] doubles, each polynomial in the
+// layout-C order of bk_to_ntt_kernel
+constexpr size_t k2BkStepDoubles = (size_t)2 * k2BkRows * k2Prods * k2Half;   // 98304 = 768 KiB
+constexpr int k2KsNumBase = 1 << (k2KsBasebit - 1);
+
+struct RotDesc2 {          // lvl0 operands, lvl2 result (sample-extracted TLWE)
+    const uint32_t* in0;
+    const uint32_t* in1;
+    uint64_t* out;
+    int32_t ca, cb;
+    uint32_t off;
+    uint32_t pad;
+};
+struct LinDesc64 {         // out(lvl0) = KS(ca * in0 + cb * in1 + (0, .., off)) on lvl2 TLWEs
+    const uint64_t* in0;
+    const uint64_t* in1;
+    uint32_t* out;
+    int32_t ca, cb;
+    uint64_t off;
+};
+
+__host__ __device__ constexpr uint64_t decomp_offset2()
+{
+    uint64_t o = 0;
+    for (int i = 1; i <= k2L; i++) o += (1ull << (k2Bgbit - 1)) << (64 - i * k2Bgbit);
+    return o + (1ull << (64 - k2L * k2Bgbit - 1));     // + roundoffset
+}
+__host__ __device__ constexpr uint64_t decomp_signmask2()
+{
+    uint64_t m = 0;
+    for (int i = 1; i <= k2L; i++) m |= (1ull << (k2Bgbit - 1)) << (64 - i * k2Bgbit);
+    return m;
+}
+
+// wave context whose per-lane twiddle tables live in global memory (tables of half `h`)
+__device__ __forceinline__ WaveCtx make_wave_ctx_gtab(char* lds, int tile_off, const NttTables* gt, int lane)
+{
+    const int lam = lane & 15, hi = lane >> 4;
+    WaveCtx c;
+    c.a65 = lds + opaque(tile_off + 8 * lane);
+    c.a66 = c.a65;
+    c.b65 = lds + opaque(tile_off + 8 * (65 * lam + hi));
+    c.b66 = lds + opaque(tile_off + 8 * (66 * lam + hi));
+    c.tb_fwd = (const char*)gt->tb_fwd + 8 * lam;
+    c.tb_inv = (const char*)gt->tb_inv + 8 * lam;
+    c.tc_fwd = (const char*)gt->tc_fwd + 8 * lane;
+    c.tc_inv = (const char*)gt->tc_inv + 8 * lane;
+    c.gt = gt;
+    return c;
+}
+
+// integer value (mod 2^64) of an integer-valued double |c| < 2^51
+__device__ __forceinline__ uint64_t to_u64(double c)
+{
+    const double t = c + fpf::MAGIC0;                  // mantissa = 2^51 + c
+    uint64_t bits;
+    __builtin_memcpy(&bits, &t, 8);
+    return (bits & ((1ull << 52) - 1)) - (1ull << 51);
+}
+
+// ----------------------------------------------------------------------------------
+// BK (torus, uint64) -> NTT domain.  One wave per (polynomial, limb).
+// bk: [step][row][out][2048]; bk_ntt as described above, scaled by 2048^-1.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kNttThreads) void bk2_to_ntt_kernel(
+    double* __restrict__ bk_ntt, const uint64_t* __restrict__ bk, size_t polys,
+    const NttTables* __restrict__ gt2, double n_inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t w = (size_t)blockIdx.x * kNttWavesPerBlock + wave;
+    if (w >= polys * k2Limbs) return;
+    const size_t poly = w / k2Limbs;
+    const int limb = (int)(w % k2Limbs);
+    const size_t step = poly / (2 * k2BkRows);
+    const int row = (int)((poly / 2) % k2BkRows), out = (int)(poly % 2);
+    const uint64_t* src = bk + poly * k2N;
+    double x0[kRegs], x1[kRegs];
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) {
+        double v[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            int64_t s = (int64_t)src[hh * k2Half + lane + 64 * r];
+            int64_t l = (s << (64 - k2LimbBits)) >> (64 - k2LimbBits);
+            for (int m = 0; m < limb; m++) {
+                s = (s - l) >> k2LimbBits;
+                l = (m + 1 == k2Limbs - 1) ? s : (s << (64 - k2LimbBits)) >> (64 - k2LimbBits);
+            }
+            v[hh] = (double)l;
+        }
+        x0[r] = __builtin_fma(v[1], fpf::ROOT4, v[0]);      // exact: |I b| < 2^47
+        x1[r] = __builtin_fma(-v[1], fpf::ROOT4, v[0]);
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const WaveCtx ctx = make_wave_ctx_gtab(smem, wave * kTileBytes, gt2 + h, lane);
+        double x[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) x[r] = h ? x1[r] : x0[r];
+        ntt_forward<false>(x, ctx);
+        double2* dst = (double2*)(bk_ntt + (((step * 2 + h) * k2BkRows + row) * k2Prods + out * k2Limbs + limb) * k2Half);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            double2 v;
+            v.x = fpf::reduce(fpf::mulmod_wide(x[2 * q], n_inverse));
+            v.y = fpf::reduce(fpf::mulmod_wide(x[2 * q + 1], n_inverse));
+            dst[q * 64 + lane] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Blind rotate lvl02 + sample extract, one workgroup per rotation.
+// ----------------------------------------------------------------------------------
+constexpr int k2Threads = 512;
+constexpr int k2LdsTiles = 0;
+constexpr int k2LdsAcc = k2LdsTiles + 8 * kTileBytes;            // 67584
+constexpr int k2LdsSum = k2LdsAcc + 2 * k2N * 8;                 // + 32768
+constexpr int k2LdsAbar = k2LdsSum + k2Prods * k2Half * 8;       // + 49152
+constexpr int k2LdsBytes = k2LdsAbar + kAbarBytes + 16;          // 150800
+
+__device__ __forceinline__ void load_key_poly(double2 (&b)[8], const double* poly, int lane)
+{
+    const double2* p = (const double2*)poly;
+#pragma unroll
+    for (int q = 0; q < 8; q++) b[q] = p[q * 64 + lane];
+}
+// sums[reg][lane] += x * key, x reduced (|x| <= p/2): each product is below 0.55 p, eight
+// rows stay below 4.4 p
+__device__ __forceinline__ void accumulate_poly(double* sums, const double (&x)[kRegs], const double2 (&b)[8], int lane)
+{
+    double* s0 = sums + lane;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        __hip_atomic_fetch_add(s0 + (2 * q) * 64, fpf::mulmod(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(s0 + (2 * q + 1) * 64, fpf::mulmod(x[2 * q + 1], b[q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+__global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
+    const RotDesc2* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const NttTables* __restrict__ gt2, int steps, uint64_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    uint64_t* accL = (uint64_t*)(smem + k2LdsAcc);            // [j][2048]
+    double* sumL = (double*)(smem + k2LdsSum);                // [out * 3 + limb][reg][lane]
+    uint16_t* abar_lds = (uint16_t*)(smem + k2LdsAbar);
+    uint32_t* bbar_slot = (uint32_t*)(smem + k2LdsAbar + kAbarBytes);
+
+    const RotDesc2 d = descs[g];
+    for (int i = tid; i <= kLvl0N; i += k2Threads) {
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - k2Nbit))) >> (32 - 1 - k2Nbit));
+        else *bbar_slot = 2 * k2N - ((c + d.off) >> (32 - 1 - k2Nbit));
+    }
+    for (int i = tid; i < k2Prods * k2Half; i += k2Threads) sumL[i] = 0.0;
+    __syncthreads();
+    {   // RotatedTestVector<lvl2param>, include/gatebootstrapping_gpu.cuh:29-52
+        const uint32_t bbar = *bbar_slot;
+        for (int e = tid; e < k2N; e += k2Threads) {
+            const bool neg = (bbar != 2 * k2N) && (((uint32_t)e < (bbar & (k2N - 1))) != ((bbar >> k2Nbit) != 0));
+            accL[e] = 0;
+            accL[k2N + e] = neg ? 0ull - k2Mu : k2Mu;
+        }
+    }
+    __syncthreads();
+
+    const int wj = wave / k2L, wd = wave % k2L;               // this wave's TRGSW row = wj * l + wd
+    const WaveCtx ctx0 = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
+    const WaveCtx ctx1 = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2 + 1, lane);
+    const bool inv_wave = wave < k2Prods;
+    const int sh = k2Bgbit * wd;
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        const int alo = (int)(abar & (k2N - 1));
+        const bool ahi = (abar >> k2Nbit) != 0;
+        const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+        double2 bA[8], bB[8];
+        load_key_poly(bA, key, lane);                         // in flight during the decomposition + NTT
+
+        // digit wd of (X^abar - 1) acc_wj at e and e + 1024, then the first forward stage
+        double x0[kRegs], x1[kRegs];
+        {
+            const char* accj = (const char*)(accL + wj * k2N);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                const int e0 = lane + 64 * r;
+                const int i0 = (e0 - alo) & (k2N - 1), i1 = i0 ^ k2Half;
+                const uint64_t rot0 = *(const uint64_t*)(accj + 8 * i0), rot1 = *(const uint64_t*)(accj + 8 * i1);
+                const uint64_t cur0 = *(const uint64_t*)(accj + 8 * e0), cur1 = *(const uint64_t*)(accj + 8 * (e0 + k2Half));
+                const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
+                const uint64_t t0 = ((neg0 ? 0ull - rot0 : rot0) - cur0 + decomp_offset2()) ^ decomp_signmask2();
+                const uint64_t t1 = ((neg1 ? 0ull - rot1 : rot1) - cur1 + decomp_offset2()) ^ decomp_signmask2();
+                const double a = (double)(int)((int64_t)(t0 << sh) >> (64 - k2Bgbit));
+                const double b = (double)(int)((int64_t)(t1 << sh) >> (64 - k2Bgbit));
+                x0[r] = __builtin_fma(b, fpf::ROOT4, a);       // exact: |I b| < 2^33
+                x1[r] = __builtin_fma(-b, fpf::ROOT4, a);
+            }
+        }
+        double R0[kRegs];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const WaveCtx& ctx = h ? ctx1 : ctx0;
+            double x[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) x[r] = h ? x1[r] : x0[r];
+            ntt_forward<false>(x, ctx);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
+            const double* kh = key + (size_t)h * (k2BkRows * k2Prods * k2Half);
+#pragma unroll
+            for (int pp = 0; pp < k2Prods; pp += 2) {
+                load_key_poly(bB, kh + (pp + 1) * k2Half, lane);
+                accumulate_poly(sumL + pp * k2Half, x, bA, lane);
+                if (pp + 2 < k2Prods) load_key_poly(bA, kh + (pp + 2) * k2Half, lane);
+                else if (h == 0) load_key_poly(bA, key + (size_t)(k2BkRows * k2Prods * k2Half), lane);   // half 1, first polynomial
+                accumulate_poly(sumL + (pp + 1) * k2Half, x, bB, lane);
+            }
+            __syncthreads();
+            if (inv_wave) {
+                double* s = sumL + wave * k2Half + lane;
+                double A[kRegs];
+#pragma unroll
+                for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
+                ntt_inverse(A, ctx);                           // |A| <= 2 p, natural order
+                if (h == 0) {
+#pragma unroll
+                    for (int r = 0; r < kRegs; r++) R0[r] = A[r];
+                } else {
+                    // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, then each wave
+                    // adds its limb of the exact sum, shifted, into the 64-bit accumulator
+                    const int out = wave / k2Limbs, shl = k2LimbBits * (wave % k2Limbs);
+                    unsigned long long* acck = (unsigned long long*)(accL + out * k2N) + lane;
+#pragma unroll
+                    for (int r = 0; r < kRegs; r++) {
+                        const double lo = fpf::reduce(R0[r] + A[r]);
+                        const double hi = fpf::reduce(fpf::mulmod(R0[r] - A[r], -fpf::ROOT4));
+                        __hip_atomic_fetch_add(acck + 64 * r, to_u64(lo) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(acck + k2Half + 64 * r, to_u64(hi) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    if (acc_dump) {
+        uint64_t* o = acc_dump + (size_t)g * 2 * k2N;
+        for (int e = tid; e < 2 * k2N; e += k2Threads) o[e] = accL[e];
+    }
+    if (d.out) {   // __SampleExtractIndex__<lvl2param,0>, src/bootstrap_gpu.cu:366-381
+        uint64_t* o = d.out;
+        for (int e = tid; e < k2N; e += k2Threads) {
+            if (e == 0) { o[0] = accL[0]; o[k2N] = accL[k2N]; }
+            else o[k2N - e] = 0ull - accL[e];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Key switch lvl2 -> lvl0 (KeySwitchFromTLWE<lvl20>, include/keyswitch_gpu.cuh:83-134) with
+// the linear pre-add of the Mux fused.  One workgroup (16 waves) per ciphertext, wave w takes
+// a'_j for j in [128 w, 128 w + 128); rows are read from L2, the 16 partial sums are added
+// through LDS.  Table layout as lvl1: [j][k][v][640] padded rows.
+// ----------------------------------------------------------------------------------
+constexpr int k2KsStepRows = k2KsT * k2KsNumBase;             // 14 rows per j
+
+__global__ __launch_bounds__(kKsThreads) void keyswitch_lvl2_kernel(
+    const LinDesc64* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
+{
+    __shared__ uint32_t part[kKsWaves][kKsRowPad];
+    __shared__ uint16_t dig[k2N];
+    __shared__ uint32_t bprime_s;
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const LinDesc64 d = descs[g];
+    // iksoffsetgen<lvl20> + roundoffset (:13-23,92-98); only the top t*basebit = 14 bits carry digits
+    uint64_t koff = 1ull << (64 - (1 + k2KsBasebit * k2KsT));
+    for (int i = 1; i <= k2KsT; i++) koff += ((1ull << k2KsBasebit) / 2) << (64 - i * k2KsBasebit);
+    for (int j = tid; j < k2Words; j += kKsThreads) {
+        const uint64_t v = (uint64_t)(int64_t)d.ca * d.in0[j] + (uint64_t)(int64_t)d.cb * d.in1[j];
+        if (j == k2N) bprime_s = (uint32_t)((v + d.off + (1ull << 31)) >> 32);     // rounding narrowing, :100-101
+        else dig[j] = (uint16_t)((v + koff) >> 48);
+    }
+    __syncthreads();
+
+    int piece[kKsPieces];
+    piece[0] = lane; piece[1] = lane + 64; piece[2] = lane < 32 ? lane + 128 : 159;
+    uint4 res[kKsPieces];
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
+    const uint4* base = (const uint4*)ksk_padded;
+    constexpr int kRowPieces = kKsRowPad / 4;
+#pragma unroll 1
+    for (int jj = 0; jj < k2N / kKsWaves; jj++) {
+        const int j = wave * (k2N / kKsWaves) + jj;
+        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+        int val[k2KsT];
+        uint4 row[k2KsT][kKsPieces];
+#pragma unroll
+        for (int k = 0; k < k2KsT; k++) {
+            val[k] = (int)((dj >> (16 - (k + 1) * k2KsBasebit)) & ((1u << k2KsBasebit) - 1)) - (1 << (k2KsBasebit - 1));
+            const int v = val[k] > 0 ? val[k] : -val[k];
+            const uint4* r = base + ((size_t)(j * k2KsT + k) * k2KsNumBase + (v ? v - 1 : 0)) * kRowPieces;
+#pragma unroll
+            for (int m = 0; m < kKsPieces; m++) row[k][m] = r[piece[m]];
+        }
+#pragma unroll
+        for (int k = 0; k < k2KsT; k++) {
+            if (val[k] > 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x -= row[k][m].x; res[m].y -= row[k][m].y; res[m].z -= row[k][m].z; res[m].w -= row[k][m].w; }
+            } else if (val[k] < 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x += row[k][m].x; res[m].y += row[k][m].y; res[m].z += row[k][m].z; res[m].w += row[k][m].w; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) {
+        if (m == 2 && lane >= 32) break;
+        *(uint4*)&part[wave][4 * piece[m]] = res[m];
+    }
+    __syncthreads();
+    for (int i = tid; i <= kLvl0N; i += kKsThreads) {
+        uint32_t v = (i == kLvl0N) ? bprime_s : 0u;
+#pragma unroll
+        for (int w = 0; w < kKsWaves; w++) v += part[w][i];
+        d.out[i] = v;
+    }
+}
+
+}  // namespace cufhe_amd

@@ -149,6 +149,36 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
  * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words. */
 int cufhe_amd_set_option(const char* key, long value);
 
+/* ---- N = 2048 ring, 64-bit torus (BASELINE.json configs[4]; lvl2 / lvl02 / lvl20) ----
+ * The reference has no N = 2048 path (its NTT is `if constexpr (N == 1024) ... else if
+ * (N == 512)`, include/ntt_gpu/ntt_gpuntt.cuh, and its prime has no 4096-th root); these entry
+ * points are what its gate templates compute when instantiated at brP = lvl02, iksP = lvl20:
+ * __HomGate__ br -> iks (src/bootstrap_gpu.cu:402-421), the Mux of :515-588, Accumulate
+ * (include/gatebootstrapping_gpu.cuh:115-285) and KeySwitchFromTLWE (include/keyswitch_gpu.cuh:
+ * 83-134, 64-bit domain, 32-bit target).  Gates take and return lvl0 ciphertexts. */
+typedef struct cufhe_amd_lvl2_params {
+    uint32_t n, N, nbit, k, l, Bgbit, t, basebit;
+    uint32_t lvl0_words, lvl2_words;   /* lvl2 TLWE: N + 1 uint64 words */
+    uint64_t mu;                       /* 2^61 */
+    uint64_t bk_words;                 /* n * (k+1)l * (k+1) * N uint64 words */
+    uint64_t ksk_words;                /* k N * t * 2^(basebit-1) * (n+1) uint32 words */
+    uint64_t bk_ntt_bytes;             /* bytes one blind rotation reads */
+} cufhe_amd_lvl2_params;
+int cufhe_amd_lvl2_get_params(cufhe_amd_lvl2_params* out);
+/* bk: host, [n][(k+1)l][k+1][N] uint64 torus words (TRGSW of the lvl0 key bits under the lvl2
+ * key); ksk: host, [kN][t][2^(basebit-1)][n+1] uint32.  Independent of cufhe_amd_initialize. */
+int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
+/* same contract as cufhe_amd_gate_batch at level 0 */
+int cufhe_amd_lvl2_gate_batch(int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
+                              uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2,
+                              size_t stride_words);
+/* tlwe0[count][n+1] -> acc[count][2N] (uint64) after `steps` CMux steps (< 0: all n) */
+int cufhe_amd_lvl2_blind_rotate_batch(int device, void* stream, size_t count, const uint32_t* tlwe0,
+                                      uint64_t* acc, int steps);
+/* tlwe2[count][N+1] (uint64) -> tlwe0[count][n+1] */
+int cufhe_amd_lvl2_keyswitch_batch(int device, void* stream, size_t count, const uint64_t* tlwe2,
+                                   uint32_t* tlwe0);
+
 /* ---- measurement ----
  * When enabled, every blind-rotate / key-switch launch is bracketed by HIP events on the
  * stream it runs on; get_profile synchronises and returns accumulated kernel time. */

@@ -1,0 +1,112 @@
+"""GPU parity tests of the N = 2048 / 64-bit-torus gate path (BASELINE.json configs[4]).
+
+The reference has no N = 2048 path: parity is against oracle/tfhe_oracle_lvl2.c
+(pinned by tests/test_oracle_lvl2.py) word for word, plus decrypt == truth table at the full
+4096-gate size.  Bit-exact, no tolerance.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def keys2(oracle, keys):
+    return ol.KeysLvl2(oracle, keys, seed=7)
+
+
+@pytest.fixture(scope="module")
+def engine2(engine, keys2):
+    engine.lvl2_initialize(keys2.bk, keys2.ksk)
+    return engine
+
+
+def _upload(eng, arr):
+    arr = np.ascontiguousarray(arr)
+    if arr.dtype == np.uint64:
+        arr = arr.view(np.uint32)
+    arr = np.ascontiguousarray(arr, dtype=np.uint32)
+    return eng.api.DeviceBuffer(arr.size).upload(arr)
+
+
+def test_params(engine2):
+    p = engine2.lvl2_params()
+    assert (p.n, p.N, p.l, p.Bgbit, p.t, p.basebit) == (630, 2048, 4, 9, 7, 2)
+    assert p.mu == ol.MU2 and p.bk_words == ol.BK2_WORDS and p.ksk_words == ol.KSK2_WORDS
+
+
+@pytest.mark.parametrize("steps", [0, 1, 2, 3, 33, 630])
+def test_blind_rotate_accumulator_words(engine2, keys2, steps):
+    count = 4 if steps == 630 else 8
+    rng = np.random.default_rng(200 + steps)
+    tl = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+    tl[0, :4] = 0                                  # abar = 0 steps
+    tl[1, ol.n] = 0                                # bbar = 2N
+    tl[2, ol.n] = 0xFFFFFFFF                       # bbar = 1
+    tl[3, :8] = 0x7FFFFFFF
+    tl[3, ol.n] = 0x80000000                       # bbar = N
+    dt = _upload(engine2, tl)
+    dacc = engine2.api.DeviceBuffer(count * 2 * ol.N2 * 2)
+    engine2.lvl2_blind_rotate_batch(dt, dacc, count, steps)
+    got = dacc.download().view(np.uint64).reshape(count, 2 * ol.N2)
+    for g in range(count):
+        want = keys2.blind_rotate(tl[g], steps)
+        assert np.array_equal(got[g], want), f"accumulator of rotation {g} differs after {steps} steps"
+
+
+def test_keyswitch_words(engine2, keys2):
+    count = 12
+    rng = np.random.default_rng(9)
+    t2 = rng.integers(0, 2**64, size=(count, ol.LVL2_WORDS), dtype=np.uint64)
+    t2[0] = 0
+    t2[1] = np.uint64(2**64 - 1)
+    t2[2, ol.N2] = np.uint64(0x7FFFFFFF80000000)   # rounding of b carries into bit 31
+    d2 = _upload(engine2, t2)
+    d0 = engine2.api.DeviceBuffer(count * (ol.n + 1))
+    engine2.lvl2_keyswitch_batch(d2, d0, count)
+    got = d0.download().reshape(count, ol.n + 1)
+    for g in range(count):
+        assert np.array_equal(got[g], keys2.keyswitch(t2[g])), f"key switch {g} differs"
+
+
+def test_every_gate_words_and_truth(engine2, keys, keys2, oracle):
+    ops = np.arange(len(ol.OPS), dtype=np.int32)
+    count = ops.size
+    rng = np.random.default_rng(21)
+    bits = rng.integers(0, 2, (3, count)).astype(np.uint8)
+    cts = [keys.encrypt(bits[i], 0, seed=300 + i) for i in range(3)]
+    d = [_upload(engine2, c) for c in cts]
+    dout = engine2.api.DeviceBuffer(count * (ol.n + 1))
+    engine2.lvl2_gate_batch(ops, dout, d[0], d[1], d[2])
+    got = dout.download().reshape(count, ol.n + 1)
+    want = keys2.gate_batch(ops, cts[0], cts[1], cts[2])
+    for g in range(count):
+        assert np.array_equal(got[g], want[g]), f"{ol.OPS[g]} differs from the oracle"
+    dec = keys.decrypt(got, 0)
+    for g in range(count):
+        assert dec[g] == ol.truth(oracle, g, bits[0, g], bits[1, g], bits[2, g]), ol.OPS[g]
+
+
+def test_4096_nands_decrypt_and_sampled_words(engine2, keys, keys2):
+    count = 4096
+    rng = np.random.default_rng(33)
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    ca, cb = keys.encrypt(bits[0], 0, seed=401), keys.encrypt(bits[1], 0, seed=402)
+    da, db = _upload(engine2, ca), _upload(engine2, cb)
+    dout = engine2.api.DeviceBuffer(count * (ol.n + 1))
+    engine2.lvl2_gate_batch(ol.OPS.index("NAND"), dout, da, db)
+    got = dout.download().reshape(count, ol.n + 1)
+    assert np.array_equal(keys.decrypt(got, 0), 1 - (bits[0] & bits[1]))
+    pick = rng.choice(count, 8, replace=False)
+    want = keys2.gate_batch(ol.OPS.index("NAND"), ca[pick], cb[pick])
+    assert np.array_equal(got[pick], want)
+
+
+def test_errors(engine2):
+    buf = engine2.api.DeviceBuffer(ol.n + 1)
+    with pytest.raises(engine2.CufheAmdError):
+        engine2.lvl2_gate_batch(99, buf, buf, buf)
+    with pytest.raises(engine2.CufheAmdError):
+        engine2.lvl2_initialize(np.zeros(8, np.uint64), np.zeros(8, np.uint32))
