@@ -104,6 +104,36 @@ def cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
     }
 
 
+def cpu_baseline_lvl2(ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
+    """Same for the N = 2048 workload (oracle/tfhe_oracle_lvl2.c)."""
+    L = ol.load()
+    ek = L.orc2_evalkey_create(bk, ksk)
+    threads = L.orc_max_threads()
+    nand = np.array([0], np.int32)
+    words = ol.n + 1
+
+    def run(count, threads):
+        out = np.zeros(count * words, np.uint32)
+        a = np.ascontiguousarray(in0[:count]).ravel()
+        b = np.ascontiguousarray(in1[:count])
+        t = time.perf_counter()
+        L.orc2_gate_batch(ek, nand, 0, count, out, a, b.ctypes.data, None, threads)
+        return time.perf_counter() - t, out.reshape(count, words)
+
+    threads = min(threads, 32)
+    dt, _ = run(threads, threads)
+    count = int(min(in0.shape[0], max(threads, threads * round(target_seconds / max(dt, 1e-3)))))
+    dt, out = run(count, threads)
+    L.orc2_evalkey_destroy(ek)
+    return {
+        "value": count / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
+        "visible_cores": int(L.orc_max_threads()),
+        "sample": f"{count} of the batch's NAND gates, OpenMP over gates, {dt:.1f} s",
+        "ms_per_gate_per_core": 1e3 * dt * threads / count,
+        "gpu_words_match_oracle": bool(np.array_equal(out, gpu_out[:count])),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,8 +143,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true",
                     help="also time one gate alone on the idle device (adds 1-gate launches to a profile)")
-    ap.add_argument("--workload", choices=["nand", "mux", "mixed"], default="nand",
-                    help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix")
+    ap.add_argument("--workload", choices=["nand", "mux", "mixed", "nand_lvl2"], default="nand",
+                    help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix; "
+                         "nand_lvl2 = configs[4] (N = 2048 ring, 64-bit torus)")
     args = ap.parse_args()
     if args.gpus != WORLD:
         if WORLD == 1 and args.gpus > 1:
@@ -137,19 +168,28 @@ def main():
     count = args.gates
     rng = np.random.default_rng(42 + RANK)
     # synthetic keys and ciphertexts: uniform torus words (the path's work is data-independent)
-    bk = rng.integers(0, 2**32, size=ol.BK_WORDS, dtype=np.uint64).astype(np.uint32)
-    ksk = rng.integers(0, 2**32, size=ol.KSK_WORDS, dtype=np.uint64).astype(np.uint32)
+    lvl2 = args.workload == "nand_lvl2"
+    if lvl2:
+        p2 = eng.lvl2_params()
+        bk = rng.integers(0, 2**64, size=int(p2.bk_words), dtype=np.uint64)
+        ksk = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.uint32)
+    else:
+        bk = rng.integers(0, 2**32, size=ol.BK_WORDS, dtype=np.uint64).astype(np.uint32)
+        ksk = rng.integers(0, 2**32, size=ol.KSK_WORDS, dtype=np.uint64).astype(np.uint32)
     in0 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
     in1 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
 
     eng.SetGPUNum(1)
-    eng.Initialize(bk, ksk)
+    if lvl2:
+        eng.lvl2_initialize(bk, ksk)
+    else:
+        eng.Initialize(bk, ksk)
     d0 = eng.api.DeviceBuffer(in0.size).upload(in0)
     d1 = eng.api.DeviceBuffer(in1.size).upload(in1)
     in2 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
     d2 = eng.api.DeviceBuffer(in2.size).upload(in2)
     dout = eng.api.DeviceBuffer(count * (ol.n + 1))
-    if args.workload == "nand":
+    if args.workload in ("nand", "nand_lvl2"):
         ops, rot_per_gate = eng.api.NAND, 1
     elif args.workload == "mux":
         ops, rot_per_gate = eng.api.MUX, 2
@@ -160,7 +200,10 @@ def main():
     st.Create()
 
     def step():
-        eng.gate_batch(ops, 0, dout, d0, d1, d2, count=count, device=0, stream=st.st())
+        if lvl2:
+            eng.lvl2_gate_batch(ops, dout, d0, d1, d2, count=count, device=0, stream=st.st())
+        else:
+            eng.gate_batch(ops, 0, dout, d0, d1, d2, count=count, device=0, stream=st.st())
 
     def barrier():
         if WORLD > 1:
@@ -182,7 +225,7 @@ def main():
     elapsed = distutil.max_over_ranks(elapsed, dist)
 
     latency_ms = None
-    if RANK == 0 and args.latency:
+    if RANK == 0 and args.latency and not lvl2:
         # ms/gate latency: one gate alone on the idle device, enqueue -> result on the stream
         # (a 1-gate launch takes the workgroup-per-rotation kernel)
         lat = []
@@ -198,8 +241,10 @@ def main():
         br_ms = prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1)
         ks_ms = prof.keyswitch_ms / max(prof.keyswitch_launches, 1)
         rotations = count * rot_per_gate
-        achieved = BK_BYTES_PER_ROTATION * rotations / (br_ms * 1e-3) / 1e9
-        traffic, traffic_src = recorded_hbm_traffic(rotations)
+        # lvl2: the same n (k+1)^2 l N 8 accounting at N = 2048, l = 4 (the device key is 3x that: three limbs)
+        bk_bytes = 630 * 4 * 4 * 2048 * 8 if lvl2 else BK_BYTES_PER_ROTATION
+        achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9
+        traffic, traffic_src = (None, None) if lvl2 else recorded_hbm_traffic(rotations)
         res = {
             "metric": "nand_gate_bootstraps_per_sec" if args.workload == "nand" else f"{args.workload}_gates_per_sec",
             "value": total_gates / elapsed,
@@ -215,20 +260,21 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{count} independent {args.workload.upper()} gates per GPU per step "
-                            f"(BASELINE configs[{dict(nand=1, mux=3, mixed=2)[args.workload]}]), "
-                            "TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2, lvl0 ciphertexts resident in HBM",
+                            f"(BASELINE configs[{dict(nand=1, mux=3, mixed=2, nand_lvl2=4)[args.workload]}]), " +
+                            ("TFHE n=630 N=2048 k=1 l=4 Bgbit=9 64-bit torus, t=7 basebit=2" if lvl2 else
+                             "TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2") + ", lvl0 ciphertexts resident in HBM",
                 "gates_per_gpu": count,
                 "sharding": "gates split across ranks, per-GPU BK/KSK replica, no collective",
             },
             "ms_per_gate_throughput": 1e3 * elapsed / (count * args.steps),
             "ms_per_gate_latency_single_gate": latency_ms,
             "roofline": {
-                "bound": "hbm", "kernel": "blind_rotate_kernel",
+                "bound": "hbm", "kernel": "blind_rotate_lvl2_kernel" if lvl2 else "blind_rotate_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src,
                 "launch_ms": br_ms, "rotations_per_launch": rotations,
-                "algorithmic_bytes_per_rotation": BK_BYTES_PER_ROTATION,
+                "algorithmic_bytes_per_rotation": bk_bytes,
                 "keyswitch_launch_ms": ks_ms,
             },
         }
@@ -236,6 +282,10 @@ def main():
             gpu_out = dout.download().reshape(count, ol.n + 1)
             import oracle_lib                 # the only leg that touches the CPU oracle
             res["cpu_baseline"] = cpu_baseline(eng, oracle_lib, bk, ksk, in0, in1, gpu_out)
+        if not args.no_cpu_baseline and WORLD == 1 and lvl2:
+            gpu_out = dout.download().reshape(count, ol.n + 1)
+            import oracle_lib
+            res["cpu_baseline"] = cpu_baseline_lvl2(oracle_lib, bk, ksk, in0, in1, gpu_out)
         print(json.dumps(res), flush=True)
 
     st.Destroy()

@@ -221,8 +221,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     __syncthreads();
 
     const int wj = wave / k2L, wd = wave % k2L;               // this wave's TRGSW row = wj * l + wd
-    const WaveCtx ctx0 = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
-    const WaveCtx ctx1 = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2 + 1, lane);
+    const WaveCtx ctx_tile = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
     const bool inv_wave = wave < k2Prods;
     const int sh = k2Bgbit * wd;
 
@@ -235,8 +234,9 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         double2 bA[8], bB[8];
         load_key_poly(bA, key, lane);                         // in flight during the decomposition + NTT
 
-        // digit wd of (X^abar - 1) acc_wj at e and e + 1024, then the first forward stage
-        double x0[kRegs], x1[kRegs];
+        // digit wd of (X^abar - 1) acc_wj at e (low half-word) and e + 1024 (high half-word);
+        // kept packed across the two halves: 16 registers instead of 64
+        uint32_t ab[kRegs];
         {
             const char* accj = (const char*)(accL + wj * k2N);
 #pragma unroll
@@ -248,19 +248,36 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
                 const uint64_t t0 = ((neg0 ? 0ull - rot0 : rot0) - cur0 + decomp_offset2()) ^ decomp_signmask2();
                 const uint64_t t1 = ((neg1 ? 0ull - rot1 : rot1) - cur1 + decomp_offset2()) ^ decomp_signmask2();
-                const double a = (double)(int)((int64_t)(t0 << sh) >> (64 - k2Bgbit));
-                const double b = (double)(int)((int64_t)(t1 << sh) >> (64 - k2Bgbit));
-                x0[r] = __builtin_fma(b, fpf::ROOT4, a);       // exact: |I b| < 2^33
-                x1[r] = __builtin_fma(-b, fpf::ROOT4, a);
+                const uint32_t a = (uint32_t)((int64_t)(t0 << sh) >> (64 - k2Bgbit));
+                const uint32_t b = (uint32_t)((int64_t)(t1 << sh) >> (64 - k2Bgbit));
+                ab[r] = (a & 0xffffu) | (b << 16);
             }
         }
         double R0[kRegs];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const WaveCtx& ctx = h ? ctx1 : ctx0;
+            // table addresses of this half, rebuilt here (a few address adds) instead of being
+            // carried in 16 registers through the whole step
+            WaveCtx ctx = ctx_tile;
+            {
+                int o16 = 8 * (lane & 15), o64 = 8 * lane;
+                asm volatile("" : "+v"(o16), "+v"(o64));
+                const NttTables* gth = gt2 + h;
+                ctx.tb_fwd = (const char*)gth->tb_fwd + o16;
+                ctx.tb_inv = (const char*)gth->tb_inv + o16;
+                ctx.tc_fwd = (const char*)gth->tc_fwd + o64;
+                ctx.tc_inv = (const char*)gth->tc_inv + o64;
+                ctx.gt = gth;
+            }
             double x[kRegs];
 #pragma unroll
-            for (int r = 0; r < kRegs; r++) x[r] = h ? x1[r] : x0[r];
+            for (int r = 0; r < kRegs; r++) {
+                // first forward stage (a, b) -> a +- I b: exact, |I b| < 2^33
+                uint32_t w = ab[r];
+                asm volatile("" : "+v"(w));      // re-derive per half: keeps 16 registers live, not 64
+                const double a = (double)(int)(int16_t)(w & 0xffffu), b = (double)((int)w >> 16);
+                x[r] = __builtin_fma(h ? -b : b, fpf::ROOT4, a);
+            }
             ntt_forward<false>(x, ctx);
 #pragma unroll
             for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
