@@ -230,7 +230,11 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
         const int alo = (int)(abar & (k2N - 1));
         const bool ahi = (abar >> k2Nbit) != 0;
+#ifdef CUFHE_AMD_ABL_BK0      // timing-only diagnostic: every step reads step 0's key (cache resident)
+        const double* key = bk_ntt + (size_t)(i & 1) * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#else
         const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#endif
         double2 bA[8], bB[8];
         load_key_poly(bA, key, lane);                         // in flight during the decomposition + NTT
 

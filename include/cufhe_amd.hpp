@@ -90,6 +90,34 @@ inline void Initialize(const TFHEpp::EvalKey& ek)
 inline void CleanUp() { CUFHE_AMD_CHECK(cufhe_amd_cleanup()); }
 inline void Synchronize() { CUFHE_AMD_CHECK(cufhe_amd_synchronize()); }
 
+/// N = 2048 ring / 64-bit torus (lvl02 blind rotate, lvl20 key switch; no reference counterpart,
+/// see include/cufhe_amd.h).  Gates take and return lvl0 ciphertexts in device memory.
+namespace lvl2 {
+/// bk: [n][(k+1)l][k+1][N] uint64 torus words, ksk: [kN][t][2^(basebit-1)][n+1] uint32
+inline void Initialize(const uint64_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
+{
+    CUFHE_AMD_CHECK(cufhe_amd_lvl2_initialize(bk, bk_words, ksk, ksk_words));
+}
+#ifdef CUFHE_AMD_USE_TFHEPP
+inline void Initialize(const TFHEpp::EvalKey& ek)
+{
+    const auto& bk = ek.getbk<TFHEpp::lvl02param>();
+    const auto& ksk = ek.getiksk<TFHEpp::lvl20param>();
+    Initialize(reinterpret_cast<const uint64_t*>(bk.data()), sizeof(bk) / sizeof(uint64_t),
+               reinterpret_cast<const uint32_t*>(ksk.data()), sizeof(ksk) / sizeof(uint32_t));
+}
+#endif
+/// `count` gates of one op on contiguous lvl0 ciphertexts (stride n + 1 words) of device `device`
+inline void GateBatch(int op, size_t count, uint32_t* out, const uint32_t* in0, const uint32_t* in1,
+                      const uint32_t* in2, int device = 0, void* stream = nullptr)
+{
+    const int32_t o = op;
+    cufhe_amd_lvl2_params p;
+    CUFHE_AMD_CHECK(cufhe_amd_lvl2_get_params(&p));
+    CUFHE_AMD_CHECK(cufhe_amd_lvl2_gate_batch(device, stream, count, &o, 0, out, in0, in1, in2, p.lvl0_words));
+}
+}  // namespace lvl2
+
 /// class Stream, include/cufhe_gpu.cuh:152-189 (passed by value, never auto-destroyed)
 class Stream {
    public:

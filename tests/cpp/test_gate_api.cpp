@@ -14,6 +14,7 @@
 
 #include "../../include/cufhe_amd.hpp"
 #include "../../oracle/tfhe_oracle.h"
+#include "../../oracle/tfhe_oracle_lvl2.h"
 
 using namespace cufhe;
 
@@ -233,6 +234,41 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
     st.Destroy();
 }
 
+// BASELINE configs[4]: the same gates through the N = 2048 ring (no reference test exists:
+// the check is the one of test/test_util.h:75-94, decrypt == plain truth function)
+void Lvl2Gates(std::mt19937& eng)
+{
+    std::vector<uint32_t> s2(ORC2_N);
+    orc2_keygen(7, s2.data());
+    std::vector<uint64_t> bk(ORC2_BK_WORDS);
+    std::vector<uint32_t> ksk(ORC2_KSK_WORDS);
+    orc2_bkgen(3007, g_s0.data(), s2.data(), bk.data());
+    orc2_kskgen(4007, g_s0.data(), s2.data(), ksk.data());
+    lvl2::Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
+    const int K = 64, W = ORC_LVL0_WORDS;
+    std::vector<uint32_t> h(4 * K * W);
+    std::vector<uint8_t> pt(3 * K);
+    uint32_t* d = nullptr;
+    CUFHE_AMD_CHECK(cufhe_amd_malloc(0, h.size() * 4, (void**)&d));
+    const int ops[] = {ORC_NAND, ORC_XOR, ORC_ORNY, ORC_MUX, ORC_NMUX, ORC_NOT};
+    for (int op : ops) {
+        for (int i = 0; i < 3 * K; i++) {
+            pt[i] = eng() & 1;
+            orc_tlwe_encrypt(&g_rng, 0, g_s0.data(), pt[i], h.data() + (size_t)(K + i) * W);
+        }
+        CUFHE_AMD_CHECK(cufhe_amd_memcpy_h2d(0, nullptr, d, h.data(), h.size() * 4));
+        lvl2::GateBatch(op, K, d, d + K * W, d + 2 * K * W, d + 3 * K * W);
+        CUFHE_AMD_CHECK(cufhe_amd_memcpy_d2h(0, nullptr, h.data(), d, (size_t)K * W * 4));
+        Synchronize();
+        int bad = 0;
+        for (int i = 0; i < K; i++)
+            if (orc_tlwe_decrypt(0, g_s0.data(), h.data() + (size_t)i * W) != orc_truth(op, pt[i], pt[K + i], pt[2 * K + i])) bad++;
+        std::printf("lvl2 ring op %d: %s (%d/%d failures)\n", op, bad ? "FAIL" : "PASS", bad, K);
+        g_failures += bad;
+    }
+    CUFHE_AMD_CHECK(cufhe_amd_free(0, d));
+}
+
 int main(int argc, char** argv)
 {
     const int gpus = argc > 1 ? atoi(argv[1]) : 1;
@@ -253,6 +289,7 @@ int main(int argc, char** argv)
     DeviceResident(eng);
     TrlwePrimitives(eng, bk);
     RippleAdders(eng);
+    Lvl2Gates(eng);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
     return g_failures ? 1 : 0;

@@ -110,3 +110,27 @@ def test_errors(engine2):
         engine2.lvl2_gate_batch(99, buf, buf, buf)
     with pytest.raises(engine2.CufheAmdError):
         engine2.lvl2_initialize(np.zeros(8, np.uint64), np.zeros(8, np.uint32))
+
+
+def test_golden_vectors_on_gpu(engine2, keys, keys2):
+    """tests/golden/golden_lvl2_v1.json: every op, sha256 of the output words."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(ol.ROOT, "tests", "golden", "golden_lvl2_v1.json")) as f:
+        g = json.load(f)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    if sha(keys2.bk) != g["keys_sha256"]["bk"] or sha(keys2.ksk) != g["keys_sha256"]["ksk"]:
+        pytest.skip("key generation is not bit-reproducible on this host (libm differences)")
+    triples = np.array(g["triples"], np.uint8)
+    ins = [keys.encrypt(triples[:, i], 0, seed=7000 + i) for i in range(3)]
+    assert [sha(x) for x in ins] == g["inputs_sha256"]
+    dins = [_upload(engine2, x) for x in ins]
+    dout = engine2.api.DeviceBuffer(len(triples) * (ol.n + 1))
+    for op, name in enumerate(ol.OPS):
+        engine2.lvl2_gate_batch(op, dout, dins[0], dins[1], dins[2], count=len(triples))
+        got = dout.download().reshape(len(triples), -1)
+        assert sha(got) == g["ops"][name]["out_sha256"], name
+    dacc = engine2.api.DeviceBuffer(2 * ol.N2 * 2)
+    engine2.lvl2_blind_rotate_batch(dins[0], dacc, 1, 3)
+    assert sha(dacc.download().view(np.uint64)) == g["acc_after_3_steps_sha256"]

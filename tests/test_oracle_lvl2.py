@@ -58,3 +58,25 @@ def test_gates_decrypt_to_truth_table(oracle, keys, keys2):
     out2 = keys2.gate_batch(ol.OPS.index("NAND"), out, cts[1])
     want2 = [int(not (want[g] and bits[1, g])) for g in range(count)]
     assert list(keys.decrypt(out2, 0)) == want2
+
+
+def test_golden_vectors(oracle, keys, keys2):
+    """tests/golden/golden_lvl2_v1.json (made by tests/golden/make_golden_lvl2.py)."""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(ol.ROOT, "tests", "golden", "golden_lvl2_v1.json")) as f:
+        g = json.load(f)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert (g["key_seed"], g["key2_seed"]) == (keys.seed, 7)
+    for name, arr in (("s0", keys.s0), ("s2", keys2.s2), ("bk", keys2.bk), ("ksk", keys2.ksk)):
+        assert sha(arr) == g["keys_sha256"][name], f"key {name} is not reproducible"
+    triples = np.array(g["triples"], np.uint8)
+    ins = [keys.encrypt(triples[:, i], 0, seed=7000 + i) for i in range(3)]
+    assert [sha(x) for x in ins] == g["inputs_sha256"]
+    for name in ("NAND", "MUX", "XNOR"):
+        out = keys2.gate_batch(ol.OPS.index(name), ins[0], ins[1], ins[2])
+        assert sha(out) == g["ops"][name]["out_sha256"], name
+        if "out_words_gate0" in g["ops"][name]:
+            assert [int(x) for x in out[0]] == g["ops"][name]["out_words_gate0"]
+    assert sha(keys2.blind_rotate(ins[0][0], 3)) == g["acc_after_3_steps_sha256"]
