@@ -26,8 +26,9 @@
 // waves 0-5 then each inverse-transform one sum and add their limb of the result into the
 // 64-bit accumulator in LDS with ds_add_u64.  Four workgroup barriers per CMux step.
 // LDS: 8 transpose tiles (66 KiB), accumulator 2 x 2048 x u64 (32 KiB), sums 6 x 1024 x f64
-// (48 KiB), abar list.  The twiddle tables of the two halves do not fit beside that and are
-// read from global memory (L1/L2 resident, fetched ahead of the transposes as in lvl1).
+// (48 KiB), abar list, the per-lane twiddles of stages 4-7 (7.5 KiB).  The stage 8-9 twiddle
+// tables of the two halves (24 KiB) do not fit beside that and are read from global memory
+// (L1/L2 resident, fetched ahead of the register transposes as in lvl1).
 #pragma once
 #include "kernels.hip.h"
 
@@ -167,7 +168,9 @@ constexpr int k2LdsTiles = 0;
 constexpr int k2LdsAcc = k2LdsTiles + 8 * kTileBytes;            // 67584
 constexpr int k2LdsSum = k2LdsAcc + 2 * k2N * 8;                 // + 32768
 constexpr int k2LdsAbar = k2LdsSum + k2Prods * k2Half * 8;       // + 49152
-constexpr int k2LdsBytes = k2LdsAbar + kAbarBytes + 16;          // 150800
+constexpr int k2LdsTb = k2LdsAbar + kAbarBytes + 16;             // stage 4-7 twiddles of both halves: [h][fwd|inv][15][16]
+constexpr int k2TbBytes = 2 * kTbCount * 16 * 8;                 // 3840 per half
+constexpr int k2LdsBytes = k2LdsTb + 2 * k2TbBytes;              // 158480
 
 __device__ __forceinline__ void load_key_poly(double2 (&b)[8], const double* poly, int lane)
 {
@@ -209,6 +212,10 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         else *bbar_slot = 2 * k2N - ((c + d.off) >> (32 - 1 - k2Nbit));
     }
     for (int i = tid; i < k2Prods * k2Half; i += k2Threads) sumL[i] = 0.0;
+    for (int i = tid; i < 2 * 2 * kTbCount * 16; i += k2Threads) {     // tb_fwd and tb_inv are contiguous in NttTables
+        const int h = i / (2 * kTbCount * 16), k = i % (2 * kTbCount * 16);
+        ((double*)(smem + k2LdsTb))[i] = gt2[h].tb_fwd[k];
+    }
     __syncthreads();
     {   // RotatedTestVector<lvl2param>, include/gatebootstrapping_gpu.cuh:29-52
         const uint32_t bbar = *bbar_slot;
@@ -267,8 +274,8 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 int o16 = 8 * (lane & 15), o64 = 8 * lane;
                 asm volatile("" : "+v"(o16), "+v"(o64));
                 const NttTables* gth = gt2 + h;
-                ctx.tb_fwd = (const char*)gth->tb_fwd + o16;
-                ctx.tb_inv = (const char*)gth->tb_inv + o16;
+                ctx.tb_fwd = smem + (k2LdsTb + h * k2TbBytes) + o16;
+                ctx.tb_inv = ctx.tb_fwd + 8 * kTbCount * 16;
                 ctx.tc_fwd = (const char*)gth->tc_fwd + o64;
                 ctx.tc_inv = (const char*)gth->tc_inv + o64;
                 ctx.gt = gth;
