@@ -41,25 +41,26 @@ BK_BYTES_PER_ROTATION = 61931520          # n (k+1)^2 l N 8, SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def recorded_hbm_traffic(rotations):
+def recorded_hbm_traffic(rotations, lvl2=False):
     """HBM bytes per blind-rotate launch from the committed rocprofv3 PMC passes (separate
-    --pmc runs of this same command, profiles/r01_final_pmc_*): FETCH_SIZE is in KB and reads
+    --pmc runs of this same command, profiles/r01_{final,lvl2}_pmc_*): FETCH_SIZE is in KB and reads
     half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.
     Only meaningful for the launch shape it was recorded on (4096 rotations); else None."""
     import csv
     if rotations != 4096:
         return None, None
+    tag, kernel = ("r01_lvl2", "blind_rotate_lvl2_kernel") if lvl2 else ("r01_final", "blind_rotate_kernel")
     try:
         vals = {}
-        for name, f in (("FETCH_SIZE", "r01_final_pmc_fetch_counter_collection.csv"),
-                        ("WRITE_SIZE", "r01_final_pmc_tcc_counter_collection.csv")):
+        for name, f in (("FETCH_SIZE", f"{tag}_pmc_fetch_counter_collection.csv"),
+                        ("WRITE_SIZE", f"{tag}_pmc_tcc_counter_collection.csv")):
             path = os.path.join(ROOT, "profiles", f)
             best = 0.0
             for r in csv.DictReader(open(path)):
-                if "blind_rotate_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                if kernel in r["Kernel_Name"] and r["Counter_Name"] == name:
                     best = max(best, float(r["Counter_Value"]))
             vals[name] = best
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01_final_pmc_{fetch,tcc}_counter_collection.csv"
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"profiles/{tag}_pmc_{{fetch,tcc}}_counter_collection.csv"
     except Exception:
         return None, None
 
@@ -244,7 +245,7 @@ def main():
         # lvl2: the same n (k+1)^2 l N 8 accounting at N = 2048, l = 4 (the device key is 3x that: three limbs)
         bk_bytes = 630 * 4 * 4 * 2048 * 8 if lvl2 else BK_BYTES_PER_ROTATION
         achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None) if lvl2 else recorded_hbm_traffic(rotations)
+        traffic, traffic_src = recorded_hbm_traffic(rotations, lvl2)
         res = {
             "metric": "nand_gate_bootstraps_per_sec" if args.workload == "nand" else f"{args.workload}_gates_per_sec",
             "value": total_gates / elapsed,
