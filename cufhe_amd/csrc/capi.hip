@@ -69,6 +69,7 @@ int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
+long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
 std::mutex g_mu;
 
@@ -298,8 +299,12 @@ const int kGateTab[10][3] = {
 struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1; const uint32_t* in2; };
 
 template <class GetGate>
+int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lvl2.inc.h
+
+template <class GetGate>
 int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 {
+    if (level == 0 && g_lvl0_ring == 2048) return run_gates_lvl2(device, stream, count, get);
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
@@ -778,6 +783,11 @@ int cufhe_amd_set_option(const char* key, long value)
     }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
+    if (!strcmp(key, "lvl0_ring")) {
+        if (value != 1024 && value != 2048) return fail(-1, "lvl0_ring must be 1024 or 2048");
+        g_lvl0_ring = value;
+        return 0;
+    }
     return fail(-1, std::string("unknown option ") + key);
 }
 

@@ -134,7 +134,7 @@ int sched_flush(int device)
     Batch* b = s.cur;
     if (b->empty()) return 0;
     DeviceState& ds = g_dev[device];
-    if (b->gate_count() && !ds.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (b->gate_count() && !ds.keys_ready && !ds.keys2_ready) return fail(-3, "Initialize(ek) has not been called for this device");
 
     size_t cap;
     if (!b->uploads.empty()) {

@@ -146,7 +146,11 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
  * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
  * "wg_threshold": launches of at most this many blind rotations use the workgroup-per-rotation
  * kernel (lowest latency); larger ones the wave-per-rotation batch kernel (highest throughput).
- * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words. */
+ * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words.
+ * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
+ * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
+ * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in
+ * the C++ shim) runs through the N = 2048 path. */
 int cufhe_amd_set_option(const char* key, long value);
 
 /* ---- N = 2048 ring, 64-bit torus (BASELINE.json configs[4]; lvl2 / lvl02 / lvl20) ----

@@ -267,6 +267,10 @@ void Lvl2Gates(std::mt19937& eng)
         g_failures += bad;
     }
     CUFHE_AMD_CHECK(cufhe_amd_free(0, d));
+    // the whole per-gate API (host ciphertexts, streams, scheduler) over the same ring
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("lvl0_ring", 2048));
+    AllGates<TFHEpp::lvl0param>(16, 64, eng);
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("lvl0_ring", 1024));
 }
 
 int main(int argc, char** argv)

@@ -134,3 +134,33 @@ def test_golden_vectors_on_gpu(engine2, keys, keys2):
     dacc = engine2.api.DeviceBuffer(2 * ol.N2 * 2)
     engine2.lvl2_blind_rotate_batch(dins[0], dacc, 1, 3)
     assert sha(dacc.download().view(np.uint64)) == g["acc_after_3_steps_sha256"]
+
+
+def test_lvl0_ring_option_routes_the_level0_api(engine2, keys, keys2):
+    """cufhe_amd_set_option("lvl0_ring", 2048): cufhe_amd_gate_batch at level 0 and the recorded
+    per-gate API give the words of the lvl2 path."""
+    api = engine2.api
+    rng = np.random.default_rng(77)
+    count = 6
+    bits = rng.integers(0, 2, (2, count)).astype(np.uint8)
+    ca, cb = keys.encrypt(bits[0], 0, seed=501), keys.encrypt(bits[1], 0, seed=502)
+    want = keys2.gate_batch(ol.OPS.index("XOR"), ca, cb)
+    da, db = _upload(engine2, ca), _upload(engine2, cb)
+    dout = api.DeviceBuffer(count * (ol.n + 1))
+    api.set_option("lvl0_ring", 2048)
+    try:
+        engine2.gate_batch(api.XOR, 0, dout, da, db)
+        assert np.array_equal(dout.download().reshape(count, -1), want)
+        st = api.Stream()
+        st.Create()
+        a, b, o = api.Ctxt(0), api.Ctxt(0), api.Ctxt(0)
+        a.tlwehost[:] = ca[0]
+        b.tlwehost[:] = cb[0]
+        api.Xor(o, a, b, st)
+        api.Synchronize()
+        assert np.array_equal(o.tlwehost, want[0])
+        st.Destroy()
+    finally:
+        api.set_option("lvl0_ring", 1024)
+    with pytest.raises(engine2.CufheAmdError):
+        api.set_option("lvl0_ring", 512)
