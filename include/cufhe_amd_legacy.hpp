@@ -1,0 +1,224 @@
+// cufhe_amd_legacy.hpp -- the original cuFHE user manual API on top of cufhe_amd.hpp.
+//
+// /root/reference/README.md:46-82 and test/test_api_gpu.cu:84-159 still document and use the
+// pre-TFHEpp surface
+//     SetSeed(); PriKey pri; PubKey pub; KeyGen(pub, pri);   (or PriKeyGen / PubKeyGen)
+//     Ptxt pt; pt = 1;  Ctxt ct;  Encrypt(ct, pt, pri);  Decrypt(pt, ct, pri);
+//     Initialize(pub);  Nand(ct0, ct0, ct1, stream);  Synchronize();  CleanUp();
+//     WritePriKeyToFile / ReadPriKeyFromFile / WritePubKeyToFile / ReadPubKeyFromFile
+// although none of it is left in the reference's include/ or src/ (the current library takes
+// keys and ciphertexts from TFHEpp).  This header supplies it, so that a program written
+// against the manual builds unchanged with
+//     #include <cufhe_amd_legacy.hpp>
+//     using namespace cufhe::legacy;
+// A legacy `Ctxt` is a lvl0 ciphertext (`cufhe::Ctxt<TFHEpp::lvl0param>`): the gates bootstrap
+// lvl0 -> lvl1 -> lvl0 exactly like Nand<lvl0param>.
+//
+// Key generation, encryption and decryption are plain host C++ (standard TFHE: binary keys,
+// b = <a, s> + m + e, messages +-mu) and are NOT part of the accelerated
+// path.  The generator is std::mt19937_64: adequate for tests and demos, not a CSPRNG -- for
+// real keys generate them with TFHEpp and call cufhe::Initialize(evalkey).
+#pragma once
+#include <cmath>
+#include <fstream>
+#include <random>
+#include <stdexcept>
+#include <string>
+
+#include "cufhe_amd.hpp"
+
+namespace cufhe {
+namespace legacy {
+
+using lvl0 = TFHEpp::lvl0param;
+using lvl1 = TFHEpp::lvl1param;
+
+// ---- what the manual takes from namespace cufhe unchanged ----
+using cufhe::SetGPUNum;
+using cufhe::Synchronize;
+using cufhe::CleanUp;
+using cufhe::Stream;
+using cufhe::StreamQuery;
+using Ctxt = cufhe::Ctxt<lvl0>;
+
+struct Ptxt {
+    static const uint32_t kPtxtSpace = 2;
+    uint32_t message_ = 0;
+    Ptxt() {}
+    Ptxt(uint32_t m) : message_(m % kPtxtSpace) {}
+    Ptxt& operator=(uint32_t m) { message_ = m % kPtxtSpace; return *this; }
+    void set(uint32_t m) { message_ = m % kPtxtSpace; }
+    uint32_t get() const { return message_; }
+};
+
+struct PriKey {
+    std::vector<uint32_t> lvl0_key;   // n bits
+    std::vector<uint32_t> lvl1_key;   // N bits
+};
+struct PubKey {
+    std::vector<uint32_t> bk;         // [n][(k+1)l][k+1][N]   TRGSW_{s1}(s0[i]), torus domain
+    std::vector<uint32_t> ksk;        // [kN][t][2^(basebit-1)][n+1]
+};
+
+namespace detail {
+inline std::mt19937_64& rng() { static std::mt19937_64 g(5489u); return g; }
+inline uint32_t uniform32() { return (uint32_t)(rng()() >> 32); }
+inline uint32_t gauss32(double alpha)
+{
+    static std::normal_distribution<double> nd(0.0, 1.0);
+    return (uint32_t)(int64_t)std::llround(nd(rng()) * alpha * 4294967296.0);
+}
+constexpr double kAlpha0 = 1.0 / 32768.0;      // 2^-15
+constexpr double kAlpha1 = 1.0 / 33554432.0;   // 2^-25
+constexpr uint32_t kMu = lvl0::μ;
+constexpr uint32_t kKsT = TFHEpp::lvl10param::t, kKsBasebit = TFHEpp::lvl10param::basebit;
+constexpr uint32_t kKsNumBase = 1u << (kKsBasebit - 1);
+
+inline void tlwe_encrypt(uint32_t* ct, uint32_t msg, const std::vector<uint32_t>& key, double alpha)
+{
+    const size_t n = key.size();
+    uint32_t b = msg + gauss32(alpha);
+    for (size_t i = 0; i < n; i++) {
+        ct[i] = uniform32();
+        b += ct[i] * key[i];
+    }
+    ct[n] = b;
+}
+inline uint32_t tlwe_phase(const uint32_t* ct, const std::vector<uint32_t>& key)
+{
+    const size_t n = key.size();
+    uint32_t ph = ct[n];
+    for (size_t i = 0; i < n; i++) ph -= ct[i] * key[i];
+    return ph;
+}
+}  // namespace detail
+
+inline void SetSeed() { detail::rng().seed(std::random_device{}()); }
+inline void SetSeed(uint64_t seed) { detail::rng().seed(seed); }
+
+inline void PriKeyGen(PriKey& pri)
+{
+    pri.lvl0_key.resize(lvl0::n);
+    pri.lvl1_key.resize(lvl1::n);
+    for (auto& b : pri.lvl0_key) b = (uint32_t)(detail::rng()() >> 63);
+    for (auto& b : pri.lvl1_key) b = (uint32_t)(detail::rng()() >> 63);
+}
+
+inline void PubKeyGen(PubKey& pub, const PriKey& pri)
+{
+    constexpr uint32_t n = lvl0::n, N = lvl1::n, l = lvl1::l, Bgbit = lvl1::Bgbit;
+    const auto& s0 = pri.lvl0_key;
+    const auto& s1 = pri.lvl1_key;
+    if (s0.size() != n || s1.size() != N) throw std::invalid_argument("PubKeyGen: private key not generated");
+    // bootstrapping key: row j*l + d of TRGSW(s0[i]) is a TRLWE encryption of zero plus
+    // s0[i] * 2^(32-(d+1)Bgbit) on component j
+    pub.bk.assign((size_t)n * 2 * l * 2 * N, 0);
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t row = 0; row < 2 * l; row++) {
+            uint32_t* a = pub.bk.data() + (((size_t)i * 2 * l + row) * 2) * N;
+            uint32_t* b = a + N;
+            for (uint32_t m = 0; m < N; m++) {
+                a[m] = detail::uniform32();
+                b[m] = detail::gauss32(detail::kAlpha1);
+            }
+            for (uint32_t j = 0; j < N; j++) {          // b += a * s1 (negacyclic, binary key)
+                if (!s1[j]) continue;
+                for (uint32_t m = 0; m < j; m++) b[m] -= a[N + m - j];
+                for (uint32_t m = j; m < N; m++) b[m] += a[m - j];
+            }
+            const uint32_t h = 1u << (32 - (row % l + 1) * Bgbit);
+            (row / l == 0 ? a : b)[0] += s0[i] * h;
+        }
+    // key-switching key: ksk[j][kappa][v-1] = TLWE_{s0}(v * s1[j] * 2^(32-(kappa+1) basebit))
+    const size_t words = n + 1;
+    pub.ksk.assign((size_t)N * detail::kKsT * detail::kKsNumBase * words, 0);
+    for (uint32_t j = 0; j < N; j++)
+        for (uint32_t kap = 0; kap < detail::kKsT; kap++)
+            for (uint32_t v = 1; v <= detail::kKsNumBase; v++) {
+                uint32_t* ct = pub.ksk.data() + (((size_t)j * detail::kKsT + kap) * detail::kKsNumBase + (v - 1)) * words;
+                detail::tlwe_encrypt(ct, v * s1[j] * (1u << (32 - (kap + 1) * detail::kKsBasebit)), s0, detail::kAlpha0);
+            }
+}
+
+inline void KeyGen(PubKey& pub, PriKey& pri)
+{
+    PriKeyGen(pri);
+    PubKeyGen(pub, pri);
+}
+
+/// on a bare lvl0 TLWE (no device buffers behind it)
+inline void Encrypt(TFHEpp::TLWE<lvl0>& tlwe, const Ptxt& pt, const PriKey& pri)
+{
+    detail::tlwe_encrypt(tlwe.data(), pt.message_ ? detail::kMu : 0u - detail::kMu, pri.lvl0_key, detail::kAlpha0);
+}
+inline void Decrypt(Ptxt& pt, const TFHEpp::TLWE<lvl0>& tlwe, const PriKey& pri)
+{
+    pt.message_ = (int32_t)detail::tlwe_phase(tlwe.data(), pri.lvl0_key) > 0 ? 1 : 0;
+}
+inline void Encrypt(Ctxt& ct, const Ptxt& pt, const PriKey& pri) { Encrypt(ct.tlwehost, pt, pri); }
+inline void Decrypt(Ptxt& pt, const Ctxt& ct, const PriKey& pri) { Decrypt(pt, ct.tlwehost, pri); }
+
+/// Initialize(pub_key) of the manual: bootstrapping key to the NTT domain + key-switching key, on every GPU
+inline void Initialize(const PubKey& pub) { cufhe::Initialize(pub.bk.data(), pub.bk.size(), pub.ksk.data(), pub.ksk.size()); }
+
+// ---- gates (test/test_api_gpu.cu:130-159); outputs may alias inputs ----
+#define CUFHE_AMD_LEGACY_GATE2(NAME) \
+    inline void NAME(Ctxt& out, Ctxt& in0, Ctxt& in1, Stream st) { cufhe::NAME<lvl0>(out, in0, in1, st); }
+CUFHE_AMD_LEGACY_GATE2(And) CUFHE_AMD_LEGACY_GATE2(AndYN) CUFHE_AMD_LEGACY_GATE2(AndNY)
+CUFHE_AMD_LEGACY_GATE2(Or) CUFHE_AMD_LEGACY_GATE2(OrYN) CUFHE_AMD_LEGACY_GATE2(OrNY)
+CUFHE_AMD_LEGACY_GATE2(Nand) CUFHE_AMD_LEGACY_GATE2(Nor) CUFHE_AMD_LEGACY_GATE2(Xor) CUFHE_AMD_LEGACY_GATE2(Xnor)
+#undef CUFHE_AMD_LEGACY_GATE2
+inline void Not(Ctxt& out, Ctxt& in, Stream st) { cufhe::Not<lvl0>(out, in, st); }
+inline void Copy(Ctxt& out, Ctxt& in, Stream st) { cufhe::Copy<lvl0>(out, in, st); }
+inline void Mux(Ctxt& out, Ctxt& inc, Ctxt& in1, Ctxt& in0, Stream st) { cufhe::Mux<lvl0>(out, inc, in1, in0, st); }
+inline void NMux(Ctxt& out, Ctxt& inc, Ctxt& in1, Ctxt& in0, Stream st) { cufhe::NMux<lvl0>(out, inc, in1, in0, st); }
+
+// ---- key files ("alternatively, write / read key files", README.md:53): raw little-endian words ----
+namespace detail {
+inline void write_vec(std::ofstream& f, const std::vector<uint32_t>& v)
+{
+    const uint64_t n = v.size();
+    f.write((const char*)&n, 8);
+    f.write((const char*)v.data(), (std::streamsize)(n * 4));
+}
+inline void read_vec(std::ifstream& f, std::vector<uint32_t>& v)
+{
+    uint64_t n = 0;
+    f.read((char*)&n, 8);
+    if (!f || n > (1ull << 32)) throw std::runtime_error("key file: bad header");
+    v.resize(n);
+    f.read((char*)v.data(), (std::streamsize)(n * 4));
+    if (!f) throw std::runtime_error("key file: truncated");
+}
+}  // namespace detail
+inline void WritePriKeyToFile(const PriKey& pri, const std::string& path)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    detail::write_vec(f, pri.lvl0_key);
+    detail::write_vec(f, pri.lvl1_key);
+}
+inline void ReadPriKeyFromFile(PriKey& pri, const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    detail::read_vec(f, pri.lvl0_key);
+    detail::read_vec(f, pri.lvl1_key);
+}
+inline void WritePubKeyToFile(const PubKey& pub, const std::string& path)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    detail::write_vec(f, pub.bk);
+    detail::write_vec(f, pub.ksk);
+}
+inline void ReadPubKeyFromFile(PubKey& pub, const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    detail::read_vec(f, pub.bk);
+    detail::read_vec(f, pub.ksk);
+}
+
+}  // namespace legacy
+}  // namespace cufhe

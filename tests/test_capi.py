@@ -57,3 +57,17 @@ def test_errors_are_reported_not_fatal():
     assert lib.cufhe_amd_gate(5, None, 0, 0, None, None, None, None) < 0
     with pytest.raises(cufhe_amd.CufheAmdError):
         _lib.check(lib.cufhe_amd_gate(5, None, 0, 0, None, None, None, None))
+
+
+def test_legacy_manual_api_host_side():
+    """include/cufhe_amd_legacy.hpp (the reference README's KeyGen / Encrypt / Decrypt / key-file
+    API): plain g++ host code; key generation, an encryption round trip and the key files need
+    no GPU (tests/cpp/test_legacy_api.cpp --cpu-only)."""
+    import subprocess
+    src = os.path.join(ol.ROOT, "tests", "cpp", "test_legacy_api.cpp")
+    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_legacy_api")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src,
+                           "-L" + os.path.join(ol.ROOT, "cufhe_amd"), "-lcufhe_amd",
+                           "-Wl,-rpath," + os.path.join(ol.ROOT, "cufhe_amd")])
+    out = subprocess.run([exe, "--cpu-only"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout + out.stderr

@@ -242,6 +242,29 @@ def test_cpp_gate_api_mirror(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+def test_cpp_legacy_manual_program(engine):
+    """tests/cpp/test_legacy_api.cpp: the reference's user-manual program (README.md:46-82,
+    test/test_api_gpu.cu) -- KeyGen, Encrypt, Initialize(pub_key), nine chained in-place gates on
+    32 streams, Decrypt -- against include/cufhe_amd_legacy.hpp."""
+    import os
+    import subprocess
+    src = os.path.join(ol.ROOT, "tests", "cpp", "test_legacy_api.cpp")
+    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_legacy_api")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src,
+                           "-L" + os.path.join(ol.ROOT, "cufhe_amd"), "-lcufhe_amd",
+                           "-Wl,-rpath," + os.path.join(ol.ROOT, "cufhe_amd")])
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+        print(out.stdout[-2000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
+
+
 def test_trlwe_level_primitives(engine, keys, oracle):
     """SampleExtractAndKeySwitch, Refresh, TRGSW2NTT + CMUXNTT (src/cufhe_gates_gpu.cu:69-146):
     words identical to the oracle; Refresh keeps the plaintext (test/test_perf.cc:83-87)."""
