@@ -15,6 +15,7 @@
 #include "../../include/cufhe_amd.h"
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
+#include "kernels_ll.hip.h"
 
 using namespace cufhe_amd;
 
@@ -49,6 +50,7 @@ struct Workspace { char* base = nullptr; size_t bytes = 0; };
 struct DeviceState {
     bool ntt_ready = false, keys_ready = false;
     NttTables* tables = nullptr;
+    Ntt512Tables* tables512 = nullptr;   // [2]: the two 512-point halves (low-latency kernel)
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
     bool profiling = false;
@@ -69,6 +71,7 @@ int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
+long g_ll_threshold = 1280;    // rotations per launch up to which the 16-wave split-transform kernel is used (5 rounds of 256 workgroups = one batch-kernel launch)
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
 std::mutex g_mu;
@@ -133,6 +136,40 @@ void build_tables(NttTables& t)
     fill_tables(t, fwd, inv);
 }
 
+// the two 512-point halves of the same transform: root_h[m + g] = root[2m + h m + g]
+void build_tables_512(Ntt512Tables (&t)[2])
+{
+    std::vector<double> fwd(kN), inv(kN);
+    const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
+    for (uint32_t i = 0; i < (uint32_t)kN; i++) {
+        fwd[i] = balanced(powmod_u64(psi, bitrev(i, 10)));
+        inv[i] = balanced(powmod_u64(psi_inv, bitrev(i, 10)));
+    }
+    for (int h = 0; h < 2; h++) {
+        memset(&t[h], 0, sizeof(t[h]));
+        auto rf = [&](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return fwd[2 * m + h * m + (idx - m)]; };
+        auto ri = [&](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return inv[2 * m + h * m + (idx - m)]; };
+        for (int k = 0; k < 7; k++) {
+            int lvl = 0;
+            while ((2 << lvl) <= k + 1) lvl++;
+            const int j = k + 1 - (1 << lvl);
+            t[h].tu_fwd[k] = rf((1 << lvl) + j);
+            t[h].tu_inv[k] = ri((1 << lvl) + j);
+            for (int lam = 0; lam < 8; lam++) {
+                const int idx = (8 << lvl) + (lam << lvl) + j;
+                t[h].tb_fwd[k * 8 + lam] = rf(idx);
+                t[h].tb_inv[k * 8 + lam] = ri(idx);
+            }
+            for (int lane = 0; lane < 64; lane++) {
+                const int mu = 8 * (lane & 7) + (lane >> 3);
+                const int idx = (64 << lvl) + (mu << lvl) + j;
+                t[h].tc_fwd[k * 64 + lane] = rf(idx);
+                t[h].tc_inv[k * 64 + lane] = ri(idx);
+            }
+        }
+    }
+}
+
 int check_device(int device)
 {
     if (device < 0 || device >= g_gpu_num) return fail(-1, "device index out of range (SetGPUNum first)");
@@ -154,6 +191,10 @@ int ensure_ntt(int device)
     build_tables(host);
     HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
     HIP_TRY(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
+    static Ntt512Tables host512[2];
+    build_tables_512(host512);
+    HIP_TRY(hipMalloc((void**)&s.tables512, sizeof(host512)));
+    HIP_TRY(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
     s.ntt_ready = true;
     return 0;
 }
@@ -235,9 +276,14 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     if (!s.br_lds_opt_in) {      // > 64 KiB of dynamic LDS needs an opt-in, per device
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLlLdsBytes));
         s.br_lds_opt_in = true;
     }
-    if ((long)count <= g_wg_threshold) {
+    if ((long)count <= g_ll_threshold) {
+        // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
+        hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)count), dim3(kLlThreads), kLlLdsBytes, st, d, (int)count,
+                           s.bk_ntt, s.tables512, steps, acc_dump);
+    } else if ((long)count <= g_wg_threshold) {
         // small batch: one workgroup per rotation (latency), see kernels.hip.h
         hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)count), dim3(kWgThreads), kWgLdsBytes, st, d, (int)count,
                            s.bk_ntt, s.tables, steps, acc_dump);
@@ -508,14 +554,14 @@ int cufhe_amd_cleanup(void)
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
         s.keys2_ready = s.br2_lds_opt_in = false;
         s.tables2 = nullptr; s.bk2_ntt = nullptr; s.ksk2 = nullptr;
-        if (s.ntt_ready) HIP_TRY(hipFree(s.tables));
+        if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables512)); }
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
         s.staging.clear();
         for (auto& kv : s.workspaces) (void)hipFree(kv.second.base);
         s.workspaces.clear();
         s.ntt_ready = s.keys_ready = false;
         s.br_lds_opt_in = s.ks_lds_opt_in = false;
-        s.tables = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
+        s.tables = nullptr; s.tables512 = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
         s.prof = cufhe_amd_profile{};
     }
     return 0;
@@ -782,6 +828,7 @@ int cufhe_amd_set_option(const char* key, long value)
         return 0;
     }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
+    if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "lvl0_ring")) {
         if (value != 1024 && value != 2048) return fail(-1, "lvl0_ring must be 1024 or 2048");

@@ -1,0 +1,171 @@
+// kernels_ll.hip.h -- low-latency blind rotate: one 16-wave workgroup per rotation, every
+// transform split into its two 512-point halves (ntt_wave512.h).
+//
+// Same words as blind_rotate_kernel / blind_rotate_wg_kernel (kernels.hip.h); used for launches
+// too small to fill the chip with the wave-per-rotation kernel, where what counts is the length
+// of the dependent chain of ONE rotation: 630 CMux steps, each "decompose -> forward NTT ->
+// pointwise -> inverse NTT -> accumulate".
+//
+//   waves 0-11   (row, h) = (w / 2, w % 2): digit row `row` of the step, half h of its transform:
+//                decompose, first stage u_h = a[e] +- I a[e + 512] (exact), 512-point forward
+//                transform, 16 products against the two key polynomials of the row, ds_add_f64
+//                into the sums -- three such waves per SIMD
+//   waves 12-15  (out, h): inverse 512-point transform of half h of sum `out` -- one per SIMD;
+//                the halves meet in LDS for the last stage (u0 + u1, (u0 - u1) I^-1), then the
+//                centred lift into the accumulator
+// Three workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
+#pragma once
+#include "kernels.hip.h"
+#include "ntt_wave512.h"
+
+namespace cufhe_amd {
+
+constexpr int kLlThreads = 1024;
+constexpr int kLlRowWaves = 2 * kBkRows;                                      // 12
+constexpr int kLlLdsTables = 0;                                               // [h][tb_fwd|tb_inv|tc_fwd|tc_inv]
+constexpr int kLlLdsTiles = kLlLdsTables + 2 * kLds512TableBytes;             // 16128
+constexpr int kLlLdsAcc = kLlLdsTiles + 16 * kTile512Bytes;                   // + 72704
+constexpr int kLlLdsSum = kLlLdsAcc + 2 * 2 * kN * 4;                         // + 16384   [j][copy][N] u32
+constexpr int kLlLdsHand = kLlLdsSum + 2 * kN * 8;                            // + 16384   [out][h][c][lane] f64
+constexpr int kLlLdsAbar = kLlLdsHand + 2 * kN * 8;                           // + 16384   [out][h][e] f64
+constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 139280
+
+__global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    uint32_t* accL = (uint32_t*)(smem + kLlLdsAcc);           // [j][copy][N]
+    double* sumL = (double*)(smem + kLlLdsSum);               // [out][h][c][lane]
+    double* handL = (double*)(smem + kLlLdsHand);             // [out][h][e]
+    uint16_t* abar_lds = (uint16_t*)(smem + kLlLdsAbar);
+    uint32_t* bbar_slot = (uint32_t*)(smem + kLlLdsAbar + kAbarBytes);
+
+    for (int i = tid; i < 2 * kLds512TableDoubles; i += kLlThreads) {     // tb_fwd .. tc_inv are contiguous
+        const int h = i / kLds512TableDoubles, k = i % kLds512TableDoubles;
+        ((double*)(smem + kLlLdsTables))[i] = gt2[h].tb_fwd[k];
+    }
+    const LinDesc d = descs[g];
+    for (int i = tid; i <= kLvl0N; i += kLlThreads) {
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit));
+        else *bbar_slot = 2 * kN - ((c + d.off) >> (32 - 1 - kNbit));
+    }
+    for (int i = tid; i < 2 * kN; i += kLlThreads) sumL[i] = 0.0;
+    __syncthreads();
+    {   // RotatedTestVector, include/gatebootstrapping_gpu.cuh:29-52
+        const uint32_t bbar = *bbar_slot;
+        for (int e = tid; e < kN; e += kLlThreads) {
+            const bool neg = (bbar != 2 * kN) && (((uint32_t)e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
+            const uint32_t v = neg ? 0u - kMu : kMu;
+            accL[e] = 0; accL[kN + e] = 0;
+            accL[2 * kN + e] = v; accL[3 * kN + e] = v;
+        }
+    }
+    __syncthreads();
+
+    const bool row_wave = wave < kLlRowWaves;
+    const int h = wave & 1;                                   // half transform of this wave (both roles)
+    const int row = wave >> 1;                                // row waves: TRGSW row = wj * l + wd
+    const int wj = row / kL, wd = row % kL;
+    const int out = (wave - kLlRowWaves) >> 1;                // inverse waves
+    const Wave512Ctx ctx = make_wave512_ctx(smem, kLlLdsTiles + wave * kTile512Bytes,
+                                            kLlLdsTables + h * kLds512TableBytes, gt2 + h, lane);
+    // Spectrum position p = 512 h + 64 lam + 8 kap + c of the full transform sits in the key
+    // layout [q = p[3:1]][lane = p[9:6] | p[5:4] << 4][p[0]]: this lane (lam = lane & 7,
+    // kap = lane >> 3) reads, for its registers c = 2 cc, 2 cc + 1, the double2 at
+    // q = 4 (kap & 1) + cc, key lane = 8 h + lam + 16 (kap >> 1).
+    const int key_idx = (4 * ((lane >> 3) & 1)) * 64 + (8 * h + (lane & 7) + 16 * (lane >> 4));
+    double2 b[8];                                             // [out][cc]
+    auto load_row = [&](int step) {
+        const double2* rowp = (const double2*)(bk_ntt + ((size_t)step * kBkRows + row) * (2 * kN));
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
+    };
+    if (row_wave && steps > 0) load_row(0);
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        if (row_wave) {
+            const char* accj = (const char*)(accL + wj * 2 * kN);
+            const int alo = (int)(abar & (kN - 1));
+            const bool ahi = (abar >> kNbit) != 0;
+            const char* rbase = accj + opaque(4 * ((lane - alo) & (kN - 1)));
+            const char* cbase = accj + opaque(4 * lane);
+            const uint32_t pos = 32 - (wd + 1) * kBgbit;
+            double x[kRegs8];
+#pragma unroll
+            for (int r = 0; r < kRegs8; r++) {
+                // digits at e = lane + 64 r and e + 512, then the first stage of the transform
+                const uint32_t rot0 = *(const uint32_t*)(rbase + 256 * r), rot1 = *(const uint32_t*)(rbase + 256 * (r + 8));
+                const uint32_t cur0 = *(const uint32_t*)(cbase + 256 * r), cur1 = *(const uint32_t*)(cbase + 256 * (r + 8));
+                const bool neg0 = (lane < alo - 64 * r) != ahi, neg1 = (lane < alo - 64 * (r + 8)) != ahi;
+                const uint32_t t0 = ((neg0 ? 0u - rot0 : rot0) - cur0 + decomp_offset()) ^ decomp_signmask();
+                const uint32_t t1 = ((neg1 ? 0u - rot1 : rot1) - cur1 + decomp_offset()) ^ decomp_signmask();
+                const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(t0, pos, (uint32_t)kBgbit);
+                const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(t1, pos, (uint32_t)kBgbit);
+                x[r] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);       // exact: |I a| < 2^30
+            }
+            ntt512_forward(x, ctx);
+            double* s0 = sumL + h * kH + lane;
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    __hip_atomic_fetch_add(s0 + o * kN + (2 * cc) * 64, fpf::mulmod_wide(x[2 * cc], b[4 * o + cc].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(s0 + o * kN + (2 * cc + 1) * 64, fpf::mulmod_wide(x[2 * cc + 1], b[4 * o + cc].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+        }
+        __syncthreads();
+        double u[kRegs8];
+        if (row_wave) {
+            if (i + 1 < steps) load_row(i + 1);               // in flight during the inverse transforms
+        } else {
+            double* s = sumL + out * kN + h * kH + lane;
+#pragma unroll
+            for (int r = 0; r < kRegs8; r++) { u[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
+            ntt512_inverse(u, ctx);                           // u_h[e], e = lane + 64 r, |u| <= p
+            double* hd = handL + out * kN + h * kH + lane;
+#pragma unroll
+            for (int r = 0; r < kRegs8; r++) hd[r * 64] = u[r];
+        }
+        __syncthreads();
+        if (!row_wave) {
+            // last inverse stage (u0, u1) -> (u0 + u1, (u0 - u1) I^-1), I^-1 = -I; wave h finishes
+            // coefficients e + 512 h
+            const double* other = handL + out * kN + (h ^ 1) * kH + lane;
+            char* acck = (char*)(accL + out * 2 * kN + h * kH) + opaque(4 * lane);
+#pragma unroll
+            for (int r = 0; r < kRegs8; r++) {
+                const double v = other[r * 64];
+                const double y = h ? fpf::mulmod(v - u[r], -fpf::ROOT4) : u[r] + v;
+                const uint32_t w = *(const uint32_t*)(acck + 256 * r) + fpf::lift_u32_small(y);
+                *(uint32_t*)(acck + 256 * r) = w;
+                *(uint32_t*)(acck + 256 * r + 4096) = w;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
+        for (int e = tid; e < kN; e += kLlThreads) { o[e] = accL[e]; o[kN + e] = accL[2 * kN + e]; }
+    }
+    if (d.out) {
+        uint32_t* o = d.out;      // __SampleExtractIndex__<P,0>
+        for (int e = tid; e < kN; e += kLlThreads) {
+            if (e == 0) { o[0] = accL[0]; o[kN] = accL[2 * kN]; }
+            else o[kN - e] = 0u - accL[e];
+        }
+    }
+}
+
+}  // namespace cufhe_amd

@@ -144,8 +144,12 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
 /* ---- tuning ----
  * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process
  * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
- * "wg_threshold": launches of at most this many blind rotations use the workgroup-per-rotation
- * kernel (lowest latency); larger ones the wave-per-rotation batch kernel (highest throughput).
+ * "ll_threshold" (default 1280): launches of at most this many blind rotations use the 16-wave
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 3.7 ms for up to 64
+ * rotations, 15.6 ms for 1024, where the batch kernel needs 20.7 ms for anything up to 2048);
+ * "wg_threshold" (default 1024): above ll_threshold and up to this many, the 8-wave
+ * workgroup-per-rotation kernel (unused with the defaults); larger launches the wave-per-rotation
+ * batch kernel (highest throughput).
  * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words.
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048

@@ -13,13 +13,17 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["batch", "wg"])
+@pytest.fixture(params=["batch", "wg", "ll"])
 def br_kernel(request, engine):
-    """Run a test once per blind-rotate kernel: wave-per-rotation (batch) and
-    workgroup-per-rotation (low latency).  Both must give the oracle's words."""
-    engine.api.set_option("wg_threshold", 0 if request.param == "batch" else 1 << 30)
-    engine.api.set_option("ks_wg_threshold", 0 if request.param == "batch" else 1 << 30)
-    yield request.param
+    """Run a test once per blind-rotate kernel: wave-per-rotation (batch), workgroup-per-rotation
+    (wg) and the 16-wave split-transform kernel (ll, lowest latency).  All must give the oracle's
+    words."""
+    which = request.param
+    engine.api.set_option("ll_threshold", 1 << 30 if which == "ll" else 0)
+    engine.api.set_option("wg_threshold", 0 if which == "batch" else 1 << 30)
+    engine.api.set_option("ks_wg_threshold", 0 if which == "batch" else 1 << 30)
+    yield which
+    engine.api.set_option("ll_threshold", 1280)
     engine.api.set_option("wg_threshold", 1024)
     engine.api.set_option("ks_wg_threshold", 128)
 
