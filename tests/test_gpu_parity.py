@@ -74,6 +74,32 @@ def test_blind_rotate_accumulator_words(engine, keys, oracle, steps, br_kernel):
         assert np.array_equal(got[g], want), f"accumulator of rotation {g} differs after {steps} steps"
 
 
+def test_blind_rotate_with_extreme_key_words(engine, keys, oracle, br_kernel):
+    """Key words of maximal magnitude (0x80000000 = -2^31 in the signed reading, 0x7FFFFFFF, 0,
+    0xFFFFFFFF): the sums then run closest to the p/2 exactness bound and the lazy residues
+    closest to their limits."""
+    rng = np.random.default_rng(17)
+    ext = np.array([0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001], np.uint32)
+    bk = ext[rng.integers(0, ext.size, ol.BK_WORDS)]
+    bk[: 2 * 6 * 2 * ol.N] = 0x80000000          # steps 0 and 1: every word -2^31
+    ek = oracle.orc_evalkey_create(bk, keys.ksk)
+    engine.Initialize(bk, keys.ksk)
+    try:
+        count, steps = 6, 12
+        tl = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+        dt = _upload(engine, tl)
+        dacc = engine.api.DeviceBuffer(count * 2 * ol.N)
+        engine.blind_rotate_batch(dt, dacc, count, steps)
+        got = dacc.download().reshape(count, 2 * ol.N)
+        for g in range(count):
+            want = np.zeros(2 * ol.N, np.uint32)
+            oracle.orc_blind_rotate(ek, want, np.ascontiguousarray(tl[g]), steps)
+            assert np.array_equal(got[g], want), f"rotation {g} differs"
+    finally:
+        oracle.orc_evalkey_destroy(ek)
+        engine.Initialize(keys.bk, keys.ksk)
+
+
 def test_keyswitch_words(engine, keys, oracle, br_kernel):
     count = 16
     rng = np.random.default_rng(5)
