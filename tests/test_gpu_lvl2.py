@@ -164,3 +164,28 @@ def test_lvl0_ring_option_routes_the_level0_api(engine2, keys, keys2):
         api.set_option("lvl0_ring", 1024)
     with pytest.raises(engine2.CufheAmdError):
         api.set_option("lvl0_ring", 512)
+
+
+def test_blind_rotate_with_extreme_key_words(engine2, keys2, oracle):
+    """64-bit key words whose limbs are maximal (-2^63, 2^63 - 1, all-ones, limb boundaries)."""
+    rng = np.random.default_rng(19)
+    ext = np.array([1 << 63, (1 << 63) - 1, 0, (1 << 64) - 1, (1 << 21), (1 << 21) - 1, (1 << 43), (1 << 43) - 1,
+                    0x8000020000200000, 0x7FFFFDFFFFDFFFFF], np.uint64)
+    bk = ext[rng.integers(0, ext.size, ol.BK2_WORDS)]
+    bk[: 2 * 8 * 2 * ol.N2] = np.uint64(1 << 63)
+    ek = oracle.orc2_evalkey_create(bk, keys2.ksk)
+    engine2.lvl2_initialize(bk, keys2.ksk)
+    try:
+        count, steps = 4, 10
+        tl = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+        dt = _upload(engine2, tl)
+        dacc = engine2.api.DeviceBuffer(count * 2 * ol.N2 * 2)
+        engine2.lvl2_blind_rotate_batch(dt, dacc, count, steps)
+        got = dacc.download().view(np.uint64).reshape(count, 2 * ol.N2)
+        for g in range(count):
+            want = np.zeros(2 * ol.N2, np.uint64)
+            oracle.orc2_blind_rotate(ek, want, np.ascontiguousarray(tl[g]), steps)
+            assert np.array_equal(got[g], want), f"rotation {g} differs"
+    finally:
+        oracle.orc2_evalkey_destroy(ek)
+        engine2.lvl2_initialize(keys2.bk, keys2.ksk)
