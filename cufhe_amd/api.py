@@ -229,6 +229,11 @@ def blind_rotate_batch(tlwe0, acc, count, steps=-1, device=0, stream=None):
     check(lib.cufhe_amd_blind_rotate_batch(device, stream, count, tlwe0.ptr, acc.ptr, steps))
 
 
+def bootstrap_batch(out, inp, count, device=0, stream=None):
+    """Bootstrap (src/bootstrap_gpu.cu:782-788): refresh `count` lvl0 ciphertexts."""
+    check(lib.cufhe_amd_bootstrap_batch(device, stream, count, out.ptr, inp.ptr))
+
+
 def keyswitch_batch(tlwe1, tlwe0, count, device=0, stream=None):
     check(lib.cufhe_amd_keyswitch_batch(device, stream, count, tlwe1.ptr, tlwe0.ptr))
 

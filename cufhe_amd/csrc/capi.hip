@@ -685,6 +685,30 @@ int cufhe_amd_gate_list(int device, void* stream, int level, size_t count, const
     });
 }
 
+int cufhe_amd_bootstrap_batch(int device, void* stream, size_t count, uint32_t* out, const uint32_t* in)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!out || !in) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    Scratch sc;
+    if (int rc = open_scratch(s, st, count * (kLvl1Words * sizeof(uint32_t) + 2 * sizeof(LinDesc)) + 8192, &sc)) return rc;
+    uint32_t* t1;
+    if (int rc = sc.alloc((void**)&t1, count * kLvl1Words * sizeof(uint32_t))) return rc;
+    std::vector<LinDesc> rot(count), ks(count);
+    for (size_t g = 0; g < count; g++) {
+        rot[g] = {in + g * kLvl0Words, in + g * kLvl0Words, t1 + g * kLvl1Words, 1, 0, 0u, 0u};
+        ks[g] = {t1 + g * kLvl1Words, t1 + g * kLvl1Words, out + g * kLvl0Words, 1, 0, 0u, 0u};
+    }
+    LinDesc *drot, *dks;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = launch_blind_rotate(s, st, drot, count, kLvl0N, nullptr)) return rc;
+    return launch_keyswitch(s, st, dks, count);
+}
+
 int cufhe_amd_blind_rotate_batch(int device, void* stream, size_t count, const uint32_t* tlwe0, uint32_t* acc, int steps)
 {
     if (int rc = use_device(device)) return rc;

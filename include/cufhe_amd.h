@@ -118,6 +118,9 @@ int cufhe_amd_sched_stream_query(int device, void* stream);  /* scheduler half o
  * after `steps` CMux steps (steps < 0: all n); also the accumulator parity hook. */
 int cufhe_amd_blind_rotate_batch(int device, void* stream, size_t count, const uint32_t* tlwe0,
                                  uint32_t* acc, int steps);
+/* Bootstrap (src/bootstrap_gpu.cu:290-301,782-788): refresh lvl0 TLWEs without a gate,
+ * in[count][n+1] -> blind rotate (test vector mu = lvl1 mu) -> extract -> key switch -> out[count][n+1] */
+int cufhe_amd_bootstrap_batch(int device, void* stream, size_t count, uint32_t* out, const uint32_t* in);
 /* SEIandKS (src/keyswitch_gpu.cu:26-40) on already extracted lvl1 TLWEs:
  * tlwe1[count][N+1] -> tlwe0[count][n+1] */
 int cufhe_amd_keyswitch_batch(int device, void* stream, size_t count, const uint32_t* tlwe1,

@@ -118,6 +118,14 @@ inline void GateBatch(int op, size_t count, uint32_t* out, const uint32_t* in0, 
 }
 }  // namespace lvl2
 
+/// Bootstrap(out, in, mu, st, gpuNum) of include/bootstrap_gpu.cuh:64-65 on device pointers
+/// (lvl0 TLWE in, refreshed lvl0 TLWE out); mu must be lvl1param::mu, the only test vector built in
+inline void Bootstrap(uint32_t* out, const uint32_t* in, uint32_t mu, void* st, int gpuNum)
+{
+    if (mu != TFHEpp::lvl1param::μ) { std::fprintf(stderr, "Bootstrap: unsupported mu\n"); std::exit(-1); }
+    CUFHE_AMD_CHECK(cufhe_amd_bootstrap_batch(gpuNum, st, 1, out, in));
+}
+
 /// class Stream, include/cufhe_gpu.cuh:152-189 (passed by value, never auto-destroyed)
 class Stream {
    public:

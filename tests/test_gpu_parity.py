@@ -272,6 +272,26 @@ def test_cpp_gate_api_mirror(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+def test_plain_bootstrap(engine, keys, oracle, br_kernel):
+    """Bootstrap (src/bootstrap_gpu.cu:290-301): blind rotate -> extract -> key switch of one TLWE."""
+    rng = np.random.default_rng(31)
+    bits = rng.integers(0, 2, 12).astype(np.uint8)
+    cts = keys.encrypt(bits, 0, seed=909)
+    din = _upload(engine, cts)
+    dout = engine.api.DeviceBuffer(cts.size)
+    engine.bootstrap_batch(dout, din, len(bits))
+    got = dout.download().reshape(len(bits), -1)
+    for g in range(len(bits)):
+        acc = np.zeros(2 * ol.N, np.uint32)
+        oracle.orc_blind_rotate(keys.ek, acc, np.ascontiguousarray(cts[g]), -1)
+        t1 = np.zeros(ol.N + 1, np.uint32)
+        oracle.orc_sample_extract0(t1, acc)
+        t0 = np.zeros(ol.n + 1, np.uint32)
+        oracle.orc_keyswitch(keys.ek, t0, t1)
+        assert np.array_equal(got[g], t0)
+    assert np.array_equal(keys.decrypt(got, 0), bits)
+
+
 def test_cpp_legacy_manual_program(engine):
     """tests/cpp/test_legacy_api.cpp: the reference's user-manual program (README.md:46-82,
     test/test_api_gpu.cu) -- KeyGen, Encrypt, Initialize(pub_key), nine chained in-place gates on
