@@ -294,6 +294,10 @@ def lvl2_keyswitch_batch(tlwe2, tlwe0, count, device=0, stream=None):
     check(lib.cufhe_amd_lvl2_keyswitch_batch(device, stream, count, tlwe2.ptr, tlwe0.ptr))
 
 
+def polymul512_batch(a, b, res, count, device=0, stream=None):
+    check(lib.cufhe_amd_polymul512_batch(device, stream, count, a.ptr, b.ptr, res.ptr))
+
+
 def set_option(key, value):
     check(lib.cufhe_amd_set_option(key.encode(), int(value)))
 

@@ -50,7 +50,7 @@ struct Workspace { char* base = nullptr; size_t bytes = 0; };
 struct DeviceState {
     bool ntt_ready = false, keys_ready = false;
     NttTables* tables = nullptr;
-    Ntt512Tables* tables512 = nullptr;   // [2]: the two 512-point halves (low-latency kernel)
+    Ntt512Tables* tables512 = nullptr;   // [3]: the two 512-point halves (low-latency kernel), stand-alone N = 512
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
     bool profiling = false;
@@ -136,8 +136,35 @@ void build_tables(NttTables& t)
     fill_tables(t, fwd, inv);
 }
 
-// the two 512-point halves of the same transform: root_h[m + g] = root[2m + h m + g]
-void build_tables_512(Ntt512Tables (&t)[2])
+// Tables of one 512-point transform from accessors rf(idx) / ri(idx) = forward / inverse twiddle of
+// group g at the stage with m groups, idx = m + g.
+template <class RF, class RI>
+void fill_tables_512(Ntt512Tables& t, RF rf, RI ri)
+{
+    memset(&t, 0, sizeof(t));
+    for (int k = 0; k < 7; k++) {
+        int lvl = 0;
+        while ((2 << lvl) <= k + 1) lvl++;
+        const int j = k + 1 - (1 << lvl);
+        t.tu_fwd[k] = rf((1 << lvl) + j);
+        t.tu_inv[k] = ri((1 << lvl) + j);
+        for (int lam = 0; lam < 8; lam++) {
+            const int idx = (8 << lvl) + (lam << lvl) + j;
+            t.tb_fwd[k * 8 + lam] = rf(idx);
+            t.tb_inv[k * 8 + lam] = ri(idx);
+        }
+        for (int lane = 0; lane < 64; lane++) {
+            const int mu = 8 * (lane & 7) + (lane >> 3);
+            const int idx = (64 << lvl) + (mu << lvl) + j;
+            t.tc_fwd[k * 64 + lane] = rf(idx);
+            t.tc_inv[k * 64 + lane] = ri(idx);
+        }
+    }
+}
+
+// t[0], t[1]: the two 512-point halves of the 1024-point transform, root_h[m + g] = root[2m + h m + g];
+// t[2]: the stand-alone 512-point negacyclic transform (psi_1024 = psi_2048^2)
+void build_tables_512(Ntt512Tables (&t)[3])
 {
     std::vector<double> fwd(kN), inv(kN);
     const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
@@ -145,29 +172,13 @@ void build_tables_512(Ntt512Tables (&t)[2])
         fwd[i] = balanced(powmod_u64(psi, bitrev(i, 10)));
         inv[i] = balanced(powmod_u64(psi_inv, bitrev(i, 10)));
     }
-    for (int h = 0; h < 2; h++) {
-        memset(&t[h], 0, sizeof(t[h]));
-        auto rf = [&](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return fwd[2 * m + h * m + (idx - m)]; };
-        auto ri = [&](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return inv[2 * m + h * m + (idx - m)]; };
-        for (int k = 0; k < 7; k++) {
-            int lvl = 0;
-            while ((2 << lvl) <= k + 1) lvl++;
-            const int j = k + 1 - (1 << lvl);
-            t[h].tu_fwd[k] = rf((1 << lvl) + j);
-            t[h].tu_inv[k] = ri((1 << lvl) + j);
-            for (int lam = 0; lam < 8; lam++) {
-                const int idx = (8 << lvl) + (lam << lvl) + j;
-                t[h].tb_fwd[k * 8 + lam] = rf(idx);
-                t[h].tb_inv[k * 8 + lam] = ri(idx);
-            }
-            for (int lane = 0; lane < 64; lane++) {
-                const int mu = 8 * (lane & 7) + (lane >> 3);
-                const int idx = (64 << lvl) + (mu << lvl) + j;
-                t[h].tc_fwd[k * 64 + lane] = rf(idx);
-                t[h].tc_inv[k * 64 + lane] = ri(idx);
-            }
-        }
-    }
+    auto top = [](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return m; };
+    for (int h = 0; h < 2; h++)
+        fill_tables_512(t[h], [&](int idx) { const int m = top(idx); return fwd[2 * m + h * m + (idx - m)]; },
+                        [&](int idx) { const int m = top(idx); return inv[2 * m + h * m + (idx - m)]; });
+    const uint64_t psi2 = mulmod_u64(psi, psi), psi2_inv = powmod_u64(psi2, fpf::P_U64 - 2);
+    fill_tables_512(t[2], [&](int idx) { return balanced(powmod_u64(psi2, bitrev((uint32_t)idx, 9))); },
+                    [&](int idx) { return balanced(powmod_u64(psi2_inv, bitrev((uint32_t)idx, 9))); });
 }
 
 int check_device(int device)
@@ -191,7 +202,7 @@ int ensure_ntt(int device)
     build_tables(host);
     HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
     HIP_TRY(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
-    static Ntt512Tables host512[2];
+    static Ntt512Tables host512[3];
     build_tables_512(host512);
     HIP_TRY(hipMalloc((void**)&s.tables512, sizeof(host512)));
     HIP_TRY(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
@@ -837,6 +848,21 @@ int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_
     const unsigned blocks = (unsigned)((count + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
     hipLaunchKernelGGL(polymul_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, (hipStream_t)stream, res, a, b,
                        (int)count, g_dev[device].tables, n_inverse_balanced());
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int32_t* a, const uint32_t* b, uint32_t* res)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (count == 0) return 0;
+    const unsigned blocks = (unsigned)((count + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(polymul512_kernel, dim3(blocks), dim3(kNttThreads), kPoly512LdsBytes, (hipStream_t)stream, res, a, b,
+                       (int)count, g_dev[device].tables512 + 2, balanced(powmod_u64(kH, fpf::P_U64 - 2)));
     HIP_TRY(hipGetLastError());
     return 0;
 }

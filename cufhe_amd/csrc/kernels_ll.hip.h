@@ -168,4 +168,41 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     }
 }
 
+// ----------------------------------------------------------------------------------
+// res = a (signed small) * b (torus) mod (X^512 + 1, 2^32), one wave per product: the
+// stand-alone 512-point negacyclic transform (the reference's SmallForwardNTT_512 /
+// SmallInverseNTT_512, include/ntt_gpu/ntt_gpuntt.cuh:283-329,394-440) -- the same wave code as
+// a half transform, with the table of psi_1024 = psi_2048^2.  Parity hook.
+// ----------------------------------------------------------------------------------
+constexpr int kPoly512LdsBytes = kLds512TableBytes + kNttWavesPerBlock * kTile512Bytes;
+
+__global__ __launch_bounds__(kNttThreads) void polymul512_kernel(
+    uint32_t* __restrict__ res, const int32_t* __restrict__ a, const uint32_t* __restrict__ b,
+    int count, const Ntt512Tables* __restrict__ gt, double n_inverse)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < kLds512TableDoubles; i += kNttThreads) ((double*)smem)[i] = gt->tb_fwd[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
+    if (g >= count) return;
+    const Wave512Ctx ctx = make_wave512_ctx(smem, kLds512TableBytes + wave * kTile512Bytes, 0, gt, lane);
+    double x[kRegs8], y[kRegs8];
+#pragma unroll
+    for (int r = 0; r < kRegs8; r++) {
+        x[r] = (double)a[(size_t)g * kH + lane + 64 * r];
+        y[r] = (double)(int32_t)b[(size_t)g * kH + lane + 64 * r];
+    }
+    ntt512_forward(x, ctx);
+    ntt512_forward(y, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs8; r++) {
+        y[r] = fpf::reduce(fpf::mulmod_wide(y[r], n_inverse));
+        x[r] = fpf::reduce(fpf::mulmod_wide(x[r], y[r]));
+    }
+    ntt512_inverse(x, ctx);
+#pragma unroll
+    for (int r = 0; r < kRegs8; r++) res[(size_t)g * kH + lane + 64 * r] = fpf::lift_u32(x[r]);
+}
+
 }  // namespace cufhe_amd

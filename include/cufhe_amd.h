@@ -143,6 +143,10 @@ int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* t
  * a signed with |a| <= 128 (exactness bound of the field), all [count][N], device. */
 int cufhe_amd_polymul_batch(int device, void* stream, size_t count, const int32_t* a,
                             const uint32_t* b, uint32_t* res);
+/* the same check for the 512-point transform (SmallForwardNTT_512 / SmallInverseNTT_512,
+ * include/ntt_gpu/ntt_gpuntt.cuh:283-329): res = a * b mod (X^512 + 1, 2^32), operands [count][512] */
+int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int32_t* a,
+                               const uint32_t* b, uint32_t* res);
 
 /* ---- tuning ----
  * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process

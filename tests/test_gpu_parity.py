@@ -54,6 +54,26 @@ def test_polymul_matches_schoolbook_and_oracle_ntt(engine, oracle):
         assert np.array_equal(want, want2)
 
 
+def test_polymul512_matches_schoolbook(engine):
+    """The stand-alone 512-point transform (the wave code behind the low-latency kernel's half
+    transforms) against a schoolbook negacyclic product mod (X^512 + 1, 2^32)."""
+    rng = np.random.default_rng(8)
+    count, n = 40, 512
+    a = rng.integers(-128, 129, size=(count, n), dtype=np.int32)
+    a[0] = 128; a[1] = -128
+    b = rng.integers(0, 2**32, size=(count, n), dtype=np.uint64).astype(np.uint32)
+    b[0] = 0x80000000; b[1] = 0x7FFFFFFF; b[2] = 0
+    da, db = _upload(engine, a.view(np.uint32)), _upload(engine, b)
+    dres = engine.api.DeviceBuffer(count * n)
+    engine.polymul512_batch(da, db, dres, count)
+    got = dres.download().reshape(count, n)
+    for g in range(count):
+        full = np.convolve(a[g].astype(np.int64), b[g].astype(np.int32).astype(np.int64))   # |sum| < 2^48: exact
+        full = np.concatenate([full, np.zeros(2 * n - full.size, np.int64)])
+        want = ((full[:n] - full[n:]) & 0xFFFFFFFF).astype(np.uint32)
+        assert np.array_equal(got[g], want), f"product {g}"
+
+
 @pytest.mark.parametrize("steps", [0, 1, 2, 3, 64, 65, 630])
 def test_blind_rotate_accumulator_words(engine, keys, oracle, steps, br_kernel):
     count = 6 if steps == 630 else 10
