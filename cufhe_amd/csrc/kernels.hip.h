@@ -137,15 +137,18 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
     const bool ahi = (abar >> kNbit) != 0;
     char* wpos = tile + opaque(4 * lane + (ahi ? 0 : 4 * kN));      // where +acc goes
     char* wneg = tile + opaque(4 * lane + (ahi ? 4 * kN : 0));      // where -acc goes
+    asm volatile("" ::: "memory");      // compiler-only fences: the opaque bases below alias (see CUFHE_AMD_XPOSE)
 #pragma unroll
     for (int r = 0; r < kRegs; r++) {
         *(uint32_t*)(wpos + 256 * r) = acc[r];
         *(uint32_t*)(wneg + 256 * r) = 0u - acc[r];
     }
+    asm volatile("" ::: "memory");
     const char* rbase = tile + opaque(4 * (lane - alo + kN));
     uint32_t rot[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);   // all reads in flight together
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int r = 0; r < kRegs; r++) temp[r] = (rot[r] - acc[r] + decomp_offset()) ^ decomp_signmask();
 }
