@@ -108,3 +108,25 @@ def check(rc):
     if rc < 0:
         raise CufheAmdError(f"cufhe_amd error {rc}: {lib.cufhe_amd_last_error().decode()}")
     return rc
+
+
+# Deterministic teardown: release the library's device state while the interpreter and the HIP
+# runtime are both still fully alive, and turn the __del__ hooks of objects collected later
+# (DeviceBuffer, Ctxt) into no-ops instead of letting them call into a half-finalised process.
+closed = False
+
+
+def _shutdown():
+    global closed
+    if closed:
+        return
+    closed = True
+    try:
+        lib.cufhe_amd_cleanup()
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_shutdown)

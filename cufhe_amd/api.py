@@ -10,6 +10,7 @@ import ctypes
 
 import numpy as np
 
+from . import _lib
 from ._lib import lib, check, Params, Profile, Lvl2Params
 
 # op codes (include/cufhe_amd.h)
@@ -115,9 +116,9 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and not _lib.closed:
             check(lib.cufhe_amd_free(self.device, self.ptr))
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -144,9 +145,9 @@ class Ctxt:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and not _lib.closed:
                 lib.cufhe_amd_ctxt_destroy(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 

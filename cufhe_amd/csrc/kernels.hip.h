@@ -148,7 +148,6 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
     uint32_t rot[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);   // all reads in flight together
-    asm volatile("" ::: "memory");
 #pragma unroll
     for (int r = 0; r < kRegs; r++) temp[r] = (rot[r] - acc[r] + decomp_offset()) ^ decomp_signmask();
 }

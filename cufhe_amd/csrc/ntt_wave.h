@@ -216,7 +216,7 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
 #ifdef CUFHE_AMD_ABL_NO_XPOSE
 #define CUFHE_AMD_XPOSE(WBASE, WSTRIDE, RBASE, RSTRIDE) { asm volatile("" ::: "memory"); }
 #else
-// The two compiler fences keep the tile accesses of consecutive layout changes in program
+// The compiler fence keeps the tile accesses of consecutive layout changes in program
 // order: the per-lane base pointers are opaque on purpose, so hipcc cannot see that they address
 // the same tile and may otherwise hoist the stores of an independent later transform above the
 // loads of an earlier one (observed with two back-to-back 512-point transforms).
@@ -225,7 +225,6 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
         asm volatile("" ::: "memory");                                               \
         _Pragma("unroll") for (int r = 0; r < kRegs; r++) lds_st(WBASE, (WSTRIDE) * r, x[r]); \
         _Pragma("unroll") for (int r = 0; r < kRegs; r++) x[r] = lds_ld(RBASE, (RSTRIDE) * r); \
-        asm volatile("" ::: "memory");                                               \
     }
 #endif
 

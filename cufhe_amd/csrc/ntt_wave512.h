@@ -117,7 +117,7 @@ __device__ __forceinline__ void gs_three_stages(double (&x)[kRegs8], const TW& t
     }
 }
 
-// The compiler fences keep the tile accesses of consecutive layout changes in program order
+// The compiler fence keeps the tile accesses of consecutive layout changes in program order
 // (the hardware executes one wave's DS operations in order, but hipcc is free to hoist the
 // stores of an independent later transform above the loads of an earlier one: it does not see
 // that the per-lane base pointers, made opaque on purpose, address the same tile).
@@ -126,7 +126,6 @@ __device__ __forceinline__ void gs_three_stages(double (&x)[kRegs8], const TW& t
         asm volatile("" ::: "memory");                                                  \
         _Pragma("unroll") for (int r = 0; r < kRegs8; r++) lds_st(WBASE, (WSTRIDE) * r, x[r]); \
         _Pragma("unroll") for (int r = 0; r < kRegs8; r++) x[r] = lds_ld(RBASE, (RSTRIDE) * r); \
-        asm volatile("" ::: "memory");                                                  \
     }
 
 // forward half transform: x = u_h in layout A (|x| far below p), out in layout C, |out| <= 7.22 p
