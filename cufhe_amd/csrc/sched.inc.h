@@ -267,7 +267,7 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
     if (!c) return 0;
     std::lock_guard<std::mutex> lk(g_sched_mu);
     bool busy = false;
-    for (size_t d = 0; d < c->dev.size(); d++) busy = busy || c->write_batch[d] || c->read_batch[d];
+    for (size_t d = 0; d < c->dev.size(); d++) busy = busy || c->write_batch[d] || c->read_batch[d] || c->upload_batch[d];
     if (busy && sched_active()) (void)sched_synchronize_all();
     for (size_t d = 0; d < c->dev.size(); d++)
         if (c->dev[d]) { (void)hipSetDevice((int)d + g_device_base); (void)hipFree(c->dev[d]); }
