@@ -110,23 +110,30 @@ def check(rc):
     return rc
 
 
-# Deterministic teardown: release the library's device state while the interpreter and the HIP
-# runtime are both still fully alive, and turn the __del__ hooks of objects collected later
-# (DeviceBuffer, Ctxt) into no-ops instead of letting them call into a half-finalised process.
+# Deterministic teardown: at interpreter exit, while Python and the HIP runtime are both still fully
+# alive, release every live Ctxt / DeviceBuffer (unpinning the host memory the ciphertexts
+# registered) and the library's device state; __del__ hooks that run later are no-ops.
+import atexit  # noqa: E402
+import weakref  # noqa: E402
+
 closed = False
+live = weakref.WeakSet()        # objects with a release() method (api.Ctxt, api.DeviceBuffer)
 
 
 def _shutdown():
     global closed
     if closed:
         return
+    for obj in list(live):
+        try:
+            obj.release()
+        except Exception:
+            pass
     closed = True
     try:
         lib.cufhe_amd_cleanup()
     except Exception:
         pass
 
-
-import atexit  # noqa: E402
 
 atexit.register(_shutdown)

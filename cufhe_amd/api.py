@@ -101,6 +101,7 @@ class DeviceBuffer:
         p = ctypes.c_void_p()
         check(lib.cufhe_amd_malloc(self.device, self.words * 4, ctypes.byref(p)))
         self.ptr = p.value
+        _lib.live.add(self)
 
     def upload(self, host, stream=None):
         host = np.ascontiguousarray(host, dtype=np.uint32).ravel()
@@ -120,6 +121,8 @@ class DeviceBuffer:
             check(lib.cufhe_amd_free(self.device, self.ptr))
         self.ptr = None
 
+    release = free
+
     def __del__(self):
         try:
             self.free()
@@ -138,16 +141,20 @@ class Ctxt:
         h = ctypes.c_void_p()
         check(lib.cufhe_amd_ctxt_create(self.level, _ptr(self.tlwehost), ctypes.byref(h)))
         self._h = h
+        _lib.live.add(self)
 
     @property
     def tlwedevices(self):
         return [lib.cufhe_amd_ctxt_device_ptr(self._h, d) for d in range(GetGPUNum())]
 
+    def release(self):
+        if self._h and not _lib.closed:
+            lib.cufhe_amd_ctxt_destroy(self._h)
+        self._h = None
+
     def __del__(self):
         try:
-            if self._h and not _lib.closed:
-                lib.cufhe_amd_ctxt_destroy(self._h)
-            self._h = None
+            self.release()
         except Exception:
             pass
 
