@@ -208,5 +208,85 @@ void hm_external_product(uint32_t* out, const int32_t* dig, const uint32_t* bk, 
     if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
 }
 
+// The same external product with the schedule of the low-latency kernel
+// (cufhe_amd/csrc/ntt_wave512.h, kernels_ll.hip.h): exact first stage u_h = a[e] +- I a[e+512],
+// two 512-point half transforms (stages 1..8 narrow, stage 9 wide), six wide products per sum,
+// reduce, half inverses (s9 s8 s7 | s6 wide, reduce, s5 s4 | s3, s2 wide, reduce, s1), last stage
+// (u0 + u1, (u0 - u1)(-I)), lift_u32_small.  stats as above.
+void hm_external_product_split(uint32_t* out, const int32_t* dig, const uint32_t* bk, double* stats)
+{
+    tables();
+    Track t;
+    constexpr int H = N / 2;
+    std::vector<double> A0(N, 0.0), A1(N, 0.0), x(N), y0(N), y1(N);
+    for (int row = 0; row < 6; row++) {
+        for (int i = 0; i < N; i++) {
+            y0[i] = (double)(int32_t)bk[(row * 2 + 0) * N + i];
+            y1[i] = (double)(int32_t)bk[(row * 2 + 1) * N + i];
+        }
+        fwd(y0.data(), t, nullptr, false); fwd(y1.data(), t, nullptr, false);   // key conversion: full transform
+        if (g_fwd[1] != fpf::ROOT4) t.bad++;
+        for (int e = 0; e < H; e++) {                                           // first stage, exact
+            const double a = (double)dig[row * N + e], b = (double)dig[row * N + e + H];
+            x[e] = __builtin_fma(b, fpf::ROOT4, a);
+            x[e + H] = __builtin_fma(-b, fpf::ROOT4, a);
+            t.val(x[e]); t.val(x[e + H]);
+        }
+        for (int h = 0; h < 2; h++) {                                           // stages 1..9 of half h
+            double* xh = x.data() + h * H;
+            int tt = H >> 1, s = 1;
+            for (int m = 1; m < H; m <<= 1, tt >>= 1, s++)
+                for (int g = 0; g < m; g++) {
+                    const double w = g_fwd[2 * m + h * m + g];
+                    double* a = xh + 2 * g * tt;
+                    for (int j = 0; j < tt; j++) {
+                        const double u = a[j], v = mm(a[j + tt], w, s == 9, t);
+                        a[j] = u + v; a[j + tt] = u - v;
+                        t.val(a[j]); t.val(a[j + tt]);
+                    }
+                }
+        }
+        for (int i = 0; i < N; i++) {
+            y0[i] = fpf::reduce(mm(y0[i], g_ninv, true, t));
+            y1[i] = fpf::reduce(mm(y1[i], g_ninv, true, t));
+            A0[i] += mm(x[i], y0[i], true, t); t.val(A0[i]);
+            A1[i] += mm(x[i], y1[i], true, t); t.val(A1[i]);
+        }
+    }
+    for (int o = 0; o < 2; o++) {
+        std::vector<double>& A = o ? A1 : A0;
+        for (int i = 0; i < N; i++) A[i] = fpf::reduce(A[i]);
+        for (int h = 0; h < 2; h++) {
+            double* xh = A.data() + h * H;
+            int tt = 1, s = 9;
+            for (int m = H >> 1; m >= 1; m >>= 1, tt <<= 1, s--) {
+                const bool wide = (s == 6 || s == 2);
+                for (int g = 0; g < m; g++) {
+                    const double w = g_inv[2 * m + h * m + g];
+                    double* a = xh + 2 * g * tt;
+                    for (int j = 0; j < tt; j++) {
+                        const double u = a[j], v = a[j + tt];
+                        a[j] = u + v; t.val(a[j]);
+                        const double d = u - v; t.val(d);
+                        a[j + tt] = mm(d, w, wide, t);
+                    }
+                }
+                if (wide) for (int i = 0; i < H; i++) { xh[i] = fpf::reduce(xh[i]); t.val(xh[i]); }
+            }
+        }
+        if (g_inv[1] != -fpf::ROOT4) t.bad++;
+        for (int e = 0; e < H; e++) {
+            const double u0 = A[e], u1 = A[e + H];
+            const double lo = u0 + u1; t.val(lo);
+            const double d = u0 - u1; t.val(d);
+            const double hi = mm(d, -fpf::ROOT4, false, t);
+            if (std::fabs(lo) >= 2251799813685248.0 || std::fabs(hi) >= 2251799813685248.0) t.bad++;   // lift_u32_small domain
+            out[o * N + e] = fpf::lift_u32_small(lo);
+            out[o * N + e + H] = fpf::lift_u32_small(hi);
+        }
+    }
+    if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
+}
+
 double hm_p(void) { return fpf::P; }
 }

@@ -32,6 +32,7 @@ def hm():
     i32 = np.ctypeslib.ndpointer(np.int32, flags="C")
     L.hm_polymul.argtypes = [u32, i32, u32, f64]
     L.hm_external_product.argtypes = [u32, i32, u32, f64]
+    L.hm_external_product_split.argtypes = [u32, i32, u32, f64]
     L.hm_p.restype = ctypes.c_double
     return L
 
@@ -125,3 +126,26 @@ def test_external_product_random(hm, oracle):
             for row in range(6):
                 want += _school(oracle, dig[row], bk[row, c])
             assert np.array_equal(out[c * ol.N:(c + 1) * ol.N], want)
+
+
+def test_split_transform_schedule(hm, oracle):
+    """The schedule of the low-latency kernel (two 512-point halves per transform,
+    ntt_wave512.h): same words as the plain schedule, every intermediate an exact integer inside
+    its documented range -- for the worst case and for random inputs."""
+    rng = np.random.default_rng(10)
+    cases = [(np.full((6, ol.N), -32, np.int32), np.full((6, 2, ol.N), 0x80000000, np.uint32))]
+    for _ in range(3):
+        cases.append((rng.integers(-32, 32, size=(6, ol.N), dtype=np.int32),
+                      rng.integers(0, 2**32, size=(6, 2, ol.N), dtype=np.uint64).astype(np.uint32)))
+    for dig, bk in cases:
+        out = np.zeros(2 * ol.N, np.uint32)
+        ref = np.zeros(2 * ol.N, np.uint32)
+        st = np.zeros(4)
+        hm.hm_external_product_split(out, dig.ravel(), bk.ravel(), st)
+        hm.hm_external_product(ref, dig.ravel(), bk.ravel(), np.zeros(4))
+        assert st[0] == 0 and st[1] < 10.285 and st[2] < 5.142 and st[3] < 10.285, st
+        assert np.array_equal(out, ref)
+        want = np.zeros(ol.N, np.uint32)
+        for row in range(6):
+            want += _school(oracle, dig[row], bk[row, 0])
+        assert np.array_equal(out[:ol.N], want)
