@@ -70,6 +70,7 @@ struct DeviceState {
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
+long g_ks_split_threshold = 32; // key switches per launch up to which each ciphertext is split over 8 workgroups
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ll_threshold = 1280;    // rotations per launch up to which the 16-wave split-transform kernel is used (5 rounds of 256 workgroups = one batch-kernel launch)
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
@@ -324,7 +325,10 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
         s.ks_lds_opt_in = true;
     }
-    if ((long)count <= g_ks_wg_threshold) {
+    if ((long)count <= g_ks_split_threshold) {
+        hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
+        hipLaunchKernelGGL(keyswitch_split_kernel, dim3((unsigned)count * kKsSplit), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
+    } else if ((long)count <= g_ks_wg_threshold) {
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
         const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
@@ -880,6 +884,7 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
+    if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
     if (!strcmp(key, "lvl0_ring")) {
         if (value != 1024 && value != 2048) return fail(-1, "lvl0_ring must be 1024 or 2048");
         g_lvl0_ring = value;

@@ -690,6 +690,86 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_wg_kernel(
     }
 }
 
+// Lowest-latency key switch for a handful of ciphertexts: kKsSplit workgroups per ciphertext, each
+// taking 128 values of j (8 per wave) and adding its partial sum into the output with 32-bit
+// atomics (sums mod 2^32 are order-free: same words).  The output is zeroed by
+// keyswitch_split_zero_kernel first; the workgroup of j = 0 adds b'.
+constexpr int kKsSplit = 8;
+__global__ __launch_bounds__(256) void keyswitch_split_zero_kernel(const LinDesc* __restrict__ descs, int count)
+{
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    uint32_t* out = descs[g].out;
+    for (int i = threadIdx.x; i <= kLvl0N; i += blockDim.x) out[i] = 0u;
+}
+__global__ __launch_bounds__(kKsThreads) void keyswitch_split_kernel(
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
+{
+    __shared__ uint32_t part[kKsWaves][kKsRowPad];
+    __shared__ uint16_t dig[kN / kKsSplit];
+    const int g = blockIdx.x / kKsSplit, sp = blockIdx.x % kKsSplit;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const LinDesc d = descs[g];
+    uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
+    for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
+    constexpr int kJ = kN / kKsSplit;                          // 128 values of j per workgroup
+    const int j0 = sp * kJ;
+    if (tid < kJ) {
+        const uint32_t v = (uint32_t)d.ca * d.in0[j0 + tid] + (uint32_t)d.cb * d.in1[j0 + tid];
+        dig[tid] = (uint16_t)((v + koff) >> 16);
+    }
+    __syncthreads();
+    int piece[kKsPieces];
+    piece[0] = lane; piece[1] = lane + 64; piece[2] = lane < 32 ? lane + 128 : 159;
+    uint4 res[kKsPieces];
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
+    const uint4* base = (const uint4*)ksk_padded;
+    constexpr int kRowPieces = kKsRowPad / 4;
+#pragma unroll 1
+    for (int jj = 0; jj < kJ / kKsWaves; jj++) {
+        const int jl = wave * (kJ / kKsWaves) + jj;
+        const int j = j0 + jl;
+        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[jl]);
+        int val[kKsT];
+        uint4 row[kKsT][kKsPieces];
+#pragma unroll
+        for (int k = 0; k < kKsT; k++) {
+            val[k] = (int)((dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1)) - (1 << (kKsBasebit - 1));
+            const int v = val[k] > 0 ? val[k] : -val[k];
+            const uint4* r = base + ((size_t)(j * kKsT + k) * kKsNumBase + (v ? v - 1 : 0)) * kRowPieces;
+#pragma unroll
+            for (int m = 0; m < kKsPieces; m++) row[k][m] = r[piece[m]];
+        }
+#pragma unroll
+        for (int k = 0; k < kKsT; k++) {
+            if (val[k] > 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x -= row[k][m].x; res[m].y -= row[k][m].y; res[m].z -= row[k][m].z; res[m].w -= row[k][m].w; }
+            } else if (val[k] < 0) {
+#pragma unroll
+                for (int m = 0; m < kKsPieces; m++) { res[m].x += row[k][m].x; res[m].y += row[k][m].y; res[m].z += row[k][m].z; res[m].w += row[k][m].w; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kKsPieces; m++) {
+        if (m == 2 && lane >= 32) break;
+        *(uint4*)&part[wave][4 * piece[m]] = res[m];
+    }
+    __syncthreads();
+    for (int i = tid; i <= kLvl0N; i += kKsThreads) {
+        uint32_t v = 0u;
+        if (i == kLvl0N && sp == 0) v = (uint32_t)d.ca * d.in0[kN] + (uint32_t)d.cb * d.in1[kN] + d.off;
+#pragma unroll
+        for (int w = 0; w < kKsWaves; w++) v += part[w][i];
+        atomicAdd(d.out + i, v);
+    }
+}
+
 // __SampleExtractIndex__<P,0> on TRLWEs in global memory: trlwe[count][2N] -> tlwe1[count][N+1]
 __global__ __launch_bounds__(256) void sample_extract_kernel(uint32_t* __restrict__ tlwe1,
                                                              const uint32_t* __restrict__ trlwe, int count)

@@ -152,12 +152,15 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process
  * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
  * "ll_threshold" (default 1280): launches of at most this many blind rotations use the 16-wave
- * workgroup-per-rotation kernel with split transforms (lowest latency: 3.7 ms for up to 64
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 3.5 ms for up to 64
  * rotations, 15.6 ms for 1024, where the batch kernel needs 20.7 ms for anything up to 2048);
  * "wg_threshold" (default 1024): above ll_threshold and up to this many, the 8-wave
  * workgroup-per-rotation kernel (unused with the defaults); larger launches the wave-per-rotation
  * batch kernel (highest throughput).
- * "ks_wg_threshold": the same choice for the key switch.  All variants produce identical words.
+ * "ks_wg_threshold" (default 128) / "ks_split_threshold" (default 32): the same choice for the key
+ * switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (lowest latency), up
+ * to ks_wg_threshold one workgroup per ciphertext, above that 16 ciphertexts share each step of the
+ * key in LDS.  All variants produce identical words.
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
  * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in

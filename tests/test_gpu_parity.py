@@ -22,10 +22,12 @@ def br_kernel(request, engine):
     engine.api.set_option("ll_threshold", 1 << 30 if which == "ll" else 0)
     engine.api.set_option("wg_threshold", 0 if which == "batch" else 1 << 30)
     engine.api.set_option("ks_wg_threshold", 0 if which == "batch" else 1 << 30)
+    engine.api.set_option("ks_split_threshold", 1 << 30 if which == "ll" else 0)   # ll: 8 workgroups per key switch
     yield which
     engine.api.set_option("ll_threshold", 1280)
     engine.api.set_option("wg_threshold", 1024)
     engine.api.set_option("ks_wg_threshold", 128)
+    engine.api.set_option("ks_split_threshold", 32)
 
 
 def _upload(eng, arr):
