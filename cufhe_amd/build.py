@@ -12,10 +12,20 @@ OUT = os.path.join(HERE, "libcufhe_amd.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 
-def build(force=False, verbose=False):
+DIAG_OUT = os.path.join(HERE, "libcufhe_amd_diag.so")
+
+
+def build(force=False, verbose=False, diagnostic=None, extra=()):
+    """diagnostic: list of ablation switch names (NO_TW, NO_XPOSE, NO_BK, BK0): a timing-only build whose
+    results are WRONG; it goes to libcufhe_amd_diag.so and is never loaded by the package."""
+    if diagnostic:
+        cmd = ["hipcc"] + FLAGS + ["-DCUFHE_AMD_DIAGNOSTIC_BUILD"] + [f"-DCUFHE_AMD_ABL_{d}" for d in diagnostic] + \
+              list(extra) + ["-o", DIAG_OUT, SRC]
+        subprocess.check_call(cmd)
+        return DIAG_OUT
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = ["hipcc"] + FLAGS + ["-o", OUT, SRC]
+    cmd = ["hipcc"] + FLAGS + list(extra) + ["-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
@@ -23,4 +33,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    diag = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--diagnostic=")]
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, diagnostic=diag[0] if diag else None))

@@ -28,6 +28,14 @@
 #pragma once
 #include <stdint.h>
 
+// Ablation switches (CUFHE_AMD_ABL_*) exist for timing experiments only and make the kernels
+// compute WRONG words.  They are honoured only in a diagnostic build, which cufhe_amd/build.py
+// --diagnostic writes to libcufhe_amd_diag.so so that it can never be mistaken for the product.
+#if (defined(CUFHE_AMD_ABL_NO_TW) || defined(CUFHE_AMD_ABL_NO_XPOSE) || defined(CUFHE_AMD_ABL_NO_BK) || \
+     defined(CUFHE_AMD_ABL_BK0)) && !defined(CUFHE_AMD_DIAGNOSTIC_BUILD)
+#error "CUFHE_AMD_ABL_* switches produce wrong results: use `python cufhe_amd/build.py --diagnostic=NAME[,NAME]` (defines CUFHE_AMD_DIAGNOSTIC_BUILD, output libcufhe_amd_diag.so)"
+#endif
+
 #if defined(__HIPCC__)
 #define FPF_HD __host__ __device__ __forceinline__
 #else
@@ -91,5 +99,13 @@ FPF_HD uint32_t lift_u32_small(double a)
     __builtin_memcpy(&tb, &t, 8);
     return low32(a) - (uint32_t)tb * (uint32_t)P_U64;
 }
+
+
+// ---- compile-time bounds (units of p), used by static_asserts where parameters enter ----
+constexpr double GROW = 0.09723;                 // p / 2^53, rounded up
+constexpr double LIM_NARROW = 5.142;             // 2^52 / p, rounded down: largest |a| for mulmod
+constexpr double LIM_WIDE = 10.285;              // 2^53 / p, rounded down: largest |a| for mulmod_wide / any value
+constexpr double after_mulmod(double a) { return 0.5 + GROW * a; }        // |mulmod(a, w)|
+constexpr double after_mulmod_wide(double a) { return 1.0 + GROW * a; }   // |mulmod_wide(a, w)|
 
 }  // namespace fpf

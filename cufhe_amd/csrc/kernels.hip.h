@@ -28,7 +28,10 @@
 
 namespace cufhe_amd {
 
-// TFHE parameters; symbolic so another set is a one-line change
+// TFHE parameters.  Another set is NOT just a change of these lines: the
+// static_asserts below tie l, Bgbit and N to the FP64 prime (exactness of the external product) and
+// to the lazy-reduction schedule of ntt_wave.h; a set that fails them needs the limb split of
+// kernels_lvl2.hip.h.
 constexpr int kLvl0N = 630;            // lvl0param::n
 constexpr int kNbit = 10;              // lvl1param::nbit
 constexpr int kL = 3;                  // lvl1param::l
@@ -43,6 +46,18 @@ constexpr int kBkPolysPerStep = kBkRows * 2;            // (k+1)^2 l = 12
 constexpr size_t kBkStepDoubles = (size_t)kBkPolysPerStep * kN;   // 12288 doubles = 98304 B
 constexpr int kKsRowWords = kLvl0Words;                 // 631
 constexpr int kKsNumBase = 1 << (kKsBasebit - 1);       // 2
+
+// Exactness of the external product over the FP64 prime (fpfield.h): the true integer sum of one
+// CMux output coefficient, |sum| <= (k+1) l N (Bg/2) 2^31 with the key read as signed words, must
+// stay below p/2 or the centred lift returns a wrong torus word.
+constexpr double kExtProdSumBound = 2.0 * kL * kN * (double)(1u << (kBgbit - 1)) * 2147483648.0;
+static_assert(kExtProdSumBound < fpf::P / 2, "(k+1) l N (Bg/2) 2^31 >= p/2: this parameter set needs the limb split (kernels_lvl2.hip.h)");
+// ... and of the lazy-reduction schedule: digits of magnitude Bg/2 through the forward transform,
+// then (k+1) l unreduced wide products per accumulator
+constexpr double kDigitSpectrumBound = forward_digit_spectrum_bound((double)(1u << (kBgbit - 1)));
+static_assert(kDigitSpectrumBound > 0, "forward NTT of gadget digits: a stage input exceeds its multiplication's range");
+static_assert(pointwise_sum_fits(kDigitSpectrumBound, kBkRows), "(k+1) l unreduced pointwise products exceed 2^53");
+static_assert(kL * kBgbit <= 32 - 1, "decomposition wider than the torus word");
 
 // out = ca * in0 + cb * in1 + (0, ..., 0, off): the linear part of every gate
 struct LinDesc {
@@ -157,7 +172,7 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
 __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double (&A1)[kRegs],
                                                      const double (&x)[kRegs], const char* row_lane)
 {
-#ifdef CUFHE_AMD_ABL_NO_BK
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_BK)
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         A0[2 * q] += fpf::mulmod_wide(x[2 * q], 1234567.0 + q);

@@ -53,6 +53,15 @@ static_assert(k2Half == kN, "the half transforms reuse ntt_wave.h");
 constexpr size_t k2BkStepDoubles = (size_t)2 * k2BkRows * k2Prods * k2Half;   // 98304 = 768 KiB
 constexpr int k2KsNumBase = 1 << (k2KsBasebit - 1);
 
+// exactness per limb: |sum| <= (k+1) l N (Bg/2) 2^(limb bits - 1) < p/2; the top limb holds 64 - 2*22 = 20 bits
+constexpr double k2LimbSumBound = 2.0 * k2L * k2N * (double)(1u << (k2Bgbit - 1)) * (double)(1u << (k2LimbBits - 1));
+static_assert(k2LimbSumBound < fpf::P / 2, "lvl2 limb products do not fit the FP64 prime: use narrower limbs");
+static_assert(k2Limbs * k2LimbBits >= 64, "limbs do not cover the 64-bit key word");
+// digits of magnitude Bg/2 through the first (exact) split stage and a full reducing half transform,
+// reduced before the products: each product <= 0.5 + 0.0973 * 0.5, 2 l rows accumulate in LDS
+static_assert((double)(1u << (k2Bgbit - 1)) * (1.0 + fpf::ROOT4) < 9007199254740992.0 / 1024.0, "first split stage is not exact");
+static_assert(k2BkRows * fpf::after_mulmod(0.5001) < fpf::LIM_WIDE, "lvl2 row sums exceed 2^53");
+
 struct RotDesc2 {          // lvl0 operands, lvl2 result (sample-extracted TLWE)
     const uint32_t* in0;
     const uint32_t* in1;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
         const int alo = (int)(abar & (k2N - 1));
         const bool ahi = (abar >> k2Nbit) != 0;
-#ifdef CUFHE_AMD_ABL_BK0      // timing-only diagnostic: every step reads step 0's key (cache resident)
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)      // timing-only diagnostic: every step reads step 0's key (cache resident)
         const double* key = bk_ntt + (size_t)(i & 1) * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
 #else
         const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);

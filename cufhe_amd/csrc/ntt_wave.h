@@ -45,6 +45,55 @@ constexpr int kTcCount = 12;         // per-lane twiddles of stages 8-9
 constexpr int kTileSlots = 66 * 16;  // 8-byte slots in a wave's transpose tile
 constexpr int kTileBytes = kTileSlots * 8;   // 8448
 
+// The lazy-reduction schedule of the header comment, replayed at compile time (units of p).
+// Bound on the spectrum of a polynomial whose coefficients are at most `digit_max` in
+// magnitude, after the ten forward stages of ntt_forward<SMALL_IN = true>; -1 if a stage's
+// input would exceed what its multiplication accepts.
+constexpr double forward_digit_spectrum_bound(double digit_max)
+{
+    // stage 0 (I) and the zeta half of stage 1 multiply without reducing: the value must stay an exact double
+    const double s0 = digit_max * (1.0 + fpf::ROOT4);
+    const double s1z = s0 * (1.0 + fpf::ROOT8);
+    if (s1z >= 9007199254740992.0 / 1024.0) return -1.0;      // keep 10 bits of headroom below 2^53
+    double b = s1z / fpf::P + fpf::after_mulmod(s0 / fpf::P); // the reducing half of stage 1 dominates: ~0.5
+    for (int s = 2; s <= 8; s++) {                            // stages 2..8: mulmod
+        if (b >= fpf::LIM_NARROW) return -1.0;
+        b = b + fpf::after_mulmod(b);
+    }
+    if (b >= fpf::LIM_WIDE) return -1.0;                      // stage 9: mulmod_wide
+    return b + fpf::after_mulmod_wide(b);
+}
+// `rows` wide products of a spectrum bounded by s accumulate without reduction
+constexpr bool pointwise_sum_fits(double s, int rows)
+{
+    return s > 0 && s < fpf::LIM_WIDE && rows * fpf::after_mulmod_wide(s) < fpf::LIM_WIDE;
+}
+// inverse transform (ntt_inverse): input reduced to <= 0.5 (+ a tie); two Gentleman-Sande stages,
+// then twice the four stages of gs_four_stages (narrow, wide, reduce, narrow, narrow).  A GS
+// butterfly doubles the bound of its sum output and multiplies a difference of twice the input.
+constexpr double inverse_output_bound()
+{
+    double b = 0.5001;
+    for (int s = 0; s < 2; s++) {                 // stages 9, 8: mulmod(u - v)
+        if (2 * b >= fpf::LIM_NARROW) return -1.0;
+        b = 2 * b;
+    }
+    for (int half = 0; half < 2; half++) {        // stages 7..4, then 3..0
+        if (2 * b >= fpf::LIM_NARROW) return -1.0;    // narrow
+        b = 2 * b;
+        if (2 * b >= fpf::LIM_WIDE) return -1.0;      // wide
+        b = 2 * b;                                    // <= 8: reduce() accepts anything below 2^53
+        b = 0.5001;
+        for (int s = 0; s < 2; s++) {                 // two narrow stages
+            if (2 * b >= fpf::LIM_NARROW) return -1.0;
+            b = 2 * b;
+        }
+    }
+    return b;                                         // 2.0: below the 2^51 / p = 2.57 lift_u32_small accepts
+}
+constexpr bool inverse_schedule_fits() { return inverse_output_bound() > 0 && inverse_output_bound() < 2.57; }
+static_assert(inverse_schedule_fits(), "inverse NTT lazy-reduction schedule exceeds the FP64 mantissa");
+
 // twiddle tables, generated on the host with exact integer arithmetic (capi.cpp)
 struct NttTables {
     double tu_fwd[16];               // [k] k<15: root[2^lvl + j], lvl=floor(log2(k+1)), j=k+1-2^lvl
@@ -105,7 +154,7 @@ __device__ __forceinline__ WaveCtx make_wave_ctx(char* lds, int tile_off, int ta
     return c;
 }
 
-#ifdef CUFHE_AMD_ABL_NO_TW
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_TW)
 __device__ __forceinline__ double lds_ld(const char* p, int off) { return 12345678.0 + (double)off + (double)(uintptr_t)p * 1e-30; }
 #else
 __device__ __forceinline__ double lds_ld(const char* p, int off) { return *(const double*)(p + off); }
@@ -213,7 +262,7 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
 // Ablation switches (timing-only diagnostic builds, results are wrong when set):
 //   CUFHE_AMD_ABL_NO_XPOSE  skip the LDS transposes     CUFHE_AMD_ABL_NO_TW  constant twiddles
 //   CUFHE_AMD_ABL_NO_BK     (kernels.hip.h) no bootstrapping-key loads
-#ifdef CUFHE_AMD_ABL_NO_XPOSE
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_XPOSE)
 #define CUFHE_AMD_XPOSE(WBASE, WSTRIDE, RBASE, RSTRIDE) { asm volatile("" ::: "memory"); }
 #else
 // The compiler fence keeps the tile accesses of consecutive layout changes in program
