@@ -39,6 +39,12 @@ class Profile(ctypes.Structure):
                 ("keyswitch_launches", ctypes.c_uint64), ("keyswitches", ctypes.c_uint64)]
 
 
+class SchedStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
+                                               "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
+                                               "cross_stream_waits", "record_ns", "retire_ns", "launch_ns")]
+
+
 # every symbol include/cufhe_amd.h declares, with its signature
 SIGNATURES = {
     "cufhe_amd_get_params": (ctypes.c_int, [ctypes.POINTER(Params)]),
@@ -72,6 +78,7 @@ SIGNATURES = {
     "cufhe_amd_enqueue_copy": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_sched_get_stats": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(SchedStats), ctypes.c_int]),
     "cufhe_amd_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_sample_extract_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),

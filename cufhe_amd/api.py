@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import lib, check, Params, Profile, Lvl2Params
+from ._lib import lib, check, Params, Profile, Lvl2Params, SchedStats
 
 # op codes (include/cufhe_amd.h)
 NAND, NOR, XNOR, AND, OR, XOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NMUX, NOT, COPY = range(14)
@@ -318,3 +318,10 @@ def profile_get(device=0, reset=True):
     p = Profile()
     check(lib.cufhe_amd_profile_get(device, ctypes.byref(p), 1 if reset else 0))
     return p
+
+
+def sched_stats(device=0, reset=False):
+    """Counters of the per-gate API's scheduler: levels, launch sequences, copies (include/cufhe_amd.h)."""
+    s = SchedStats()
+    check(lib.cufhe_amd_sched_get_stats(device, ctypes.byref(s), 1 if reset else 0))
+    return s

@@ -10,9 +10,11 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/cufhe_amd.h"
+#include "sched_core.h"
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
 #include "kernels_ll.hip.h"
@@ -308,6 +310,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
         ev.units = count;
+        std::lock_guard<std::mutex> lk(s.staging_mu);
         s.br_events.push_back(ev);
     }
     return 0;
@@ -338,6 +341,7 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
         ev.units = count;
+        std::lock_guard<std::mutex> lk(s.staging_mu);
         s.ks_events.push_back(ev);
     }
     return 0;
@@ -357,7 +361,7 @@ const int kGateTab[10][3] = {
     {2, 2, 2},   {-1, 1, -1},  {1, -1, -1},  {-1, 1, 1}, {1, -1, 1},
 };
 
-struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1; const uint32_t* in2; };
+using sched::GateRef;
 
 template <class GetGate>
 int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lvl2.inc.h
@@ -459,7 +463,7 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 
 }  // namespace
 
-#include "sched.inc.h"
+#include "sched_hip.inc.h"
 #include "lvl2.inc.h"
 
 extern "C" {
@@ -493,6 +497,10 @@ int cufhe_amd_set_gpu_num(int gpu_num)
         if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
     int have = cufhe_amd_device_count();
     if (gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
+    if (gpu_num != g_gpu_num) {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        sched_retire_generation();
+    }
     g_gpu_num = gpu_num;
     g_dev.clear();
     g_dev.resize(gpu_num);
@@ -551,8 +559,7 @@ int cufhe_amd_cleanup(void)
 {
     {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
-        (void)sched_synchronize_all();
-        sched_destroy_all();
+        sched_quiesce();
     }
     std::lock_guard<std::mutex> lk(g_mu);
     for (int i = 0; i < g_gpu_num; i++) {
@@ -615,6 +622,10 @@ int cufhe_amd_stream_destroy(int device, void* stream)
             (void)hipFree(it->second.base);
             s.workspaces.erase(it);
         }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        if (g_scheduler && device < g_scheduler->gpu_num()) g_scheduler->dev(device).forget_stream(stream);
     }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return 0;
@@ -878,7 +889,31 @@ int cufhe_amd_set_option(const char* key, long value)
         for (auto& d : g_dev)
             if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "device_base must be set before Initialize");
         if (value < 0 || value + g_gpu_num > cufhe_amd_device_count()) return fail(-1, "device_base out of range");
+        if (value != g_device_base) {
+            std::lock_guard<std::mutex> lk2(g_sched_mu);
+            sched_retire_generation();
+        }
         g_device_base = (int)value;
+        return 0;
+    }
+    if (!strcmp(key, "sched_streams") || !strcmp(key, "sched_threads")) {
+        // structure of the scheduler: takes effect for the next scheduler generation
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        if (value < 0 || value > 64) return fail(-1, "value out of range");
+        if (g_scheduler && g_scheduler->live_ctxts()) return fail(-1, "sched_streams / sched_threads must be set before the first ciphertext is created");
+        sched_retire_generation();
+        (key[6] == 's' ? g_sched_streams : g_sched_threads) = value;
+        return 0;
+    }
+    if (!strcmp(key, "sched_level_gates") || !strcmp(key, "sched_total_gates")) {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        if (value < 1) return fail(-1, "value out of range");
+        (key[6] == 'l' ? g_sched_level_gates : g_sched_total_gates) = value;
+        if (g_scheduler)
+            for (int d = 0; d < g_scheduler->gpu_num(); d++) {
+                g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
+                g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
+            }
         return 0;
     }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
@@ -915,8 +950,14 @@ int cufhe_amd_profile_get(int device, cufhe_amd_profile* out, int reset)
         v.clear();
         return 0;
     };
-    if (int rc = drain(s.br_events, s.prof.blind_rotate_ms, s.prof.blind_rotate_launches, s.prof.blind_rotations)) return rc;
-    if (int rc = drain(s.ks_events, s.prof.keyswitch_ms, s.prof.keyswitch_launches, s.prof.keyswitches)) return rc;
+    std::vector<EventPair> br, ks;
+    {
+        std::lock_guard<std::mutex> lk(s.staging_mu);     // the scheduler's worker thread records launches too
+        br.swap(s.br_events);
+        ks.swap(s.ks_events);
+    }
+    if (int rc = drain(br, s.prof.blind_rotate_ms, s.prof.blind_rotate_launches, s.prof.blind_rotations)) return rc;
+    if (int rc = drain(ks, s.prof.keyswitch_ms, s.prof.keyswitch_launches, s.prof.keyswitches)) return rc;
     if (out) *out = s.prof;
     if (reset) s.prof = cufhe_amd_profile{};
     return 0;

@@ -59,6 +59,7 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
         ev.units = count;
+        std::lock_guard<std::mutex> lk(s.staging_mu);
         s.br_events.push_back(ev);
     }
     return 0;
@@ -78,6 +79,7 @@ int launch_keyswitch_lvl2(DeviceState& s, hipStream_t st, const LinDesc64* d, si
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
         ev.units = count;
+        std::lock_guard<std::mutex> lk(s.staging_mu);
         s.ks_events.push_back(ev);
     }
     return 0;

@@ -1,0 +1,913 @@
+// sched_core.h -- the level-wise stream scheduler behind the reference's per-gate API.
+//
+// The reference launches one kernel per gate on the caller's stream, bracketed by three small
+// memcpys (src/cufhe_gates_gpu.cu:148-158); throughput comes from hundreds of concurrent streams
+// (test/test_util.h:36-62) and dependent gates are chained by stream order
+// (test/test_api_gpu.cu:140-159, include/cufhe_gpu.cuh:282-313).  Here a gate call only RECORDS
+// the gate, together with its data dependences; the recorded program of a device is kept as
+// DEPENDENCE LEVELS, and level k of all streams is launched together: one blind-rotate launch and
+// one key-switch launch per level and ciphertext kind, however the caller interleaved its streams.
+//
+// What a caller of the reference API can observe is unchanged:
+//   * the result of a program is the result of executing its calls in issue order (the reference
+//     promises this per stream and leaves cross-stream conflicts undefined; the single issuing
+//     thread of its API makes issue order a legal execution of every race-free program);
+//   * `out.tlwehost` holds a gate's result once Synchronize() returned or StreamQuery(st) returned
+//     true for the stream the gate was issued on;
+//   * non-g gates take their inputs from `tlwehost` in stream order: the memory as of the call, or,
+//     when an earlier gate's result is still on its way to that `tlwehost`, that result -- the
+//     reference's D2H of the earlier gate precedes this gate's H2D on the stream;
+//   * g-gates touch device buffers only; CtxtCopyH2D / CtxtCopyD2H move data in issue order;
+//   * `out` may alias an input (test/test_api_gpu.cu:141); inputs may be shared by any number of
+//     gates on any streams (test/test_intensive.cc:103-107).
+//
+// Nothing in this file calls HIP: the device is reached through `Backend`, so the scheduler is
+// exercised on the CPU against a stubbed device layer (tests/host/sched_harness.cpp), including
+// SetGPUNum(G > 1) routing.  capi.hip supplies the HIP backend.
+//
+// Threads: one issuing thread (the reference's contract) records; each device has a worker thread
+// that turns flushed levels into launches, so recording for device B overlaps launching on device
+// A and one process can feed every GPU of a node.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace cufhe_amd {
+namespace sched {
+
+struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1; const uint32_t* in2; };
+struct CopyRec { uint32_t* dev; size_t slot; int level; };      // staging word offset <-> a ciphertext's device buffer
+
+// The device layer of ONE device.  Every method returns 0 or a negative status (text through
+// error_text()).  `s` is the index of one of the backend's internal streams; work submitted to one
+// internal stream executes in submission order, different streams are ordered only by events.
+class Backend {
+   public:
+    virtual ~Backend() {}
+    virtual void bind_thread() = 0;                                   // make this device current in the calling thread
+    virtual int num_streams() = 0;
+    virtual int words(int level) = 0;                                 // words of a level-`level` ciphertext
+    virtual int alloc_device(size_t bytes, void** p) = 0;
+    virtual int free_device(void* p) = 0;
+    virtual int alloc_pinned(size_t bytes, void** p) = 0;
+    virtual int free_pinned(void* p) = 0;
+    virtual int h2d(int s, void* dst, const void* src, size_t bytes) = 0;
+    virtual int d2h(int s, void* dst, const void* src, size_t bytes) = 0;
+    // staging[rec.slot ..] -> rec.dev (to_ctxt) or the reverse, `words(rec.level)` words each
+    virtual int copy_ctxts(int s, const CopyRec* recs, size_t n, uint32_t* staging, bool to_ctxt) = 0;
+    // n independent gates on ciphertexts of one level: no gate of the call reads what another writes
+    virtual int run_gates(int s, int level, const GateRef* g, size_t n) = 0;
+    virtual int event_create(void** ev) = 0;
+    virtual int event_destroy(void* ev) = 0;
+    virtual int event_record(int s, void* ev) = 0;
+    virtual int event_query(void* ev) = 0;                            // 1 complete, 0 not yet
+    virtual int event_sync(void* ev) = 0;
+    virtual int stream_wait(int s, void* ev) = 0;
+    virtual std::string error_text() = 0;
+};
+
+}  // namespace sched
+}  // namespace cufhe_amd
+
+// template<class P> struct Ctxt of the reference (include/cufhe_gpu.cuh:102-121): caller-owned
+// `tlwehost` plus one device buffer per GPU, and the bookkeeping that orders recorded accesses.
+struct cufhe_amd_ctxt {
+    struct PerDev {
+        uint32_t* dev = nullptr;
+        uint32_t ready = 0;         // depth from which a gate may read `dev` (0: resident since long)
+        uint32_t wdepth = 0;        // depth of the newest recorded write of `dev` (0: none on record)
+        bool w_upload = false;      // ... which was an upload (runs before the gates of its level)
+        uint64_t version = 0;       // bumps at every recorded write of `dev`
+        std::vector<uint32_t> rdepths;   // levels that read `dev` since that write
+        // the newest upload host -> dev, kept to recognise an unchanged shared input
+        void* snap_plan = nullptr;
+        size_t snap_off = 0;
+        uint64_t snap_version = 0;
+        uint32_t snap_hits = 0;
+        bool snap_owned = false;
+        std::vector<uint32_t> snap_own;
+    };
+    int level = 0;
+    uint32_t* host = nullptr;       // nullptr once the caller destroyed the ciphertext
+    int refs = 0;                   // recorded / in-flight work still naming this ciphertext
+    bool destroyed = false;
+    // a result on its way to `host`: produced on device host_dev as version host_version
+    int host_dev = -1;
+    uint64_t host_version = 0;
+    uint64_t host_token = 0;
+    std::vector<PerDev> d;
+};
+
+namespace cufhe_amd {
+namespace sched {
+
+struct Stats {
+    uint64_t gates = 0;               // gates recorded
+    uint64_t groups = 0;              // flushes handed to the device
+    uint64_t levels = 0;              // dependence levels launched
+    uint64_t launch_sequences = 0;    // run_gates calls = (level, ciphertext kind) pairs with gates
+    uint64_t uploads = 0, uploads_shared = 0, downloads = 0;
+    uint64_t forced_syncs = 0;        // a stale `tlwehost` had to be waited for (see resolve_host)
+    uint64_t max_level_gates = 0;
+    uint64_t cross_stream_waits = 0;
+    // host time: on the issuing thread (recording, delivering results) and on the launch worker
+    uint64_t record_ns = 0, retire_ns = 0;
+    std::atomic<uint64_t> launch_ns{0};
+    Stats() {}
+    Stats(const Stats& o) { *this = o; }
+    Stats& operator=(const Stats& o)
+    {
+        gates = o.gates; groups = o.groups; levels = o.levels; launch_sequences = o.launch_sequences;
+        uploads = o.uploads; uploads_shared = o.uploads_shared; downloads = o.downloads; forced_syncs = o.forced_syncs;
+        max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits;
+        record_ns = o.record_ns; retire_ns = o.retire_ns;
+        launch_ns.store(o.launch_ns.load());
+        return *this;
+    }
+};
+struct ScopedNs {
+    uint64_t* acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ScopedNs(uint64_t* a) : acc(a) {}
+    ~ScopedNs() { *acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+struct Delivery { cufhe_amd_ctxt* c; size_t slot; uint64_t token; };
+
+struct Plan {                         // one dependence level of the recorded program
+    uint32_t depth = 0;
+    std::vector<GateRef> gates[2];
+    std::vector<CopyRec> uploads, downloads;
+    std::vector<cufhe_amd_ctxt*> upload_ctxts;     // parallel to uploads
+    std::vector<Delivery> deliveries;              // parallel to downloads
+    std::vector<uint32_t> in_words;                // host snapshots of the uploads
+    size_t out_words = 0;
+    std::vector<uint32_t> dep_depths;              // earlier levels this one must follow
+    std::vector<cufhe_amd_ctxt*> touched;          // one reference per operand
+    std::vector<void*> streams;                    // caller streams with work in this level
+    size_t in_base = 0, out_base = 0;              // offsets in the group's staging blocks
+    size_t gate_count() const { return gates[0].size() + gates[1].size(); }
+};
+
+struct EventHolder {
+    Backend* be;
+    void* ev = nullptr;
+    explicit EventHolder(Backend* b) : be(b) {}
+    ~EventHolder() { if (ev) be->event_destroy(ev); }
+};
+
+struct Group {                        // consecutive levels flushed together
+    uint64_t id = 0;
+    uint32_t first_depth = 0, last_depth = 0;
+    std::vector<Plan*> plans;
+    int stream = 0;
+    std::vector<std::shared_ptr<EventHolder>> deps;
+    std::shared_ptr<EventHolder> done;
+    size_t in_words = 0, out_words = 0;
+    void *pin_in = nullptr, *pin_out = nullptr;
+    uint32_t *dev_in = nullptr, *dev_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0, dev_in_cap = 0, dev_out_cap = 0;
+    std::atomic<int> state{0};        // 0 queued, 1 launched, 2 retired
+    int error = 0;
+    std::string error_text;
+};
+
+class Scheduler;
+
+class DeviceSched {
+   public:
+    DeviceSched(Scheduler* owner, int device, Backend* be, bool threaded)
+        : owner_(owner), device_(device), be_(be), threaded_(threaded)
+    {
+        nstreams_ = std::max(1, be_->num_streams());
+        if (threaded_) worker_ = std::thread([this] { worker_loop(); });
+    }
+    ~DeviceSched() { stop_worker(); }
+
+    void stop_worker()
+    {
+        if (!worker_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        worker_.join();
+    }
+
+    Backend* backend() { return be_; }
+    Stats& stats() { return stats_; }
+    const std::string& error_text() const { return err_; }
+    size_t pending_levels() const { return levels_.size(); }
+
+    int record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* const (&ins)[3]);
+    int record_copy(void* stream, cufhe_amd_ctxt* c, bool to_device);
+    int flush(size_t max_levels = (size_t)-1);
+    int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
+    int synchronize();
+    void forget_stream(void* stream) { streams_.erase(stream); }
+    // release every cached buffer; the device must be idle (synchronize() first)
+    void release_buffers();
+    // ... and the ciphertext slabs: only once no ciphertext of this scheduler is alive
+    void release_slabs()
+    {
+        for (void* s : slabs_) be_->free_device(s);
+        slabs_.clear();
+        free_slots_[0].clear();
+        free_slots_[1].clear();
+    }
+
+    // one slot per ciphertext, carved from slabs (the reference pays a cudaMalloc per Ctxt per GPU,
+    // include/cufhe_gpu.cuh:76-95)
+    int slot_alloc(int level, uint32_t** out);
+    void slot_free(int level, uint32_t* p) { free_slots_[level].push_back(p); }
+
+    size_t level_flush_gates = 2048;   // a level this full is launched at once (one round of the blind-rotate grid)
+    size_t total_flush_gates = 32768;  // bound on the recorded program
+
+   private:
+    struct StreamState { uint32_t max_depth = 0; std::vector<uint64_t> open; };
+    struct Buf { void* p; size_t cap; };
+
+    int fail(int rc, const std::string& what)
+    {
+        err_ = what;
+        return rc;
+    }
+    Plan& plan_at(uint32_t depth)
+    {
+        while (base_depth_ + levels_.size() <= depth) {
+            Plan* p = new Plan();
+            p->depth = base_depth_ + (uint32_t)levels_.size();
+            levels_.push_back(p);
+        }
+        return *levels_[depth - base_depth_];
+    }
+    Group* find_group(uint32_t depth)
+    {
+        // live_ is sorted by depth; groups retire out of order, so a retired one may sit in the middle
+        size_t lo = 0, hi = live_.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (live_[mid]->last_depth < depth) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < live_.size() && live_[lo]->first_depth <= depth) return live_[lo];
+        return nullptr;
+    }
+    // has the level at `depth` completed and been retired?
+    bool done(uint32_t depth)
+    {
+        if (depth == 0) return true;
+        if (depth >= base_depth_) return false;
+        Group* g = find_group(depth);
+        return !g || g->state.load(std::memory_order_acquire) == 2;
+    }
+    static uint32_t max_reader(const cufhe_amd_ctxt::PerDev& pd)
+    {
+        uint32_t m = 0;
+        for (uint32_t r : pd.rdepths) m = std::max(m, r);
+        return m;
+    }
+    void add_dep(Plan& p, uint32_t depth)
+    {
+        if (depth == 0 || depth >= p.depth || done(depth)) return;
+        if (!p.dep_depths.empty() && p.dep_depths.back() == depth) return;
+        p.dep_depths.push_back(depth);
+    }
+    void add_reader(cufhe_amd_ctxt::PerDev& pd, uint32_t depth)
+    {
+        for (uint32_t r : pd.rdepths)
+            if (r == depth) return;
+        if (pd.rdepths.size() >= 8) {     // forget levels that have retired
+            size_t k = 0;
+            for (uint32_t r : pd.rdepths)
+                if (!done(r)) pd.rdepths[k++] = r;
+            pd.rdepths.resize(k);
+        }
+        pd.rdepths.push_back(depth);
+    }
+    void touch(Plan& p, cufhe_amd_ctxt* c)
+    {
+        c->refs++;
+        p.touched.push_back(c);
+    }
+    void note_stream(Plan& p, void* stream, uint32_t depth)
+    {
+        StreamState& ss = streams_[stream];
+        ss.max_depth = std::max(ss.max_depth, depth);
+        if (p.streams.empty() || p.streams.back() != stream) p.streams.push_back(stream);
+    }
+    const uint32_t* snapshot_words(const cufhe_amd_ctxt::PerDev& pd) const
+    {
+        if (pd.snap_owned) return pd.snap_own.data();
+        if (pd.snap_plan) return ((const Plan*)pd.snap_plan)->in_words.data() + pd.snap_off;
+        return nullptr;
+    }
+    int resolve_host(cufhe_amd_ctxt* c, bool* need_upload);
+    void record_upload(cufhe_amd_ctxt* c);
+    int after_record();
+    int launch(Group* g);                       // worker (or inline): submit the group's work
+    int retire(Group* g);                       // issuing thread: deliver results, recycle
+    void worker_loop();
+    void wait_worker_idle()
+    {
+        if (!threaded_) return;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_idle_.wait(lk, [&] { return queue_.empty() && !busy_; });
+    }
+    int get_buf(std::vector<Buf>& cache, size_t bytes, bool pinned, void** p, size_t* cap);
+
+    Scheduler* owner_;
+    int device_;
+    Backend* be_;
+    bool threaded_;
+    int nstreams_ = 1;
+    int rr_ = 0;
+    std::string err_;
+    Stats stats_;
+
+    // the recorded, not yet launched program: levels_[i] has depth base_depth_ + i
+    uint32_t base_depth_ = 1;
+    std::deque<Plan*> levels_;
+    size_t pending_gates_ = 0;
+    std::unordered_map<void*, StreamState> streams_;
+    uint64_t next_group_ = 1;
+    std::deque<Group*> live_;                   // launched or queued groups, oldest first
+    int sticky_error_ = 0;
+
+    std::vector<uint32_t*> free_slots_[2];
+    std::vector<void*> slabs_;
+
+    // shared with the worker
+    std::mutex mu_;
+    std::condition_variable cv_, cv_idle_;
+    std::deque<Group*> queue_;
+    bool busy_ = false, stop_ = false;
+    std::vector<Buf> pinned_cache_, dev_cache_;
+    std::thread worker_;
+};
+
+class Scheduler {
+   public:
+    // `make_backend(device)` supplies the device layer; the scheduler owns the returned objects
+    template <class Factory>
+    Scheduler(int gpu_num, bool threaded, Factory make_backend)
+    {
+        for (int d = 0; d < gpu_num; d++) {
+            backends_.emplace_back(make_backend(d));
+            devs_.emplace_back(new DeviceSched(this, d, backends_.back().get(), threaded));
+        }
+    }
+    // Tears the device objects down through the backend: only for a scheduler whose devices are
+    // idle and whose ciphertexts are gone (the HIP library keeps its scheduler for the process
+    // lifetime instead, see capi.hip).
+    ~Scheduler()
+    {
+        for (auto& d : devs_) d->stop_worker();
+        for (auto& d : devs_) {
+            d->release_buffers();
+            d->release_slabs();
+        }
+    }
+    int live_ctxts() const { return live_ctxts_; }
+    int gpu_num() const { return (int)devs_.size(); }
+    DeviceSched& dev(int d) { return *devs_[d]; }
+    uint64_t new_token() { return ++token_; }
+
+    int ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out, std::string* err)
+    {
+        cufhe_amd_ctxt* c = new cufhe_amd_ctxt();
+        c->level = level;
+        c->host = host_words;
+        c->d.resize(devs_.size());
+        for (size_t d = 0; d < devs_.size(); d++)
+            if (int rc = devs_[d]->slot_alloc(level, &c->d[d].dev)) {
+                *err = devs_[d]->error_text();
+                for (size_t e = 0; e < d; e++) devs_[e]->slot_free(level, c->d[e].dev);
+                delete c;
+                return rc;
+            }
+        live_ctxts_++;
+        *out = c;
+        return 0;
+    }
+    // The caller's ciphertext goes away; its device buffers are recycled once the last recorded or
+    // in-flight gate naming them has retired.  No flush, no wait: RAII temporaries in a circuit
+    // stay cheap.
+    void ctxt_destroy(cufhe_amd_ctxt* c)
+    {
+        c->destroyed = true;
+        c->host = nullptr;
+        if (c->refs == 0) ctxt_release(c);
+    }
+    void ctxt_unref(cufhe_amd_ctxt* c)
+    {
+        if (--c->refs == 0 && c->destroyed) ctxt_release(c);
+    }
+    int synchronize_all()
+    {
+        // hand every device its recorded work first, then wait: the devices run concurrently
+        int rc = 0;
+        for (auto& d : devs_)
+            if (int r = d->flush()) rc = rc ? rc : r;
+        for (auto& d : devs_)
+            if (int r = d->synchronize()) rc = rc ? rc : r;
+        return rc;
+    }
+
+   private:
+    void ctxt_release(cufhe_amd_ctxt* c)
+    {
+        for (size_t d = 0; d < c->d.size() && d < devs_.size(); d++)
+            if (c->d[d].dev) devs_[d]->slot_free(c->level, c->d[d].dev);
+        delete c;
+        live_ctxts_--;
+    }
+    std::vector<std::unique_ptr<Backend>> backends_;
+    std::vector<std::unique_ptr<DeviceSched>> devs_;
+    uint64_t token_ = 0;
+    int live_ctxts_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+
+inline int DeviceSched::slot_alloc(int level, uint32_t** out)
+{
+    std::vector<uint32_t*>& fl = free_slots_[level];
+    if (fl.empty()) {
+        const size_t slot_bytes = ((size_t)be_->words(level) * 4 + 255) & ~(size_t)255;
+        const size_t count = 512;
+        void* slab = nullptr;
+        be_->bind_thread();
+        if (int rc = be_->alloc_device(slot_bytes * count, &slab)) return fail(rc, be_->error_text());
+        slabs_.push_back(slab);
+        for (size_t i = count; i-- > 0;) fl.push_back((uint32_t*)((char*)slab + i * slot_bytes));
+    }
+    *out = fl.back();
+    fl.pop_back();
+    return 0;
+}
+
+inline int DeviceSched::get_buf(std::vector<Buf>& cache, size_t bytes, bool pinned, void** p, size_t* cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        size_t best = cache.size();
+        for (size_t i = 0; i < cache.size(); i++)
+            if (cache[i].cap >= bytes && (best == cache.size() || cache[i].cap < cache[best].cap)) best = i;
+        if (best != cache.size()) {
+            *p = cache[best].p;
+            *cap = cache[best].cap;
+            cache.erase(cache.begin() + best);
+            return 0;
+        }
+    }
+    *cap = bytes + bytes / 2 + 4096;
+    return pinned ? be_->alloc_pinned(*cap, p) : be_->alloc_device(*cap, p);
+}
+
+inline void DeviceSched::release_buffers()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Buf& b : pinned_cache_) be_->free_pinned(b.p);
+    for (Buf& b : dev_cache_) be_->free_device(b.p);
+    pinned_cache_.clear();
+    dev_cache_.clear();
+}
+
+// Where does the value a non-g gate must read for `c` live?  The reference copies `tlwehost` to the
+// device in stream order.  If an earlier result is still travelling to that `tlwehost`, the value
+// is that result: it is the device buffer itself when nothing overwrote the buffer since (the
+// normal chain Nand(c, ..) ; Or(d, c, ..)); otherwise the host copy has to land first.
+inline int DeviceSched::resolve_host(cufhe_amd_ctxt* c, bool* need_upload)
+{
+    cufhe_amd_ctxt::PerDev& pd = c->d[device_];
+    if (c->host_dev >= 0) {
+        if (c->host_dev == device_ && c->host_version == pd.version) {
+            *need_upload = false;
+            return 0;
+        }
+        stats_.forced_syncs++;
+        const int other = c->host_dev;
+        if (int rc = owner_->dev(other).synchronize()) return fail(rc, owner_->dev(other).error_text());
+    }
+    // `tlwehost` is plain memory now.  An unchanged input that the device buffer still holds from an
+    // earlier upload is not copied again: shared inputs (test/test_intensive.cc) stay pure reads.
+    const uint32_t* snap = pd.snap_version == pd.version ? snapshot_words(pd) : nullptr;
+    if (snap && c->host && !memcmp(snap, c->host, (size_t)be_->words(c->level) * 4)) {
+        pd.snap_hits++;
+        stats_.uploads_shared++;
+        *need_upload = false;
+        return 0;
+    }
+    *need_upload = true;
+    return 0;
+}
+
+// tlwehost (as of now) -> device buffer, at the earliest level that follows every recorded access
+inline void DeviceSched::record_upload(cufhe_amd_ctxt* c)
+{
+    cufhe_amd_ctxt::PerDev& pd = c->d[device_];
+    uint32_t U = std::max(base_depth_, pd.ready);
+    if (pd.w_upload) U = std::max(U, pd.wdepth + 1);
+    U = std::max(U, max_reader(pd) + (pd.rdepths.empty() ? 0u : 1u));
+    Plan& p = plan_at(U);
+    add_dep(p, pd.wdepth);
+    for (uint32_t r : pd.rdepths) add_dep(p, r);
+    const size_t words = (size_t)be_->words(c->level);
+    const size_t slot = p.in_words.size();
+    p.in_words.insert(p.in_words.end(), c->host, c->host + words);
+    p.uploads.push_back({pd.dev, slot, c->level});
+    p.upload_ctxts.push_back(c);
+    touch(p, c);
+    pd.version++;
+    pd.wdepth = U;
+    pd.w_upload = true;
+    pd.ready = U;
+    pd.rdepths.clear();
+    pd.snap_plan = &p;
+    pd.snap_off = slot;
+    pd.snap_version = pd.version;
+    pd.snap_hits = 0;
+    pd.snap_owned = false;
+    stats_.uploads++;
+}
+
+inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out,
+                                    cufhe_amd_ctxt* const (&ins)[3])
+{
+    ScopedNs timer(&stats_.record_ns);
+    // inputs that must be refreshed from the host (may wait for another device: do it first)
+    bool need_up[3] = {false, false, false};
+    if (copying)
+        for (int i = 0; i < 3; i++) {
+            if (!ins[i]) continue;
+            bool seen = false;
+            for (int j = 0; j < i; j++) seen = seen || ins[j] == ins[i];
+            if (seen) continue;
+            if (!ins[i]->host) return fail(-1, "gate on a destroyed ciphertext");
+            if (int rc = resolve_host(ins[i], &need_up[i])) return rc;
+        }
+    for (int i = 0; i < 3; i++)
+        if (need_up[i]) record_upload(ins[i]);
+
+    uint32_t D = base_depth_;
+    for (int i = 0; i < 3; i++)
+        if (ins[i]) D = std::max(D, ins[i]->d[device_].ready);
+    cufhe_amd_ctxt::PerDev& po = out->d[device_];
+    D = std::max(D, po.ready);
+    if (!po.rdepths.empty()) D = std::max(D, max_reader(po) + 1);     // write after read
+
+    Plan& p = plan_at(D);
+    for (int i = 0; i < 3; i++) {
+        if (!ins[i]) continue;
+        cufhe_amd_ctxt::PerDev& pd = ins[i]->d[device_];
+        add_dep(p, pd.wdepth);
+        touch(p, ins[i]);
+    }
+    add_dep(p, po.wdepth);
+    for (uint32_t r : po.rdepths) add_dep(p, r);
+    for (int i = 0; i < 3; i++)
+        if (ins[i]) add_reader(ins[i]->d[device_], D);
+    // the write: in-place gates are safe, every kernel reads its operands before it writes
+    po.version++;
+    po.wdepth = D;
+    po.w_upload = false;
+    po.ready = D + 1;
+    po.rdepths.clear();
+    po.snap_plan = nullptr;
+    po.snap_owned = false;
+    touch(p, out);
+    p.gates[out->level].push_back(GateRef{op, po.dev, ins[0]->d[device_].dev,
+                                          ins[1] ? ins[1]->d[device_].dev : nullptr,
+                                          ins[2] ? ins[2]->d[device_].dev : nullptr});
+    if (copying) {
+        const size_t slot = p.out_words;
+        p.out_words += (size_t)be_->words(out->level);
+        p.downloads.push_back({po.dev, slot, out->level});
+        const uint64_t token = owner_->new_token();
+        p.deliveries.push_back({out, slot, token});
+        touch(p, out);
+        out->host_dev = device_;
+        out->host_version = po.version;
+        out->host_token = token;
+        stats_.downloads++;
+    }
+    note_stream(p, stream, D);
+    pending_gates_++;
+    stats_.gates++;
+    return after_record();
+}
+
+inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_device)
+{
+    cufhe_amd_ctxt::PerDev& pd = c->d[device_];
+    if (to_device) {     // CtxtCopyH2D, include/cufhe_gpu.cuh:193-199
+        if (!c->host) return fail(-1, "copy of a destroyed ciphertext");
+        bool need = false;
+        if (int rc = resolve_host(c, &need)) return rc;
+        if (need) {
+            record_upload(c);
+            note_stream(plan_at(pd.wdepth), stream, pd.wdepth);
+        }
+        return 0;
+    }
+    // CtxtCopyD2H, :201-207: the gather of a level runs after its gates
+    const uint32_t D = std::max(base_depth_, pd.wdepth);
+    Plan& p = plan_at(D);
+    add_dep(p, pd.wdepth);
+    add_reader(pd, D);
+    const size_t slot = p.out_words;
+    p.out_words += (size_t)be_->words(c->level);
+    p.downloads.push_back({pd.dev, slot, c->level});
+    const uint64_t token = owner_->new_token();
+    p.deliveries.push_back({c, slot, token});
+    touch(p, c);
+    c->host_dev = device_;
+    c->host_version = pd.version;
+    c->host_token = token;
+    stats_.downloads++;
+    note_stream(p, stream, D);
+    return 0;
+}
+
+inline int DeviceSched::after_record()
+{
+    if (!levels_.empty() && levels_.front()->gate_count() >= level_flush_gates) return flush(1);
+    if (pending_gates_ >= total_flush_gates) return flush();
+    return 0;
+}
+
+inline int DeviceSched::flush(size_t max_levels)
+{
+    // trailing levels without any work (created by plan_at) are dropped, leading ones launched as no-ops
+    while (!levels_.empty()) {
+        Plan* b = levels_.back();
+        if (b->gate_count() || !b->uploads.empty() || !b->downloads.empty()) break;
+        delete b;
+        levels_.pop_back();
+    }
+    if (levels_.empty()) return 0;
+    const size_t k = std::min(max_levels, levels_.size());
+    Group* g = new Group();
+    g->id = next_group_++;
+    g->first_depth = base_depth_;
+    g->last_depth = base_depth_ + (uint32_t)k - 1;
+    g->stream = rr_++ % nstreams_;
+    size_t ngates = 0;
+    for (size_t i = 0; i < k; i++) {
+        Plan* p = levels_.front();
+        levels_.pop_front();
+        p->in_base = g->in_words;
+        p->out_base = g->out_words;
+        g->in_words += p->in_words.size();
+        g->out_words += p->out_words;
+        g->plans.push_back(p);
+        ngates += p->gate_count();
+        stats_.max_level_gates = std::max<uint64_t>(stats_.max_level_gates, p->gate_count());
+        if (p->gate_count()) stats_.levels++;
+        for (int l = 0; l < 2; l++)
+            if (!p->gates[l].empty()) stats_.launch_sequences++;
+    }
+    // dependences on levels that were launched earlier on another internal stream
+    for (Plan* p : g->plans)
+        for (uint32_t dd : p->dep_depths) {
+            if (dd >= g->first_depth) continue;
+            Group* dg = find_group(dd);
+            if (!dg || dg->state.load(std::memory_order_acquire) == 2 || dg->stream == g->stream) continue;
+            bool have = false;
+            for (auto& e : g->deps) have = have || e == dg->done;
+            if (!have) {
+                g->deps.push_back(dg->done);
+                stats_.cross_stream_waits++;
+            }
+        }
+    base_depth_ += (uint32_t)k;
+    pending_gates_ -= std::min(pending_gates_, ngates);
+    for (Plan* p : g->plans)
+        for (void* st : p->streams) {
+            StreamState& ss = streams_[st];
+            if (ss.open.empty() || ss.open.back() != g->id) ss.open.push_back(g->id);
+        }
+    g->done = std::make_shared<EventHolder>(be_);
+    live_.push_back(g);
+    stats_.groups++;
+    if (threaded_) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            queue_.push_back(g);
+        }
+        cv_.notify_one();
+        return 0;
+    }
+    be_->bind_thread();
+    launch(g);
+    return 0;       // a launch error surfaces at the next Synchronize / StreamQuery
+}
+
+inline void DeviceSched::worker_loop()
+{
+    be_->bind_thread();
+    for (;;) {
+        Group* g;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            if (queue_.empty()) return;
+            g = queue_.front();
+            queue_.pop_front();
+            busy_ = true;
+        }
+        launch(g);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            busy_ = false;
+        }
+        cv_idle_.notify_all();
+    }
+}
+
+inline int DeviceSched::launch(Group* g)
+{
+    uint64_t ns = 0;
+    struct Add { std::atomic<uint64_t>& a; uint64_t& n; ~Add() { a += n; } } add{stats_.launch_ns, ns};
+    ScopedNs timer(&ns);
+    int rc = 0;
+    const int s = g->stream;
+    auto step = [&](int r) {
+        if (r && !rc) {
+            rc = r;
+            g->error_text = be_->error_text();
+        }
+        return !rc;
+    };
+    step(be_->event_create(&g->done->ev));
+    for (auto& e : g->deps)
+        if (e->ev && rc == 0) step(be_->stream_wait(s, e->ev));
+    if (rc == 0 && g->in_words) {
+        const size_t bytes = g->in_words * 4;
+        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_in, &g->pin_in_cap)) &&
+            step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_in, &g->dev_in_cap))) {
+            for (Plan* p : g->plans)
+                if (!p->in_words.empty())
+                    memcpy((uint32_t*)g->pin_in + p->in_base, p->in_words.data(), p->in_words.size() * 4);
+            step(be_->h2d(s, g->dev_in, g->pin_in, bytes));
+        }
+    }
+    if (rc == 0 && g->out_words) {
+        const size_t bytes = g->out_words * 4;
+        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_out, &g->pin_out_cap)))
+            step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_out, &g->dev_out_cap));
+    }
+    for (Plan* p : g->plans) {
+        if (rc) break;
+        if (!p->uploads.empty()) step(be_->copy_ctxts(s, p->uploads.data(), p->uploads.size(), g->dev_in + p->in_base, true));
+        for (int l = 0; l < 2 && !rc; l++)
+            if (!p->gates[l].empty()) step(be_->run_gates(s, l, p->gates[l].data(), p->gates[l].size()));
+        if (!rc && !p->downloads.empty())
+            step(be_->copy_ctxts(s, p->downloads.data(), p->downloads.size(), g->dev_out + p->out_base, false));
+    }
+    if (rc == 0 && g->out_words) step(be_->d2h(s, g->pin_out, g->dev_out, g->out_words * 4));
+    if (g->done->ev) {
+        const int r = be_->event_record(s, g->done->ev);
+        if (r && !rc) {
+            rc = r;
+            g->error_text = be_->error_text();
+        }
+    }
+    g->error = rc;
+    g->state.store(1, std::memory_order_release);
+    return rc;
+}
+
+// the group's event has completed: hand results to the host ciphertexts, recycle everything
+inline int DeviceSched::retire(Group* g)
+{
+    if (g->state.load(std::memory_order_acquire) == 2) return 0;
+    ScopedNs timer(&stats_.retire_ns);
+    int rc = g->error;
+    if (rc) {
+        sticky_error_ = rc;
+        err_ = g->error_text;
+    }
+    for (Plan* p : g->plans) {
+        for (const Delivery& dl : p->deliveries) {
+            cufhe_amd_ctxt* c = dl.c;
+            if (c->host_token != dl.token) continue;          // superseded by a newer result
+            if (c->host && !rc)
+                memcpy(c->host, (const uint32_t*)g->pin_out + p->out_base + dl.slot, (size_t)be_->words(c->level) * 4);
+            c->host_dev = -1;
+        }
+        // an upload snapshot lives in this level's staging copy: keep it only for inputs that were re-used
+        for (size_t i = 0; i < p->uploads.size(); i++) {
+            cufhe_amd_ctxt::PerDev& pd = p->upload_ctxts[i]->d[device_];
+            if (pd.snap_plan != (void*)p || pd.snap_off != p->uploads[i].slot) continue;
+            if (pd.snap_hits > 0 && pd.snap_version == pd.version) {
+                const uint32_t* w = p->in_words.data() + pd.snap_off;
+                pd.snap_own.assign(w, w + be_->words(p->uploads[i].level));
+                pd.snap_owned = true;
+            }
+            pd.snap_plan = nullptr;
+        }
+        for (cufhe_amd_ctxt* c : p->touched) owner_->ctxt_unref(c);
+        delete p;
+    }
+    g->plans.clear();
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (g->pin_in) pinned_cache_.push_back({g->pin_in, g->pin_in_cap});
+        if (g->pin_out) pinned_cache_.push_back({g->pin_out, g->pin_out_cap});
+        if (g->dev_in) dev_cache_.push_back({g->dev_in, g->dev_in_cap});
+        if (g->dev_out) dev_cache_.push_back({g->dev_out, g->dev_out_cap});
+    }
+    g->deps.clear();
+    g->state.store(2, std::memory_order_release);
+    while (!live_.empty() && live_.front()->state.load(std::memory_order_acquire) == 2) {
+        delete live_.front();
+        live_.pop_front();
+    }
+    return rc;
+}
+
+inline int DeviceSched::synchronize()
+{
+    if (int rc = flush()) return rc;
+    wait_worker_idle();
+    be_->bind_thread();
+    int rc = 0;
+    for (;;) {      // retire() may delete groups: look the next one up afresh every time
+        Group* g = nullptr;
+        for (Group* x : live_)
+            if (x->state.load(std::memory_order_acquire) != 2) {
+                g = x;
+                break;
+            }
+        if (!g) break;
+        if (g->done->ev && !g->error)
+            if (int r = be_->event_sync(g->done->ev)) {
+                rc = rc ? rc : r;
+                err_ = be_->error_text();
+            }
+        if (int r = retire(g)) rc = rc ? rc : r;
+    }
+    if (sticky_error_ && !rc) rc = sticky_error_;
+    sticky_error_ = 0;
+    return rc;
+}
+
+inline int DeviceSched::stream_query(void* stream)
+{
+    auto it = streams_.find(stream);
+    if (it == streams_.end()) return 1;
+    StreamState& ss = it->second;                 // references survive a rehash, iterators do not
+    if (ss.max_depth >= base_depth_)
+        if (int rc = flush()) return rc;          // it can only complete once it has been launched
+    be_->bind_thread();
+    size_t keep = 0;
+    int busy = 0;
+    for (uint64_t id : ss.open) {
+        Group* g = nullptr;
+        for (Group* x : live_)
+            if (x->id == id) g = x;
+        if (!g || g->state.load(std::memory_order_acquire) == 2) continue;
+        bool complete = false;
+        if (g->state.load(std::memory_order_acquire) == 1) {
+            if (g->error || !g->done->ev) complete = true;
+            else {
+                const int q = be_->event_query(g->done->ev);
+                if (q < 0) return fail(q, be_->error_text());
+                complete = q == 1;
+            }
+        }
+        if (complete) {
+            if (int rc = retire(g)) return rc;
+        } else {
+            ss.open[keep++] = id;
+            busy = 1;
+        }
+    }
+    ss.open.resize(keep);
+    if (busy) return 0;
+    if (sticky_error_) {
+        const int rc = sticky_error_;
+        sticky_error_ = 0;
+        return rc;
+    }
+    streams_.erase(stream);
+    return 1;
+}
+
+}  // namespace sched
+}  // namespace cufhe_amd

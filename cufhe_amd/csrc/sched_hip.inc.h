@@ -1,0 +1,338 @@
+// sched_hip.inc.h -- HIP device layer of the stream scheduler (sched_core.h) and the C ABI of the
+// reference's per-gate API (included by capi.hip).
+//
+// One DeviceSched per GPU; each owns a few internal non-blocking HIP streams (independent flushes
+// overlap, dependent ones are ordered by events) and a worker thread that turns flushed dependence
+// levels into launches.  Ciphertext traffic is batched per flush: inputs are gathered into one pinned
+// block, moved with one H2D copy and scattered to the ciphertexts' device buffers by a kernel before
+// the level that reads them; results travel the other way and land in `tlwehost` when completion is
+// observed (Synchronize / StreamQuery), as in the reference (src/cufhe_gates_gpu.cu:148-158).
+
+namespace {
+
+long g_sched_streams = 4;        // internal HIP streams per device
+long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
+long g_sched_level_gates = 2048; // a dependence level this full is launched at once
+long g_sched_total_gates = 32768;
+
+class HipBackend : public sched::Backend {
+   public:
+    explicit HipBackend(int device) : device_(device) {}
+    void bind_thread() override { (void)hipSetDevice(device_ + g_device_base); }
+    int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
+    int words(int level) override { return level ? kLvl1Words : kLvl0Words; }
+    int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
+    int free_device(void* p) override { return chk(hipFree(p), "hipFree"); }
+    int alloc_pinned(size_t bytes, void** p) override { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
+    int free_pinned(void* p) override { return chk(hipHostFree(p), "hipHostFree"); }
+    int h2d(int s, void* dst, const void* src, size_t bytes) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        return chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync H2D");
+    }
+    int d2h(int s, void* dst, const void* src, size_t bytes) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        return chk(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st), "hipMemcpyAsync D2H");
+    }
+    int copy_ctxts(int s, const sched::CopyRec* recs, size_t n, uint32_t* staging, bool to_ctxt) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        DeviceState& ds = g_dev[device_];
+        for (int level = 0; level < 2; level++) {     // one lincomb (COPY) launch per ciphertext kind
+            std::vector<LinDesc> d;
+            for (size_t i = 0; i < n; i++)
+                if (recs[i].level == level) {
+                    uint32_t* slot = staging + recs[i].slot;
+                    if (to_ctxt) d.push_back({slot, slot, recs[i].dev, 1, 0, 0u, 0u});
+                    else d.push_back({recs[i].dev, recs[i].dev, slot, 1, 0, 0u, 0u});
+                }
+            if (d.empty()) continue;
+            // the stream's workspace is reused from offset 0 by every launch sequence: the descriptor
+            // copy of the next sequence is ordered behind the kernels of this one
+            Scratch sc;
+            if (int rc = open_scratch(ds, st, d.size() * sizeof(LinDesc) + 4096, &sc)) return keep(rc);
+            LinDesc* dd;
+            if (int rc = upload_descs(ds, sc, d, &dd)) return keep(rc);
+            if (int rc = launch_lincomb(st, dd, d.size(), level ? kLvl1Words : kLvl0Words)) return keep(rc);
+        }
+        return 0;
+    }
+    int run_gates(int s, int level, const sched::GateRef* g, size_t n) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        return keep(::run_gates(device_, (void*)st, level, n, [&](size_t i) { return g[i]; }));
+    }
+    int event_create(void** ev) override
+    {
+        hipEvent_t e;
+        if (int rc = chk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return rc;
+        *ev = (void*)e;
+        return 0;
+    }
+    int event_destroy(void* ev) override { return chk(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+    int event_record(int s, void* ev) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        return chk(hipEventRecord((hipEvent_t)ev, st), "hipEventRecord");
+    }
+    int event_query(void* ev) override
+    {
+        const hipError_t e = hipEventQuery((hipEvent_t)ev);
+        if (e == hipSuccess) return 1;
+        if (e == hipErrorNotReady) return 0;
+        return chk(e, "hipEventQuery");
+    }
+    int event_sync(void* ev) override { return chk(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"); }
+    int stream_wait(int s, void* ev) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        return chk(hipStreamWaitEvent(st, (hipEvent_t)ev, 0), "hipStreamWaitEvent");
+    }
+    std::string error_text() override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return err_;
+    }
+    // the device must be idle: drop the internal streams (and their workspaces)
+    void destroy_streams()
+    {
+        bind_thread();
+        for (hipStream_t st : st_) {
+            DeviceState& ds = g_dev[device_];
+            {
+                std::lock_guard<std::mutex> lk(ds.staging_mu);
+                auto it = ds.workspaces.find(st);
+                if (it != ds.workspaces.end()) {
+                    (void)hipFree(it->second.base);
+                    ds.workspaces.erase(it);
+                }
+            }
+            (void)hipStreamDestroy(st);
+        }
+        st_.clear();
+    }
+
+   private:
+    int chk(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return 0;
+        std::lock_guard<std::mutex> lk(mu_);
+        err_ = std::string(what) + ": " + hipGetErrorString(e);
+        return -2;
+    }
+    int keep(int rc)       // the launch helpers report through the calling thread's g_err
+    {
+        if (rc) {
+            std::lock_guard<std::mutex> lk(mu_);
+            err_ = g_err;
+        }
+        return rc;
+    }
+    int stream(int s, hipStream_t* out)
+    {
+        std::lock_guard<std::mutex> lk(st_mu_);
+        while ((int)st_.size() <= s) {
+            hipStream_t st;
+            if (int rc = chk(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate")) return rc;
+            st_.push_back(st);
+        }
+        *out = st_[s];
+        return 0;
+    }
+    int device_;
+    std::vector<hipStream_t> st_;
+    std::mutex mu_, st_mu_;
+    std::string err_;
+};
+
+// The scheduler of the current SetGPUNum generation.  It is created on first use and lives until the
+// GPU count (or device_base) changes; a scheduler that still owns live ciphertexts at that point is
+// parked instead of destroyed, so that those ciphertexts can still be released.  Nothing is torn down
+// from a static destructor: at process exit the HIP runtime may already be gone.
+sched::Scheduler* g_scheduler = nullptr;
+std::vector<HipBackend*> g_sched_backends;
+std::vector<sched::Scheduler*> g_parked;
+std::unordered_map<cufhe_amd_ctxt*, sched::Scheduler*> g_ctxt_owner;
+std::mutex g_sched_mu;     // the reference API is single-issuer; this only guards against misuse
+
+sched::Scheduler* scheduler()
+{
+    if (!g_scheduler) {
+        g_sched_backends.clear();
+        g_scheduler = new sched::Scheduler(g_gpu_num, g_sched_threads != 0, [](int d) {
+            HipBackend* b = new HipBackend(d);
+            g_sched_backends.push_back(b);
+            return b;
+        });
+        for (int d = 0; d < g_gpu_num; d++) {
+            g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
+            g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
+        }
+    }
+    return g_scheduler;
+}
+
+bool sched_active() { return g_scheduler != nullptr; }
+
+int sched_synchronize_all()
+{
+    if (!g_scheduler) return 0;
+    if (int rc = g_scheduler->synchronize_all()) {
+        for (int d = 0; d < g_scheduler->gpu_num(); d++)
+            if (!g_scheduler->dev(d).error_text().empty()) return fail(rc, g_scheduler->dev(d).error_text());
+        return fail(rc, "scheduler error");
+    }
+    return 0;
+}
+
+// CleanUp: everything recorded completes, cached staging buffers and the internal streams go; the
+// scheduler itself (ciphertext slabs, workers) stays for the ciphertexts that outlive CleanUp.
+void sched_quiesce()
+{
+    if (!g_scheduler) return;
+    (void)g_scheduler->synchronize_all();
+    for (int d = 0; d < g_scheduler->gpu_num(); d++) {
+        g_scheduler->dev(d).backend()->bind_thread();
+        g_scheduler->dev(d).release_buffers();
+        if (g_scheduler->live_ctxts() == 0) g_scheduler->dev(d).release_slabs();
+    }
+    for (HipBackend* b : g_sched_backends) b->destroy_streams();
+}
+
+// SetGPUNum / device_base change: the next use builds a scheduler for the new device set
+void sched_retire_generation()
+{
+    if (!g_scheduler) return;
+    sched_quiesce();
+    if (g_scheduler->live_ctxts() == 0) delete g_scheduler;
+    else g_parked.push_back(g_scheduler);
+    g_scheduler = nullptr;
+    g_sched_backends.clear();
+}
+
+int sched_error(sched::DeviceSched& ds, int rc) { return fail(rc, ds.error_text().empty() ? "scheduler error" : ds.error_text()); }
+
+}  // namespace
+
+extern "C" {
+
+int cufhe_amd_ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out)
+{
+    if (level != 0 && level != 1) return fail(-1, "level must be 0 or 1");
+    if (!host_words || !out) return fail(-1, "null pointer");
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    sched::Scheduler* S = scheduler();
+    std::string err;
+    if (int rc = S->ctxt_create(level, host_words, out, &err)) return fail(rc, err);
+    g_ctxt_owner[*out] = S;
+    return 0;
+}
+
+int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
+{
+    if (!c) return 0;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    auto it = g_ctxt_owner.find(c);
+    if (it == g_ctxt_owner.end()) return fail(-1, "unknown ciphertext handle");
+    sched::Scheduler* S = it->second;
+    g_ctxt_owner.erase(it);
+    S->ctxt_destroy(c);       // no flush, no wait: the buffers are recycled when the last gate naming them retires
+    return 0;
+}
+
+uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)
+{
+    if (!c || device < 0 || device >= (int)c->d.size()) return nullptr;
+    return c->d[device].dev;
+}
+
+static int sched_check_ctxt(sched::Scheduler* S, cufhe_amd_ctxt* c)
+{
+    auto it = g_ctxt_owner.find(c);
+    if (it == g_ctxt_owner.end()) return fail(-1, "unknown ciphertext handle");
+    if (it->second != S) return fail(-1, "ciphertext was created before SetGPUNum changed the GPU set");
+    return 0;
+}
+
+int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
+                           cufhe_amd_ctxt* in0, cufhe_amd_ctxt* in1, cufhe_amd_ctxt* in2)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (op < 0 || op >= CUFHE_AMD_NUM_OPS) return fail(-1, "unknown gate op");
+    if (!out || !in0) return fail(-1, "null ciphertext");
+    const bool three = op == CUFHE_AMD_MUX || op == CUFHE_AMD_NMUX;
+    const bool one = op == CUFHE_AMD_NOT || op == CUFHE_AMD_COPY;
+    if (!one && !in1) return fail(-1, "gate needs a second operand");
+    if (three && !in2) return fail(-1, "mux needs a third operand");
+    cufhe_amd_ctxt* ins[3] = {in0, one ? nullptr : in1, three ? in2 : nullptr};
+    sched::Scheduler* S = scheduler();
+    if (int rc = sched_check_ctxt(S, out)) return rc;
+    for (cufhe_amd_ctxt* c : ins) {
+        if (!c) continue;
+        if (int rc = sched_check_ctxt(S, c)) return rc;
+        if (c->level != out->level) return fail(-1, "operands of one gate must have the same level");
+    }
+    const DeviceState& ds = g_dev[device];
+    if (!ds.keys_ready && !ds.keys2_ready && !one) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins)) return sched_error(S->dev(device), rc);
+    return 0;
+}
+
+/* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207) in issue order.
+ * to_device != 0: tlwehost -> device buffer; else device buffer -> tlwehost, visible after
+ * Synchronize / StreamQuery like a gate result. */
+int cufhe_amd_enqueue_copy(int device, void* stream, cufhe_amd_ctxt* c, int to_device)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!c) return fail(-1, "null ciphertext");
+    sched::Scheduler* S = scheduler();
+    if (int rc = sched_check_ctxt(S, c)) return rc;
+    if (int rc = S->dev(device).record_copy(stream, c, to_device != 0)) return sched_error(S->dev(device), rc);
+    return 0;
+}
+
+int cufhe_amd_flush(int device)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!g_scheduler) return 0;
+    if (int rc = g_scheduler->dev(device).flush()) return sched_error(g_scheduler->dev(device), rc);
+    return 0;
+}
+
+int cufhe_amd_sched_stream_query(int device, void* stream)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!g_scheduler) return 1;
+    const int q = g_scheduler->dev(device).stream_query(stream);
+    if (q < 0) return sched_error(g_scheduler->dev(device), q);
+    return q;
+}
+
+int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!out) return fail(-1, "null");
+    memset(out, 0, sizeof(*out));
+    if (!g_scheduler) return 0;
+    sched::Stats& s = g_scheduler->dev(device).stats();
+    out->gates = s.gates; out->groups = s.groups; out->levels = s.levels; out->launch_sequences = s.launch_sequences;
+    out->uploads = s.uploads; out->uploads_shared = s.uploads_shared; out->downloads = s.downloads;
+    out->forced_syncs = s.forced_syncs; out->max_level_gates = s.max_level_gates; out->cross_stream_waits = s.cross_stream_waits;
+    out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
+    if (reset) s = sched::Stats();
+    return 0;
+}
+
+}  // extern "C"

@@ -103,15 +103,34 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c);
 uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
 /* Nand(out, in0, in1, st) ... NMux, Not, Copy (copying != 0: src/cufhe_gates_gpu.cu:148-158,
  * inputs taken from tlwehost, result delivered to out's tlwehost) and gNand ... (copying == 0:
- * :160-167, device buffers only).  The gate is recorded; recorded gates of a device run as
- * one batch at Synchronize / StreamQuery / dependence / 2048 gates.  Stream order, output
- * aliasing and completion semantics are those of the reference (see csrc/sched.inc.h). */
+ * :160-167, device buffers only).  The gate is RECORDED with its data dependences; the recorded
+ * program of a device is launched level by level (all gates whose operands are ready: one
+ * blind-rotate + one key-switch launch per level) at Synchronize / StreamQuery / cufhe_amd_flush,
+ * or as soon as a level holds 2048 gates.  Stream order, output aliasing, shared inputs and
+ * completion semantics are those of the reference (see cufhe_amd/csrc/sched_core.h).
+ * cufhe_amd_ctxt_destroy never waits: buffers are recycled when the last recorded gate naming
+ * them has retired. */
 int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
                            cufhe_amd_ctxt* in0, cufhe_amd_ctxt* in1, cufhe_amd_ctxt* in2);
 /* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207), ordered with the recorded gates */
 int cufhe_amd_enqueue_copy(int device, void* stream, cufhe_amd_ctxt* c, int to_device);
 int cufhe_amd_flush(int device);                        /* launch what is recorded, do not wait */
 int cufhe_amd_sched_stream_query(int device, void* stream);  /* scheduler half of StreamQuery */
+/* what the scheduler did (no reference counterpart; the reference launches per gate,
+ * src/bootstrap_gpu.cu:834-1292) */
+typedef struct cufhe_amd_sched_stats {
+    uint64_t gates;              /* gates recorded */
+    uint64_t groups;             /* flushes handed to the device */
+    uint64_t levels;             /* dependence levels launched */
+    uint64_t launch_sequences;   /* blind-rotate + key-switch launch pairs */
+    uint64_t uploads, uploads_shared, downloads;   /* ciphertext copies; _shared = unchanged inputs not copied again */
+    uint64_t forced_syncs;       /* a result had to reach tlwehost before a gate could be recorded */
+    uint64_t max_level_gates;
+    uint64_t cross_stream_waits; /* event dependences between flushes on different internal streams */
+    uint64_t record_ns, retire_ns;  /* host time on the issuing thread: recording gates, delivering results */
+    uint64_t launch_ns;             /* host time on the device's launch worker */
+} cufhe_amd_sched_stats;
+int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 
 /* ---- pieces of the path (TRLWE-level primitives and parity hooks) ----
  * BootstrapTLWE2TRLWE (src/bootstrap_gpu.cu:806-815): tlwe0[count][n+1] -> acc[count][2N]
@@ -164,7 +183,12 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
  * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in
- * the C++ shim) runs through the N = 2048 path. */
+ * the C++ shim) runs through the N = 2048 path.
+ * "sched_streams" (default 4): internal HIP streams per device over which independent flushes of the
+ * per-gate API overlap; "sched_threads" (default 1): one launch worker thread per device (0: launches
+ * happen on the issuing thread).  Both before the first ciphertext is created.
+ * "sched_level_gates" (default 2048) / "sched_total_gates" (default 32768): a dependence level this
+ * full is launched at once / bound on the recorded program. */
 int cufhe_amd_set_option(const char* key, long value);
 
 /* ---- N = 2048 ring, 64-bit torus (BASELINE.json configs[4]; lvl2 / lvl02 / lvl20) ----

@@ -80,6 +80,7 @@ void Chained(std::mt19937& eng)
         pa[i] = eng() & 1; pb[i] = eng() & 1; pc[i] = eng() & 1;
         encrypt(a[i], pa[i]); encrypt(b[i], pb[i]); encrypt(c[i], pc[i]);
     }
+    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
     for (int i = 0; i < kNumTests; i++) {
         Stream s = st[i % kNumSMs];
         Nand(a[i], a[i], b[i], s); pa[i] = 1 - pa[i] * pb[i];
@@ -91,7 +92,12 @@ void Chained(std::mt19937& eng)
     Synchronize();
     int bad = 0;
     for (int i = 0; i < kNumTests; i++) bad += decrypt(a[i]) != pa[i];
-    std::printf("chained in-place gates: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, kNumTests);
+    // five dependence levels, however the 64 chains were interleaved: not 320 one-gate launches
+    cufhe_amd_sched_stats stats;
+    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
+    if (stats.launch_sequences > 6) bad++;
+    std::printf("chained in-place gates: %s (%d/%d failures, %llu launch sequences for %llu gates)\n", bad ? "FAIL" : "PASS", bad,
+                kNumTests, (unsigned long long)stats.launch_sequences, (unsigned long long)stats.gates);
     g_failures += bad;
     for (int i = 0; i < kNumSMs; i++) st[i].Destroy();
     delete[] st;
@@ -169,6 +175,7 @@ void RippleAdders(std::mt19937& eng)
         for (int k = 0; k < kBits; k++) { encrypt(a[i * kBits + k], (va[i] >> k) & 1); encrypt(b[i * kBits + k], (vb[i] >> k) & 1); }
         encrypt(carry[i], 0);
     }
+    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
     for (int k = 0; k < kBits; k++)
         for (int i = 0; i < kAdders; i++) {
             Ctxt<P>&x = a[i * kBits + k], &y = b[i * kBits + k], &s = sum[i * kBits + k], &c = carry[i];
@@ -186,9 +193,45 @@ void RippleAdders(std::mt19937& eng)
         got |= (unsigned)decrypt(carry[i]) << kBits;
         bad += got != va[i] + vb[i];
     }
-    std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums)\n", bad ? "FAIL" : "PASS", bad, kAdders);
+    cufhe_amd_sched_stats stats;
+    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
+    if (stats.launch_sequences > 40) bad++;
+    std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums, %llu launch sequences)\n",
+                bad ? "FAIL" : "PASS", bad, kAdders, (unsigned long long)stats.launch_sequences);
     g_failures += bad;
     for (int i = 0; i < kAdders; i++) st[i].Destroy();
+    delete[] st;
+}
+
+// BASELINE configs[2] at full size on one GPU, as the reference's harness runs it (test/test_util.h:29-94):
+// 32 768 mixed AND / OR / XOR / NAND gates round-robin over 256 streams, Synchronize, decrypt all.
+void MixedAtSize(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl0param;
+    const int kGates = 32768, kStreams = 256;
+    std::vector<Ctxt<P>> a(kGates), b(kGates), o(kGates);
+    std::vector<uint8_t> pa(kGates), pb(kGates);
+    Stream* st = new Stream[kStreams];
+    for (int i = 0; i < kStreams; i++) st[i].Create();
+    for (int i = 0; i < kGates; i++) { pa[i] = eng() & 1; pb[i] = eng() & 1; encrypt(a[i], pa[i]); encrypt(b[i], pb[i]); }
+    for (int i = 0; i < kGates; i++) {
+        Stream s = st[i % kStreams];
+        switch (i % 4) {
+            case 0: And(o[i], a[i], b[i], s); break;
+            case 1: Or(o[i], a[i], b[i], s); break;
+            case 2: Xor(o[i], a[i], b[i], s); break;
+            default: Nand(o[i], a[i], b[i], s); break;
+        }
+    }
+    Synchronize();
+    int bad = 0;
+    for (int i = 0; i < kGates; i++) {
+        const int exp = i % 4 == 0 ? (pa[i] & pb[i]) : i % 4 == 1 ? (pa[i] | pb[i]) : i % 4 == 2 ? (pa[i] ^ pb[i]) : 1 - (pa[i] & pb[i]);
+        bad += decrypt(o[i]) != exp;
+    }
+    std::printf("32768 mixed gates on 256 streams: %s (%d failures)\n", bad ? "FAIL" : "PASS", bad);
+    g_failures += bad;
+    for (int i = 0; i < kStreams; i++) st[i].Destroy();
     delete[] st;
 }
 
@@ -293,6 +336,7 @@ int main(int argc, char** argv)
     DeviceResident(eng);
     TrlwePrimitives(eng, bk);
     RippleAdders(eng);
+    MixedAtSize(eng);
     Lvl2Gates(eng);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");

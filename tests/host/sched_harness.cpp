@@ -1,0 +1,425 @@
+// sched_harness.cpp -- the stream scheduler (cufhe_amd/csrc/sched_core.h) against a stubbed device layer.
+//
+// The stub is an asynchronous machine with the ordering rules of HIP streams and nothing more:
+// work submitted to one internal stream runs in order, streams are ordered only by events, copies
+// read their source when they EXECUTE, and execution happens at arbitrary later moments (a seeded
+// random interleaving, advanced only when the scheduler queries or waits for an event).  "Gates" are
+// a non-commutative word mixer, executed in random order within a launch -- so a scheduler that puts
+// two dependent gates into one launch, lets a copy overtake a gate, or delivers a stale result fails
+// the comparison with a plain in-order interpreter of the reference API's semantics
+// (include/cufhe_gpu.cuh:193-313, src/cufhe_gates_gpu.cu:148-167).
+//
+// Usage: sched_harness <seeds> <gpus> <threaded 0|1>      prints one line per check, "ALL PASS" at the end.
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+
+#include "../../cufhe_amd/csrc/sched_core.h"
+
+using namespace cufhe_amd::sched;
+
+static const int kWords[2] = {37, 53};      // toy ciphertext sizes (odd on purpose)
+enum { OP_NOT = 12, OP_COPY = 13, OP_MUX = 10, OP_NMUX = 11 };
+
+static inline uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static uint32_t mix(int op, uint32_t a, uint32_t b, uint32_t c, uint32_t w)
+{
+    uint32_t v = a * 0x9E3779B1u + rotl(b, 5) * 0x85EBCA77u + rotl(c, 11) * 0xC2B2AE3Du + (uint32_t)op * 0x27D4EB2Fu + w;
+    return v ^ (a >> 15) ^ (v << 7);
+}
+static void toy_gate(int op, int level, uint32_t* out, const uint32_t* a, const uint32_t* b, const uint32_t* c)
+{
+    std::vector<uint32_t> r(kWords[level]);
+    for (int w = 0; w < kWords[level]; w++) r[w] = mix(op, a[w], b ? b[w] : 0u, c ? c[w] : 0u, (uint32_t)w);
+    memcpy(out, r.data(), r.size() * 4);
+}
+
+struct FakeEvent { uint64_t submitted = 0, completed = 0; };
+
+class FakeBackend : public Backend {
+   public:
+    FakeBackend(int nstreams, uint64_t seed) : q_(nstreams), rng_(seed) {}
+    void bind_thread() override {}
+    int num_streams() override { return (int)q_.size(); }
+    int words(int level) override { return kWords[level]; }
+    int alloc_device(size_t bytes, void** p) override { *p = calloc(1, bytes); return 0; }
+    int free_device(void* p) override { free(p); return 0; }
+    int alloc_pinned(size_t bytes, void** p) override { *p = malloc(bytes); memset(*p, 0xAB, bytes); return 0; }
+    int free_pinned(void* p) override { free(p); return 0; }
+    int h2d(int s, void* dst, const void* src, size_t bytes) override { push(s, [=] { memcpy(dst, src, bytes); }); return 0; }
+    int d2h(int s, void* dst, const void* src, size_t bytes) override { push(s, [=] { memcpy(dst, src, bytes); }); return 0; }
+    int copy_ctxts(int s, const CopyRec* recs, size_t n, uint32_t* staging, bool to_ctxt) override
+    {
+        std::vector<CopyRec> r(recs, recs + n);
+        push(s, [=] {
+            for (const CopyRec& c : r) {
+                if (to_ctxt) memcpy(c.dev, staging + c.slot, kWords[c.level] * 4);
+                else memcpy(staging + c.slot, c.dev, kWords[c.level] * 4);
+            }
+        });
+        return 0;
+    }
+    int run_gates(int s, int level, const GateRef* g, size_t n) override
+    {
+        launches++;
+        std::vector<GateRef> v(g, g + n);
+        std::shuffle(v.begin(), v.end(), rng_);
+        push(s, [=] {
+            for (const GateRef& r : v) toy_gate(r.op, level, r.out, r.in0, r.in1, r.in2);
+        });
+        return 0;
+    }
+    int event_create(void** ev) override { *ev = new FakeEvent(); return 0; }
+    int event_destroy(void* ev) override { delete (FakeEvent*)ev; return 0; }
+    int event_record(int s, void* ev) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = (FakeEvent*)ev;
+        e->submitted++;
+        q_[s].push_back({[e] { e->completed++; }, nullptr, 0});
+        return 0;
+    }
+    int stream_wait(int s, void* ev) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = (FakeEvent*)ev;
+        q_[s].push_back({[] {}, e, e->submitted});
+        return 0;
+    }
+    int event_query(void* ev) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        const int n = (int)(rng_() % 4);
+        for (int i = 0; i < n; i++) pump_one();
+        FakeEvent* e = (FakeEvent*)ev;
+        return e->completed == e->submitted ? 1 : 0;
+    }
+    int event_sync(void* ev) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = (FakeEvent*)ev;
+        while (e->completed != e->submitted)
+            if (!pump_one()) { fprintf(stderr, "stub device: event can never complete (missing dependence?)\n"); abort(); }
+        return 0;
+    }
+    std::string error_text() override { return "stub"; }
+    void drain()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        while (pump_one()) {}
+    }
+    uint64_t launches = 0;
+
+   private:
+    struct Op { std::function<void()> fn; FakeEvent* wait; uint64_t target; };
+    void push(int s, std::function<void()> fn)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_[s].push_back({std::move(fn), nullptr, 0});
+    }
+    bool pump_one()
+    {
+        std::vector<int> ready;
+        for (size_t s = 0; s < q_.size(); s++)
+            if (!q_[s].empty() && (!q_[s].front().wait || q_[s].front().wait->completed >= q_[s].front().target)) ready.push_back((int)s);
+        if (ready.empty()) return false;
+        const int s = ready[rng_() % ready.size()];
+        Op op = std::move(q_[s].front());
+        q_[s].pop_front();
+        op.fn();
+        return true;
+    }
+    std::mutex mu_;
+    std::vector<std::deque<Op>> q_;
+    std::mt19937_64 rng_;
+};
+
+// ---- in-order interpreter of the reference semantics ----
+struct ModelCtxt {
+    int level;
+    std::vector<uint32_t> host;                 // what tlwehost will eventually hold
+    std::vector<std::vector<uint32_t>> dev;     // per device
+    std::vector<bool> dev_defined;
+};
+
+struct Test {
+    int G;
+    Scheduler* S;
+    std::vector<FakeBackend*> be;
+    std::mt19937_64 rng;
+    struct C { cufhe_amd_ctxt* h; std::vector<uint32_t> host; ModelCtxt m; void* last_host_writer_stream = nullptr; bool alive = true; };
+    std::vector<C*> ct;
+    int failures = 0;
+
+    Test(int gpus, bool threaded, uint64_t seed, int nstreams) : G(gpus), rng(seed)
+    {
+        S = new Scheduler(gpus, threaded, [&](int d) {
+            FakeBackend* b = new FakeBackend(nstreams, seed * 131 + d);
+            be.push_back(b);
+            return b;
+        });
+    }
+    ~Test()
+    {
+        S->synchronize_all();
+        for (C* c : ct) { if (c->alive) S->ctxt_destroy(c->h); delete c; }
+        delete S;
+    }
+    C* make(int level)
+    {
+        C* c = new C();
+        c->host.resize(kWords[level]);
+        for (auto& w : c->host) w = (uint32_t)rng();
+        std::string err;
+        if (S->ctxt_create(level, c->host.data(), &c->h, &err)) { fprintf(stderr, "ctxt_create: %s\n", err.c_str()); abort(); }
+        c->m.level = level;
+        c->m.host = c->host;
+        c->m.dev.assign(G, std::vector<uint32_t>(kWords[level], 0));
+        c->m.dev_defined.assign(G, false);
+        ct.push_back(c);
+        return c;
+    }
+    void gate(int dev, void* st, int op, bool copying, C* out, C* a, C* b, C* c3)
+    {
+        C* ins[3] = {a, b, c3};
+        cufhe_amd_ctxt* hs[3] = {a->h, b ? b->h : nullptr, c3 ? c3->h : nullptr};
+        if (int rc = S->dev(dev).record_gate(st, op, copying, out->h, hs)) { fprintf(stderr, "record_gate rc %d: %s\n", rc, S->dev(dev).error_text().c_str()); abort(); }
+        // model, in issue order
+        if (copying)
+            for (C* i : ins)
+                if (i) { i->m.dev[dev] = i->m.host; i->m.dev_defined[dev] = true; }
+        std::vector<uint32_t> r(kWords[out->m.level]);
+        toy_gate(op, out->m.level, r.data(), a->m.dev[dev].data(), b ? b->m.dev[dev].data() : nullptr, c3 ? c3->m.dev[dev].data() : nullptr);
+        out->m.dev[dev] = r;
+        out->m.dev_defined[dev] = true;
+        if (copying) { out->m.host = r; out->last_host_writer_stream = st; }
+    }
+    void copy(int dev, void* st, C* c, bool to_device)
+    {
+        if (int rc = S->dev(dev).record_copy(st, c->h, to_device)) { fprintf(stderr, "record_copy rc %d\n", rc); abort(); }
+        if (to_device) { c->m.dev[dev] = c->m.host; c->m.dev_defined[dev] = true; }
+        else { c->m.host = c->m.dev[dev]; c->last_host_writer_stream = st; }
+    }
+    void check_host(C* c, const char* when)
+    {
+        if (c->host != c->m.host) {
+            failures++;
+            printf("FAIL host mismatch (%s) ctxt %p level %d\n", when, (void*)c, c->m.level);
+        }
+    }
+    void sync_and_check(bool check_dev)
+    {
+        if (int rc = S->synchronize_all()) { fprintf(stderr, "synchronize rc %d\n", rc); abort(); }
+        for (auto* b : be) b->drain();
+        for (C* c : ct) {
+            if (!c->alive) continue;
+            check_host(c, "after Synchronize");
+            if (check_dev)
+                for (int d = 0; d < G; d++)
+                    if (c->m.dev_defined[d] && memcmp(c->h->d[d].dev, c->m.dev[d].data(), kWords[c->m.level] * 4)) {
+                        failures++;
+                        printf("FAIL device mismatch ctxt %p dev %d\n", (void*)c, d);
+                    }
+        }
+    }
+};
+
+static int random_program(uint64_t seed, int gpus, bool threaded)
+{
+    std::mt19937_64 prng(seed);
+    Test t(gpus, threaded, seed, 1 + (int)(prng() % 4));
+    for (int d = 0; d < gpus; d++) {
+        t.S->dev(d).level_flush_gates = 4 + prng() % 40;     // exercise partial flushes
+        t.S->dev(d).total_flush_gates = 30 + prng() % 200;
+    }
+    const int kStreams = 6;
+    auto stream_handle = [&](int dev, int s) { return (void*)(uintptr_t)(0x1000 + dev * 64 + s); };
+    for (int i = 0; i < 24; i++) t.make(i % 3 == 0 ? 1 : 0);
+    const int steps = 300 + (int)(prng() % 500);
+    auto pick = [&](int level) {
+        for (;;) {
+            Test::C* c = t.ct[prng() % t.ct.size()];
+            if (c->alive && c->m.level == level) return c;
+        }
+    };
+    auto pick_defined = [&](int level, int dev) -> Test::C* {
+        for (int tries = 0; tries < 64; tries++) {
+            Test::C* c = t.ct[prng() % t.ct.size()];
+            if (c->alive && c->m.level == level && c->m.dev_defined[dev]) return c;
+        }
+        return nullptr;
+    };
+    for (int step = 0; step < steps; step++) {
+        const int dev = (int)(prng() % gpus);
+        void* st = stream_handle(dev, (int)(prng() % kStreams));
+        const int level = prng() % 4 == 0 ? 1 : 0;
+        const unsigned r = (unsigned)(prng() % 100);
+        if (r < 40) {                               // copying gate
+            const int kind = (int)(prng() % 10);
+            Test::C* out = pick(level);
+            Test::C* a = prng() % 5 == 0 ? out : pick(level);      // in-place now and then
+            if (kind == 0) t.gate(dev, st, prng() % 2 ? OP_NOT : OP_COPY, true, out, a, nullptr, nullptr);
+            else if (kind <= 2) t.gate(dev, st, prng() % 2 ? OP_MUX : OP_NMUX, true, out, a, pick(level), pick(level));
+            else t.gate(dev, st, (int)(prng() % 10), true, out, a, prng() % 7 == 0 ? a : pick(level), nullptr);
+        } else if (r < 65) {                        // g-gate on device-resident values
+            Test::C *a = pick_defined(level, dev), *b = pick_defined(level, dev), *c3 = pick_defined(level, dev);
+            if (!a || !b || !c3) continue;
+            Test::C* out = prng() % 4 == 0 ? a : pick(level);
+            const int kind = (int)(prng() % 10);
+            if (kind == 0) t.gate(dev, st, OP_NOT, false, out, a, nullptr, nullptr);
+            else if (kind <= 2) t.gate(dev, st, OP_MUX, false, out, a, b, c3);
+            else t.gate(dev, st, (int)(prng() % 10), false, out, a, b, nullptr);
+        } else if (r < 72) {
+            t.copy(dev, st, pick(level), true);
+        } else if (r < 80) {
+            Test::C* c = pick_defined(level, dev);
+            if (c) t.copy(dev, st, c, false);
+        } else if (r < 92) {                        // StreamQuery poll
+            const int q = t.S->dev(dev).stream_query(st);
+            if (q < 0) { fprintf(stderr, "stream_query rc %d\n", q); abort(); }
+            if (q == 1)
+                for (Test::C* c : t.ct)
+                    if (c->alive && c->last_host_writer_stream == st) t.check_host(c, "after StreamQuery");
+        } else if (r < 95) {                        // Synchronize, then the host may edit ciphertexts
+            t.sync_and_check(true);
+            for (int k = 0; k < 3; k++) {
+                Test::C* c = t.ct[prng() % t.ct.size()];
+                if (!c->alive) continue;
+                for (auto& w : c->host) w = (uint32_t)prng();
+                c->m.host = c->host;
+            }
+        } else if (r < 98) {                        // a ciphertext goes out of scope while work on it is recorded
+            Test::C* c = t.ct[prng() % t.ct.size()];
+            if (!c->alive) continue;
+            t.S->ctxt_destroy(c->h);
+            c->alive = false;
+            t.make(c->m.level);
+        } else {
+            t.S->dev(dev).flush();
+        }
+    }
+    t.sync_and_check(true);
+    return t.failures;
+}
+
+// ---- shaped programs with launch-count expectations ----
+struct Shape { const char* name; uint64_t launch_sequences, levels, gates, groups, uploads, uploads_shared; int failures; };
+
+static Shape chained(bool threaded)
+{
+    // test/test_api_gpu.cu:140-159 as tests/cpp/test_gate_api.cpp Chained(): 64 chains x 5 in-place gates on 8 streams
+    Test t(1, threaded, 7, 4);
+    const int K = 64;
+    std::vector<Test::C*> a, b, c;
+    for (int i = 0; i < K; i++) { a.push_back(t.make(0)); b.push_back(t.make(0)); c.push_back(t.make(0)); }
+    for (int i = 0; i < K; i++) {
+        void* st = (void*)(uintptr_t)(0x100 + i % 8);
+        t.gate(0, st, 0, true, a[i], a[i], b[i], nullptr);
+        t.gate(0, st, 4, true, a[i], a[i], b[i], nullptr);
+        t.gate(0, st, 5, true, a[i], a[i], c[i], nullptr);
+        t.gate(0, st, OP_NOT, true, a[i], a[i], nullptr, nullptr);
+        t.gate(0, st, OP_MUX, true, a[i], a[i], b[i], c[i]);
+    }
+    t.sync_and_check(true);
+    const Stats& s = t.S->dev(0).stats();
+    return {"chained", s.launch_sequences, s.levels, s.gates, s.groups, s.uploads, s.uploads_shared, t.failures};
+}
+
+static Shape ripple(bool threaded)
+{
+    // tests/cpp/test_gate_api.cpp RippleAdders(): 16 x 8-bit ripple-carry adders, one stream each, issued bit by bit
+    Test t(1, threaded, 8, 4);
+    const int A = 16, B = 8;
+    std::vector<Test::C*> x, y, sum, carry, t1, t2;
+    for (int i = 0; i < A * B; i++) { x.push_back(t.make(0)); y.push_back(t.make(0)); sum.push_back(t.make(0)); }
+    for (int i = 0; i < A; i++) { carry.push_back(t.make(0)); t1.push_back(t.make(0)); t2.push_back(t.make(0)); }
+    for (int k = 0; k < B; k++)
+        for (int i = 0; i < A; i++) {
+            void* st = (void*)(uintptr_t)(0x200 + i);
+            Test::C *X = x[i * B + k], *Y = y[i * B + k], *Sm = sum[i * B + k], *Cy = carry[i];
+            t.gate(0, st, 5, true, t1[i], X, Y, nullptr);
+            t.gate(0, st, 5, true, Sm, t1[i], Cy, nullptr);
+            t.gate(0, st, 3, true, t2[i], t1[i], Cy, nullptr);
+            t.gate(0, st, 3, true, t1[i], X, Y, nullptr);
+            t.gate(0, st, 4, true, Cy, t1[i], t2[i], nullptr);
+        }
+    t.sync_and_check(true);
+    const Stats& s = t.S->dev(0).stats();
+    return {"ripple_adders", s.launch_sequences, s.levels, s.gates, s.groups, s.uploads, s.uploads_shared, t.failures};
+}
+
+static Shape intensive(bool threaded)
+{
+    // test/test_intensive.cc:21-128: poll StreamQuery and refill, three inputs shared by every stream
+    Test t(1, threaded, 9, 4);
+    const int kStreams = 200, kRounds = 4;
+    Test::C *in0 = t.make(0), *in1 = t.make(0), *inc = t.make(0);
+    std::vector<Test::C*> out;
+    std::vector<int> round(kStreams, 0);
+    for (int i = 0; i < kStreams; i++) out.push_back(t.make(0));
+    auto st = [](int i) { return (void*)(uintptr_t)(0x300 + i); };
+    for (int i = 0; i < kStreams; i++) t.gate(0, st(i), 0, true, out[i], in0, in1, nullptr);
+    int done = 0;
+    long polls = 0;
+    while (done < kStreams && polls < 100000000) {
+        for (int i = 0; i < kStreams; i++) {
+            polls++;
+            if (round[i] >= kRounds) continue;
+            if (t.S->dev(0).stream_query(st(i)) != 1) continue;
+            t.check_host(out[i], "intensive");
+            if (++round[i] == kRounds) { done++; continue; }
+            if (round[i] % 2) t.gate(0, st(i), OP_MUX, true, out[i], inc, in1, in0);
+            else t.gate(0, st(i), 0, true, out[i], in0, in1, nullptr);
+        }
+    }
+    if (done < kStreams) { t.failures++; printf("FAIL intensive never completed\n"); }
+    t.sync_and_check(true);
+    const Stats& s = t.S->dev(0).stats();
+    return {"intensive", s.launch_sequences, s.levels, s.gates, s.groups, s.uploads, s.uploads_shared, t.failures};
+}
+
+static Shape multi_gpu(bool threaded)
+{
+    // test/test_gate_gpu_multi.cc:36-93: default-constructed streams round-robin the devices
+    // (include/cufhe_gpu.cuh:154-159); every gate must land on its stream's device only
+    const int G = 3, K = 96;
+    Test t(G, threaded, 10, 2);
+    std::vector<Test::C*> a, b, o;
+    for (int i = 0; i < K; i++) { a.push_back(t.make(0)); b.push_back(t.make(0)); o.push_back(t.make(0)); }
+    for (int i = 0; i < K; i++) t.gate(i % G, (void*)(uintptr_t)(0x400 + i), 0, true, o[i], a[i], b[i], nullptr);
+    // a second round consuming results produced on ANOTHER device: the host copy has to land first
+    for (int i = 0; i < K; i++) t.gate((i + 1) % G, (void*)(uintptr_t)(0x400 + i), 5, true, a[i], o[i], b[i], nullptr);
+    t.sync_and_check(true);
+    Shape sh{"multi_gpu", 0, 0, 0, 0, 0, 0, t.failures};
+    for (int d = 0; d < G; d++) {
+        const Stats& s = t.S->dev(d).stats();
+        if (s.gates != 2 * K / G) { sh.failures++; printf("FAIL device %d recorded %llu gates, expected %d\n", d, (unsigned long long)s.gates, 2 * K / G); }
+        sh.launch_sequences += s.launch_sequences; sh.levels += s.levels; sh.gates += s.gates; sh.groups += s.groups;
+        sh.uploads += s.uploads; sh.uploads_shared += s.uploads_shared;
+    }
+    return sh;
+}
+
+int main(int argc, char** argv)
+{
+    const int seeds = argc > 1 ? atoi(argv[1]) : 50;
+    const int gpus = argc > 2 ? atoi(argv[2]) : 2;
+    const bool threaded = argc > 3 ? atoi(argv[3]) != 0 : true;
+    int failures = 0;
+    for (int s = 1; s <= seeds; s++) {
+        const int f = random_program(1000 + s, 1 + (s % gpus), threaded);
+        if (f) printf("FAIL random program seed %d: %d mismatches\n", 1000 + s, f);
+        failures += f;
+    }
+    printf("random programs: %d seeds, %d failures\n", seeds, failures);
+    for (Shape sh : {chained(threaded), ripple(threaded), intensive(threaded), multi_gpu(threaded)}) {
+        printf("SHAPE {\"name\": \"%s\", \"launch_sequences\": %llu, \"levels\": %llu, \"gates\": %llu, \"groups\": %llu, "
+               "\"uploads\": %llu, \"uploads_shared\": %llu, \"failures\": %d}\n",
+               sh.name, (unsigned long long)sh.launch_sequences, (unsigned long long)sh.levels, (unsigned long long)sh.gates,
+               (unsigned long long)sh.groups, (unsigned long long)sh.uploads, (unsigned long long)sh.uploads_shared, sh.failures);
+        failures += sh.failures;
+    }
+    printf("%s\n", failures ? "FAILED" : "ALL PASS");
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,295 @@
+"""The per-gate API (Stream / Ctxt / Nand ... NMux, g-gates, explicit copies) on the GPU, checked
+WORD FOR WORD against the CPU oracle -- not only by decryption -- and by the scheduler's own launch
+counters: dependent gates must be cut into dependence levels, not into 1-gate launches.
+
+Reference programs: test/test_api_gpu.cu:140-159 (chained in-place gates), test/test_gate_gpu.cc:36-91
+and test/test_util.h:29-94 (every gate over many streams), test/test_intensive.cc:21-128 (polling),
+include/cufhe_gpu.cuh:282-313 (g-gates).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+O = ol.OPS.index
+
+
+def _ctxts(api, keys, bits, level, seed):
+    enc = keys.encrypt(bits, level, seed=seed)
+    cts = []
+    for row in enc:
+        c = api.Ctxt(level)
+        c.tlwehost[:] = row
+        cts.append(c)
+    return cts, enc
+
+
+def _host(cts):
+    return np.stack([c.tlwehost.copy() for c in cts])
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_enqueue_gate_words(engine, keys, level):
+    """All 14 ops through cufhe_amd_enqueue_gate on 8 streams: delivered words == oracle."""
+    api = engine.api
+    count = 56
+    rng = np.random.default_rng(60 + level)
+    bits = rng.integers(0, 2, size=(3, count)).astype(np.uint8)
+    ins = [_ctxts(api, keys, bits[i], level, 6100 + 10 * level + i) for i in range(3)]
+    outs = [api.Ctxt(level) for _ in range(count)]
+    sts = [api.Stream() for _ in range(8)]
+    for s in sts:
+        s.Create()
+    fns2 = {"NAND": api.Nand, "NOR": api.Nor, "XNOR": api.Xnor, "AND": api.And, "OR": api.Or, "XOR": api.Xor,
+            "ANDNY": api.AndNY, "ANDYN": api.AndYN, "ORNY": api.OrNY, "ORYN": api.OrYN}
+    ops = np.array([g % 14 for g in range(count)], np.int32)
+    api.sched_stats(reset=True)
+    for g in range(count):
+        name, st = ol.OPS[ops[g]], sts[g % 8]
+        a, b, c = ins[0][0][g], ins[1][0][g], ins[2][0][g]
+        if name in fns2:
+            fns2[name](outs[g], a, b, st)
+        elif name == "MUX":
+            api.Mux(outs[g], a, b, c, st)
+        elif name == "NMUX":
+            api.NMux(outs[g], a, b, c, st)
+        elif name == "NOT":
+            api.Not(outs[g], a, st)
+        else:
+            api.Copy(outs[g], a, st)
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == count and stats.launch_sequences == 1, (stats.gates, stats.launch_sequences)
+    want = keys.gate_batch(ops, level, ins[0][1], ins[1][1], ins[2][1])
+    assert np.array_equal(_host(outs), want), "words delivered through enqueue_gate differ from the oracle"
+    for s in sts:
+        s.Destroy()
+
+
+def test_chained_program_levels_and_words(engine, keys):
+    """test/test_api_gpu.cu:140-159: 64 chains of 5 in-place gates on 8 streams, one Synchronize.
+    Must run as 5 dependence levels (<= 6 launch sequences), whole program == oracle word for word."""
+    api = engine.api
+    K = 64
+    rng = np.random.default_rng(71)
+    bits = rng.integers(0, 2, size=(3, K)).astype(np.uint8)
+    (a, ea), (b, eb), (c, ec) = (_ctxts(api, keys, bits[i], 0, 7100 + i) for i in range(3))
+    sts = [api.Stream() for _ in range(8)]
+    for s in sts:
+        s.Create()
+    api.sched_stats(reset=True)
+    for i in range(K):             # chain by chain: depth-first issue order
+        st = sts[i % 8]
+        api.Nand(a[i], a[i], b[i], st)
+        api.Or(a[i], a[i], b[i], st)
+        api.Xor(a[i], a[i], c[i], st)
+        api.Not(a[i], a[i], st)
+        api.Mux(a[i], a[i], b[i], c[i], st)
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == 5 * K
+    assert stats.launch_sequences <= 6, f"{stats.launch_sequences} launch sequences for a 5-level program"
+    w = keys.gate_batch(O("NAND"), 0, ea, eb)
+    w = keys.gate_batch(O("OR"), 0, w, eb)
+    w = keys.gate_batch(O("XOR"), 0, w, ec)
+    w = keys.gate_batch(O("NOT"), 0, w)
+    w = keys.gate_batch(O("MUX"), 0, w, eb, ec)
+    assert np.array_equal(_host(a), w)
+    for s in sts:
+        s.Destroy()
+
+
+def test_ripple_adders_levels_and_words(engine, keys):
+    """16 8-bit ripple-carry adders issued bit by bit, one stream each (640 dependent gates,
+    tests/cpp/test_gate_api.cpp RippleAdders): <= 40 launch sequences, sums == oracle words."""
+    api = engine.api
+    A, B = 16, 8
+    rng = np.random.default_rng(72)
+    va, vb = rng.integers(0, 256, A), rng.integers(0, 256, A)
+    xb = np.array([[(va[i] >> k) & 1 for k in range(B)] for i in range(A)], np.uint8).ravel()
+    yb = np.array([[(vb[i] >> k) & 1 for k in range(B)] for i in range(A)], np.uint8).ravel()
+    x, ex = _ctxts(api, keys, xb, 0, 7201)
+    y, ey = _ctxts(api, keys, yb, 0, 7202)
+    carry, ecarry = _ctxts(api, keys, np.zeros(A, np.uint8), 0, 7203)
+    sums = [api.Ctxt(0) for _ in range(A * B)]
+    t1 = [api.Ctxt(0) for _ in range(A)]
+    t2 = [api.Ctxt(0) for _ in range(A)]
+    sts = [api.Stream() for _ in range(A)]
+    for s in sts:
+        s.Create()
+    api.sched_stats(reset=True)
+    for k in range(B):
+        for i in range(A):
+            X, Y, S, C, st = x[i * B + k], y[i * B + k], sums[i * B + k], carry[i], sts[i]
+            api.Xor(t1[i], X, Y, st)
+            api.Xor(S, t1[i], C, st)
+            api.And(t2[i], t1[i], C, st)
+            api.And(t1[i], X, Y, st)          # overwrites t1 after its readers
+            api.Or(C, t1[i], t2[i], st)       # in place on the carry
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == 5 * A * B
+    assert stats.launch_sequences <= 40, f"{stats.launch_sequences} launch sequences"
+    # the same program on the oracle, bit by bit (batched over the adders)
+    ex, ey = ex.reshape(A, B, -1), ey.reshape(A, B, -1)
+    wc = ecarry
+    want_sums = np.zeros((A, B, ol.n + 1), np.uint32)
+    for k in range(B):
+        w1 = keys.gate_batch(O("XOR"), 0, ex[:, k], ey[:, k])
+        want_sums[:, k] = keys.gate_batch(O("XOR"), 0, w1, wc)
+        w2 = keys.gate_batch(O("AND"), 0, w1, wc)
+        w1 = keys.gate_batch(O("AND"), 0, ex[:, k], ey[:, k])
+        wc = keys.gate_batch(O("OR"), 0, w1, w2)
+    assert np.array_equal(_host(sums).reshape(A, B, -1), want_sums)
+    assert np.array_equal(_host(carry), wc)
+    got = [sum(int(keys.decrypt(sums[i * B + k].tlwehost, 0)[0]) << k for k in range(B)) +
+           (int(keys.decrypt(carry[i].tlwehost, 0)[0]) << B) for i in range(A)]
+    assert got == [int(va[i] + vb[i]) for i in range(A)]
+    for s in sts:
+        s.Destroy()
+
+
+def test_g_gate_flush_copy_poll_then_copying_gate(engine, keys):
+    """A g-gate result fetched with CtxtCopyD2H and observed through a StreamQuery poll must be what a
+    later copying gate reads (the reference runs D2H then H2D on the stream): words, both ways."""
+    api = engine.api
+    st = api.Stream()
+    st.Create()
+    (a, b, e), enc = _ctxts(api, keys, [1, 0, 1], 0, 7301)
+    c, d = api.Ctxt(0), api.Ctxt(0)
+    api.CtxtCopyH2D(a, st); api.CtxtCopyH2D(b, st)
+    api.gNand(c, a, b, st)                 # c (device only) = NAND(a, b)
+    api.Flush(0)
+    api.CtxtCopyD2H(c, st)                 # its host copy becomes current only through this
+    while not api.StreamQuery(st):
+        pass
+    w_c = keys.gate_batch(O("NAND"), 0, enc[0:1], enc[1:2])
+    assert np.array_equal(c.tlwehost, w_c[0])
+    api.Xor(d, c, e, st)                   # copying gate: must see NAND(a, b), not a stale tlwehost
+    api.Synchronize()
+    assert np.array_equal(d.tlwehost, keys.gate_batch(O("XOR"), 0, w_c, enc[2:3])[0])
+    # a g-gate reading `a` followed, in the same recorded program, by a copying gate whose upload rewrites
+    # a's device buffer from an edited tlwehost: the g-gate must have read the old device value
+    new_a = keys.encrypt([0], 0, seed=7302)
+    f, g = api.Ctxt(0), api.Ctxt(0)
+    api.gOr(f, a, b, st)                   # reads a's device buffer (= enc[0])
+    a.tlwehost[:] = new_a[0]
+    api.And(g, a, e, st)                   # uploads the new a
+    api.CtxtCopyD2H(f, st)
+    api.Synchronize()
+    assert np.array_equal(f.tlwehost, keys.gate_batch(O("OR"), 0, enc[0:1], enc[1:2])[0])
+    assert np.array_equal(g.tlwehost, keys.gate_batch(O("AND"), 0, new_a, enc[2:3])[0])
+    st.Destroy()
+
+
+def test_intensive_polling_shares_inputs(engine, keys):
+    """test/test_intensive.cc:21-128 in small: 64 streams x 4 rounds of Nand / Mux on three SHARED
+    inputs, refilled by polling StreamQuery; every polled result must be the oracle's words, the
+    inputs are uploaded once, and the gates run as a few large launches."""
+    api = engine.api
+    (in0, in1, inc), enc = _ctxts(api, keys, [1, 1, 0], 0, 7401)
+    S, R = 64, 4
+    outs = [api.Ctxt(0) for _ in range(S)]
+    sts = [api.Stream() for _ in range(S)]
+    for s in sts:
+        s.Create()
+    w_nand = keys.gate_batch(O("NAND"), 0, enc[0:1], enc[1:2])[0]
+    w_mux = keys.gate_batch(O("MUX"), 0, enc[2:3], enc[1:2], enc[0:1])[0]
+    api.sched_stats(reset=True)
+    rnd = [0] * S
+    for i in range(S):
+        api.Nand(outs[i], in0, in1, sts[i])
+    done = 0
+    while done < S:
+        for i in range(S):
+            if rnd[i] >= R or not api.StreamQuery(sts[i]):
+                continue
+            assert np.array_equal(outs[i].tlwehost, w_nand if rnd[i] % 2 == 0 else w_mux), (i, rnd[i])
+            rnd[i] += 1
+            if rnd[i] == R:
+                done += 1
+            elif rnd[i] % 2:
+                api.Mux(outs[i], inc, in1, in0, sts[i])
+            else:
+                api.Nand(outs[i], in0, in1, sts[i])
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == S * R and stats.uploads <= 6 and stats.launch_sequences <= 3 * R, \
+        (stats.gates, stats.uploads, stats.launch_sequences)
+    for s in sts:
+        s.Destroy()
+
+
+def test_config2_mixed_32768_per_gate_api_256_streams(engine, keys, oracle):
+    """BASELINE configs[2] at full size on one GPU through the per-gate API: 32 768 mixed
+    AND/OR/XOR/NAND gates round-robin over 256 streams (test/test_util.h:36-62), Synchronize, decrypt
+    every output against the truth table (test/test_util.h:75-94) and compare 64 sampled outputs word
+    for word with the oracle."""
+    api = engine.api
+    count, nst = 32768, 256
+    rng = np.random.default_rng(43)
+    bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+    enc = [keys.encrypt(bits[i], 0, seed=4300 + i) for i in range(2)]
+    ops = np.array([[O("AND"), O("OR"), O("XOR"), O("NAND")][g % 4] for g in range(count)], np.int32)
+    fns = {O("AND"): api.And, O("OR"): api.Or, O("XOR"): api.Xor, O("NAND"): api.Nand}
+    sts = [api.Stream() for _ in range(nst)]
+    for s in sts:
+        s.Create()
+    cin = [[api.Ctxt(0) for _ in range(count)] for _ in range(2)]
+    for i in range(2):
+        for g in range(count):
+            cin[i][g].tlwehost[:] = enc[i][g]
+    outs = [api.Ctxt(0) for _ in range(count)]
+    api.sched_stats(reset=True)
+    for g in range(count):
+        fns[int(ops[g])](outs[g], cin[0][g], cin[1][g], sts[g % nst])
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == count and stats.launch_sequences <= count // 2048 + 1
+    got = _host(outs)
+    exp = np.array([ol.truth(oracle, int(ops[g]), bits[0, g], bits[1, g]) for g in range(count)], np.uint8)
+    assert np.array_equal(keys.decrypt(got, 0), exp)
+    idx = np.arange(5, count, count // 64)[:64]
+    want = keys.gate_batch(ops[idx], 0, enc[0][idx], enc[1][idx])
+    assert np.array_equal(got[idx], want)
+    for s in sts:
+        s.Destroy()
+    for lst in (cin[0], cin[1], outs):
+        for c in lst:
+            c.release()
+
+
+def test_config2_mixed_32768_gate_batch(engine, keys, oracle):
+    """The same 32 768 mixed gates through the native batched entry (cufhe_amd_gate_batch)."""
+    count = 32768
+    rng = np.random.default_rng(43)
+    bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+    enc = [keys.encrypt(bits[i], 0, seed=4300 + i) for i in range(2)]
+    ops = np.array([[O("AND"), O("OR"), O("XOR"), O("NAND")][g % 4] for g in range(count)], np.int32)
+    d = [engine.api.DeviceBuffer(e.size).upload(e) for e in enc]
+    dout = engine.api.DeviceBuffer(count * (ol.n + 1))
+    engine.gate_batch(ops, 0, dout, d[0], d[1], count=count)
+    got = dout.download().reshape(count, -1)
+    exp = np.array([ol.truth(oracle, int(ops[g]), bits[0, g], bits[1, g]) for g in range(count)], np.uint8)
+    assert np.array_equal(keys.decrypt(got, 0), exp)
+    idx = np.arange(5, count, count // 64)[:64]
+    assert np.array_equal(got[idx], keys.gate_batch(ops[idx], 0, enc[0][idx], enc[1][idx]))
+
+
+@pytest.mark.parametrize("op", ["MUX", "NMUX"])
+def test_config3_mux_4096(engine, keys, oracle, op):
+    """BASELINE configs[3] at full size: 4096 MUX (and NMUX) gates = 8192 blind rotations + 4096 key
+    switches (src/bootstrap_gpu.cu:515-588); decrypt all, 64 sampled outputs == oracle words."""
+    count = 4096
+    rng = np.random.default_rng(44)
+    bits = rng.integers(0, 2, size=(3, count)).astype(np.uint8)
+    enc = [keys.encrypt(bits[i], 0, seed=4400 + i) for i in range(3)]
+    d = [engine.api.DeviceBuffer(e.size).upload(e) for e in enc]
+    dout = engine.api.DeviceBuffer(count * (ol.n + 1))
+    engine.gate_batch(O(op), 0, dout, d[0], d[1], d[2], count=count)
+    got = dout.download().reshape(count, -1)
+    exp = np.array([ol.truth(oracle, O(op), bits[0, g], bits[1, g], bits[2, g]) for g in range(count)], np.uint8)
+    assert np.array_equal(keys.decrypt(got, 0), exp)
+    idx = np.arange(3, count, count // 64)[:64]
+    assert np.array_equal(got[idx], keys.gate_batch(O(op), 0, enc[0][idx], enc[1][idx], enc[2][idx]))
