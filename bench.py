@@ -6,16 +6,31 @@ One "step" = one pass of the hot path over one batch: 4096 independent NAND gate
 cufhe_amd_gate_batch call = one blind-rotate launch + one key-switch launch.  With N > 1
 ranks (one per GPU, launched by torch.distributed.run) every rank runs its own 4096 gates
 against its own BK/KSK replica: weak scaling, no data-path collective.
+`--workload mixed --total-gates 32768` is BASELINE configs[2] instead: the 32 768 mixed gates of
+SURVEY.md 8(d) config 3 split contiguously over the ranks (strong scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (blind rotate)
-with the BK-sweep accounting of SURVEY.md 8(d): 61 931 520 algorithmic bytes per rotation,
-divided by the launch time measured with HIP events on the launch stream.  `cpu_baseline`
-times the CPU oracle (oracle/, a restatement of the same gate) on this box's host cores on
-a bounded sample of the same inputs and checks the GPU words against it.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step      the timed region: K steps, no profiling hooks inside
+  ms_per_gate_latency_single_gate   one gate alone on the idle device (the metric's second half)
+  roofline                 the dominant kernel (blind rotate) priced with the BK-sweep accounting of
+                           SURVEY.md 8(d) (61 931 520 algorithmic bytes per rotation) over its launch
+                           time, measured with HIP events on the launch stream in a SEPARATE pass;
+                           `traffic` and `valu` come from the committed rocprofv3 PMC passes and are
+                           printed only while the kernel sources still hash to what was profiled
+  api_pcie_inclusive       the reference-style per-gate API on host-resident ciphertexts over 256
+                           streams, enqueue -> Synchronize (test/test_util.h:29-72), and the host cost
+                           per gate of that path
+  extra_workloads          mux (configs[3]), mixed (configs[2] op mix), nand_lvl2 (configs[4]): rate,
+                           roofline fraction and a word-for-word oracle check each
+  cpu_baseline             an optimised CPU implementation of the same gate (oracle/cpu_fast.c: same
+                           exact FP64 field, AVX-512/AVX2, OpenMP over gates) timed on this box's host
+                           cores on a bounded sample; the CPU oracle checks both its words and the GPU's
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,100 +53,93 @@ import torch  # noqa: E402  (first: its bundled HIP runtime is the one the proce
 import torch.distributed as dist  # noqa: E402
 
 BK_BYTES_PER_ROTATION = 61931520          # n (k+1)^2 l N 8, SURVEY.md 8(d)
+BK2_BYTES_PER_ROTATION = 630 * 4 * 4 * 2048 * 8   # the same accounting at N = 2048, l = 4
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS = 1024                              # 256 CUs x 4
 
 
-def recorded_hbm_traffic(rotations, lvl2=False):
-    """HBM bytes per blind-rotate launch from the committed rocprofv3 PMC passes (separate
-    --pmc runs of this same command, profiles/r01_{final,lvl2}_pmc_*): FETCH_SIZE is in KB and reads
-    half of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM), WRITE_SIZE is exact.
-    Only meaningful for the launch shape it was recorded on (4096 rotations); else None."""
-    import csv
-    if rotations != 4096:
-        return None, None
-    tag, kernel = ("r01_lvl2", "blind_rotate_lvl2_kernel") if lvl2 else ("r01_final", "blind_rotate_kernel")
+def source_hash():
+    """sha256 over the kernel / host sources: recorded PMC facts are only valid for the exact code."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cufhe_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def kernel_facts(kernel, rotations):
+    """HBM traffic and VALU counters per launch from the committed rocprofv3 PMC passes
+    (profiles/kernel_facts.json, written by tools/kernel_facts.py from separate --pmc runs of this
+    command).  None when the sources changed since, or for another launch shape."""
     try:
-        vals = {}
-        for name, f in (("FETCH_SIZE", f"{tag}_pmc_fetch_counter_collection.csv"),
-                        ("WRITE_SIZE", f"{tag}_pmc_tcc_counter_collection.csv")):
-            path = os.path.join(ROOT, "profiles", f)
-            best = 0.0
-            for r in csv.DictReader(open(path)):
-                if kernel in r["Kernel_Name"] and r["Counter_Name"] == name:
-                    best = max(best, float(r["Counter_Value"]))
-            vals[name] = best
-        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, f"profiles/{tag}_pmc_{{fetch,tcc}}_counter_collection.csv"
+        facts = json.load(open(os.path.join(ROOT, "profiles", "kernel_facts.json")))
     except Exception:
-        return None, None
+        return None, "no recorded PMC passes"
+    if facts.get("source_sha256") != source_hash():
+        return None, "stale: cufhe_amd/csrc changed since the PMC passes were recorded (%s)" % facts.get("recorded", "?")
+    k = facts.get("kernels", {}).get(kernel)
+    if not k or k.get("rotations_per_launch") != rotations:
+        return None, "no PMC pass for this kernel / launch shape"
+    return k, facts.get("recorded", "")
 
 
-def cpu_baseline(eng, ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
-    """Time the CPU oracle on a bounded sample of the same workload; verify GPU words."""
-    import ctypes
-    L = ol.load()
-    ek = L.orc_evalkey_create(bk, ksk)
-    threads = L.orc_max_threads()
-    nand = np.array([0], np.int32)
-    words = ol.n + 1
-
-    def run(count):
-        out = np.zeros(count * words, np.uint32)
-        a = np.ascontiguousarray(in0[:count]).ravel()
-        b = np.ascontiguousarray(in1[:count])
-        t = time.perf_counter()
-        L.orc_gate_batch(ek, nand, 0, 0, count, out, a, b.ctypes.data, None, threads)
-        return time.perf_counter() - t, out.reshape(count, words)
-
-    # the container's CPU share can be far below the visible core count: calibrate the
-    # thread count on one round each and keep the fastest
-    best = None
-    for cand in sorted({min(16, threads), min(32, threads), threads}):
-        threads = cand
-        dt, _ = run(cand)
-        if best is None or cand / dt > best[0]:
-            best = (cand / dt, cand, dt)
-    _, threads, dt = best
-    per_round = max(dt, 1e-3)
-    count = int(min(in0.shape[0], max(threads, threads * round(target_seconds / per_round))))
-    dt, out = run(count)
-    L.orc_evalkey_destroy(ek)
-    match = bool(np.array_equal(out, gpu_out[:count]))
-    return {
-        "value": count / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
-        "visible_cores": int(L.orc_max_threads()),
-        "sample": f"{count} of the batch's NAND gates, OpenMP over gates, {dt:.1f} s",
-        "ms_per_gate_per_core": 1e3 * dt * threads / count,
-        "gpu_words_match_oracle": match,
-    }
+def oracle_check(ol, L, ek, ops, in0, in1, in2, gpu_out, idx):
+    """GPU words of the sampled gates == CPU oracle words (the checker, not the thing measured)."""
+    idx = np.asarray(idx)
+    ops_arr = np.ascontiguousarray(ops[idx] if isinstance(ops, np.ndarray) else np.full(idx.size, ops), np.int32)
+    out = np.zeros(idx.size * (ol.n + 1), np.uint32)
+    a = np.ascontiguousarray(in0[idx]).ravel()
+    b = np.ascontiguousarray(in1[idx])
+    c = np.ascontiguousarray(in2[idx])
+    L.orc_gate_batch(ek, ops_arr, 1, 0, idx.size, out, a, b.ctypes.data, c.ctypes.data, min(L.orc_max_threads(), 32))
+    return bool(np.array_equal(out.reshape(idx.size, -1), gpu_out[idx]))
 
 
-def cpu_baseline_lvl2(ol, bk, ksk, in0, in1, gpu_out, target_seconds=15.0):
-    """Same for the N = 2048 workload (oracle/tfhe_oracle_lvl2.c)."""
-    L = ol.load()
-    ek = L.orc2_evalkey_create(bk, ksk)
-    threads = L.orc_max_threads()
+def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12.0):
+    """Time the optimised CPU gate (oracle/cpu_fast.c) on a bounded sample of the same workload."""
+    fek = L.fast_evalkey_create(bk, ksk)
+    visible = L.orc_max_threads()
     nand = np.array([0], np.int32)
     words = ol.n + 1
 
     def run(count, threads):
         out = np.zeros(count * words, np.uint32)
         a = np.ascontiguousarray(in0[:count]).ravel()
-        b = np.ascontiguousarray(in1[:count])
+        b = np.ascontiguousarray(in1[:count]).ravel()
         t = time.perf_counter()
-        L.orc2_gate_batch(ek, nand, 0, count, out, a, b.ctypes.data, None, threads)
+        L.fast_gate_batch(fek, nand, 0, count, out, a, b, threads)
         return time.perf_counter() - t, out.reshape(count, words)
 
-    threads = min(threads, 32)
-    dt, _ = run(threads, threads)
-    count = int(min(in0.shape[0], max(threads, threads * round(target_seconds / max(dt, 1e-3)))))
+    # the container's CPU share can be far below the visible core count: calibrate the thread
+    # count on one round each (16 gates per thread: one block) and keep the fastest
+    best = None
+    for cand in sorted({min(16, visible), min(32, visible), min(64, visible), visible}):
+        dt, _ = run(16 * cand, cand)
+        if best is None or 16 * cand / dt > best[0]:
+            best = (16 * cand / dt, cand, dt)
+    rate, threads, _ = best
+    count = int(min(in0.shape[0], max(16 * threads, 16 * threads * round(target_seconds * rate / (16 * threads)))))
     dt, out = run(count, threads)
-    L.orc2_evalkey_destroy(ek)
+    L.fast_evalkey_destroy(fek)
+    # the checker: the restatement of the reference's algorithm on a handful of the same gates
+    idx = np.arange(0, count, max(1, count // 32))[:32]
+    want = np.zeros(idx.size * words, np.uint32)
+    L.orc_gate_batch(oracle_ek, nand, 0, 0, idx.size, want, np.ascontiguousarray(in0[idx]).ravel(),
+                     np.ascontiguousarray(in1[idx]).ctypes.data, None, min(visible, 32))
+    want = want.reshape(idx.size, words)
     return {
         "value": count / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
-        "visible_cores": int(L.orc_max_threads()),
-        "sample": f"{count} of the batch's NAND gates, OpenMP over gates, {dt:.1f} s",
+        "implementation": "oracle/cpu_fast.c: exact FP64-field NTT, constant-geometry radix-2, "
+                          + {4: "AVX-512", 3: "AVX2+FMA", 0: "scalar"}[int(L.fast_isa_level())] + ", OpenMP over gates",
+        "visible_cores": int(visible),
+        "sample": f"{count} of the batch's NAND gates, {dt:.1f} s",
         "ms_per_gate_per_core": 1e3 * dt * threads / count,
-        "gpu_words_match_oracle": bool(np.array_equal(out, gpu_out[:count])),
+        "cpu_words_match_oracle": bool(np.array_equal(out[idx], want)),
+        "gpu_words_match_cpu": bool(np.array_equal(out, gpu_out[:count])),
+        "gpu_words_match_oracle": bool(np.array_equal(gpu_out[idx], want)),
+        "reference_readme_context": "TFHE library on CPU: 10 ms per gate; cuFHE: 13 ms per gate per A100 SM (README.md:29-31)",
     }
 
 
@@ -141,9 +149,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
+    ap.add_argument("--total-gates", type=int, default=0,
+                    help="strong scaling: this many gates per step split contiguously over the ranks (configs[2]: 32768)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency", action="store_true",
-                    help="also time one gate alone on the idle device (adds 1-gate launches to a profile)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads / api_pcie_inclusive / latency")
     ap.add_argument("--workload", choices=["nand", "mux", "mixed", "nand_lvl2"], default="nand",
                     help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix; "
                          "nand_lvl2 = configs[4] (N = 2048 ring, 64-bit torus)")
@@ -161,50 +170,57 @@ def main():
 
     import cufhe_amd as eng                  # fails loudly if the HIP library is missing
     eng.api.set_option("device_base", DEV)   # logical device 0 of this process = this rank's GPU
+    api = eng.api
 
     class ol:                                 # sizes come from the library, not from the oracle
         n, N = int(eng.PARAMS.n), int(eng.PARAMS.N)
         BK_WORDS, KSK_WORDS = int(eng.PARAMS.bk_words), int(eng.PARAMS.ksk_words)
 
-    count = args.gates
-    rng = np.random.default_rng(42 + RANK)
-    # synthetic keys and ciphertexts: uniform torus words (the path's work is data-independent)
-    lvl2 = args.workload == "nand_lvl2"
-    if lvl2:
-        p2 = eng.lvl2_params()
-        bk = rng.integers(0, 2**64, size=int(p2.bk_words), dtype=np.uint64)
-        ksk = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.uint32)
+    strong = args.total_gates > 0
+    if strong:
+        lo, hi = distutil.shard(args.total_gates, RANK, WORLD)     # gate i -> rank floor(i / ceil(total / W))
+        count, first_gate = hi - lo, lo
     else:
-        bk = rng.integers(0, 2**32, size=ol.BK_WORDS, dtype=np.uint64).astype(np.uint32)
-        ksk = rng.integers(0, 2**32, size=ol.KSK_WORDS, dtype=np.uint64).astype(np.uint32)
-    in0 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
-    in1 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
+        count, first_gate = args.gates, 0
+    # synthetic keys and ciphertexts: uniform torus words (the path's work is data-independent).  Keys are
+    # the same on every rank (per-GPU replicas of ONE key set, as the reference uploads them); inputs differ.
+    krng = np.random.default_rng(4242)
+    rng = np.random.default_rng(42 + (0 if strong else RANK))
+    lvl2 = args.workload == "nand_lvl2"
+    bk = krng.integers(0, 2**32, size=ol.BK_WORDS, dtype=np.uint64).astype(np.uint32)
+    ksk = krng.integers(0, 2**32, size=ol.KSK_WORDS, dtype=np.uint64).astype(np.uint32)
+    total = args.total_gates if strong else count
+    ins_all = [rng.integers(0, 2**32, size=(total, ol.n + 1), dtype=np.uint64).astype(np.uint32) for _ in range(3)]
+    in0, in1, in2 = (x[first_gate:first_gate + count] for x in ins_all)
 
     eng.SetGPUNum(1)
+    eng.Initialize(bk, ksk)
+    p2 = bk2 = ksk2 = None
+
+    def init_lvl2():
+        nonlocal p2, bk2, ksk2
+        p2 = api.lvl2_params()
+        r2 = np.random.default_rng(4343)
+        bk2 = r2.integers(0, 2**64, size=int(p2.bk_words), dtype=np.uint64)
+        ksk2 = r2.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.uint32)
+        api.lvl2_initialize(bk2, ksk2)
+
     if lvl2:
-        eng.lvl2_initialize(bk, ksk)
-    else:
-        eng.Initialize(bk, ksk)
-    d0 = eng.api.DeviceBuffer(in0.size).upload(in0)
-    d1 = eng.api.DeviceBuffer(in1.size).upload(in1)
-    in2 = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
-    d2 = eng.api.DeviceBuffer(in2.size).upload(in2)
-    dout = eng.api.DeviceBuffer(count * (ol.n + 1))
-    if args.workload in ("nand", "nand_lvl2"):
-        ops, rot_per_gate = eng.api.NAND, 1
-    elif args.workload == "mux":
-        ops, rot_per_gate = eng.api.MUX, 2
-    else:   # configs[2]: op[i] = {AND, OR, XOR, NAND}[i mod 4]
-        ops = np.array([[eng.api.AND, eng.api.OR, eng.api.XOR, eng.api.NAND][g % 4] for g in range(count)], np.int32)
-        rot_per_gate = 1
+        init_lvl2()
+    d0, d1, d2 = (api.DeviceBuffer(max(x.size, 1)).upload(x) for x in (in0, in1, in2))
+    dout = api.DeviceBuffer(max(count, 1) * (ol.n + 1))
     st = eng.Stream(0)
     st.Create()
+    mixed_ops = np.array([[api.AND, api.OR, api.XOR, api.NAND][(first_gate + g) % 4] for g in range(count)], np.int32)
 
-    def step():
-        if lvl2:
-            eng.lvl2_gate_batch(ops, dout, d0, d1, d2, count=count, device=0, stream=st.st())
+    def run_step(workload, n=count):
+        if n == 0:
+            return
+        if workload == "nand_lvl2":
+            api.lvl2_gate_batch(api.NAND, dout, d0, d1, d2, count=n, device=0, stream=st.st())
         else:
-            eng.gate_batch(ops, 0, dout, d0, d1, d2, count=count, device=0, stream=st.st())
+            ops = {"nand": api.NAND, "mux": api.MUX, "mixed": mixed_ops}[workload]
+            api.gate_batch(ops, 0, dout, d0, d1, d2, count=n, device=0, stream=st.st())
 
     def barrier():
         if WORLD > 1:
@@ -212,81 +228,177 @@ def main():
         eng.Synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_get(reset=True)
-    eng.profile_enable(False)
-    elapsed = distutil.max_over_ranks(elapsed, dist)
+    def timed(workload, steps, warmup):
+        for _ in range(warmup):
+            run_step(workload)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run_step(workload)
+        barrier()
+        return time.perf_counter() - t0
 
+    def kernel_times(workload, steps=2):
+        """launch durations from HIP events on the launch stream, in a pass of their own"""
+        eng.Synchronize()
+        api.profile_get(reset=True)
+        api.profile_enable(True)
+        for _ in range(steps):
+            run_step(workload)
+        eng.Synchronize()
+        prof = api.profile_get(reset=True)
+        api.profile_enable(False)
+        return (prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1), prof.keyswitch_ms / max(prof.keyswitch_launches, 1))
+
+    def roofline(workload, br_ms, ks_ms, n=count):
+        l2 = workload == "nand_lvl2"
+        rotations = n * (2 if workload == "mux" else 1)
+        bk_bytes = BK2_BYTES_PER_ROTATION if l2 else BK_BYTES_PER_ROTATION
+        kernel = "blind_rotate_lvl2_kernel" if l2 else "blind_rotate_kernel"
+        achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+        facts, note = kernel_facts(kernel, rotations)
+        r = {
+            "bound": "hbm", "kernel": kernel,
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "accounting": "BK sweep (SURVEY.md 8d): the bytes a cache-less sweep of the bootstrapping key would read; "
+                          "the measured HBM traffic is `traffic`, the actual limiter is FP64 VALU issue (`valu`)",
+            "traffic": None, "traffic_unit": "bytes per launch",
+            "launch_ms": br_ms, "rotations_per_launch": rotations, "algorithmic_bytes_per_rotation": bk_bytes,
+            "keyswitch_launch_ms": ks_ms, "pmc_source": note,
+        }
+        if facts:
+            r["traffic"] = facts["hbm_bytes_per_launch"]
+            insts, clk = facts["valu_insts_per_launch"], facts["clock_hz"]
+            r["valu"] = {
+                "insts_per_step_per_wave": facts["valu_insts_per_step_per_wave"],
+                "pipe_busy": facts["valu_pipe_busy"],                      # under the profiler, from the PMC pass
+                "frac_of_fp64_issue": 4.0 * insts / (SIMDS * clk * br_ms * 1e-3),   # this run's launch time
+                "waves_per_simd": facts.get("waves_per_simd"),
+                "recorded_launch_ms": facts.get("launch_ms"),
+            }
+        return r
+
+    wl = args.workload
+    elapsed = distutil.max_over_ranks(timed(wl, args.steps, args.warmup), dist)
+    br_ms, ks_ms = kernel_times(wl)
+
+    extras_on = RANK == 0 and WORLD == 1 and not args.no_extra and not strong
     latency_ms = None
-    if RANK == 0 and args.latency and not lvl2:
+    if extras_on and not lvl2:
         # ms/gate latency: one gate alone on the idle device, enqueue -> result on the stream
         # (a 1-gate launch takes the workgroup-per-rotation kernel)
         lat = []
-        for _ in range(5):
+        for _ in range(7):
             eng.Synchronize()
             t1 = time.perf_counter()
-            eng.gate_batch(eng.api.NAND, 0, dout, d0, d1, count=1, device=0, stream=st.st())
+            run_step("nand", 1)
             eng.Synchronize()
             lat.append(1e3 * (time.perf_counter() - t1))
         latency_ms = sorted(lat)[len(lat) // 2]
+
     if RANK == 0:
-        total_gates = count * args.steps * WORLD
-        br_ms = prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1)
-        ks_ms = prof.keyswitch_ms / max(prof.keyswitch_launches, 1)
-        rotations = count * rot_per_gate
-        # lvl2: the same n (k+1)^2 l N 8 accounting at N = 2048, l = 4 (the device key is 3x that: three limbs)
-        bk_bytes = 630 * 4 * 4 * 2048 * 8 if lvl2 else BK_BYTES_PER_ROTATION
-        achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9
-        traffic, traffic_src = recorded_hbm_traffic(rotations, lvl2)
+        gates_per_step = args.total_gates if strong else count * WORLD
         res = {
-            "metric": "nand_gate_bootstraps_per_sec" if args.workload == "nand" else f"{args.workload}_gates_per_sec",
-            "value": total_gates / elapsed,
+            "metric": "nand_gate_bootstraps_per_sec" if wl == "nand" else f"{wl}_gates_per_sec",
+            "value": gates_per_step * args.steps / elapsed,
             "unit": "gate-bootstraps/s",
             "n_gpus": WORLD,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{count} independent {args.workload.upper()} gates per GPU per step "
-                            f"(BASELINE configs[{dict(nand=1, mux=3, mixed=2, nand_lvl2=4)[args.workload]}]), " +
+                "workload": (f"{args.total_gates} {wl.upper()} gates per step split contiguously over {WORLD} GPU(s)" if strong else
+                             f"{count} independent {wl.upper()} gates per GPU per step") +
+                            f" (BASELINE configs[{dict(nand=1, mux=3, mixed=2, nand_lvl2=4)[wl]}]), " +
                             ("TFHE n=630 N=2048 k=1 l=4 Bgbit=9 64-bit torus, t=7 basebit=2" if lvl2 else
                              "TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2") + ", lvl0 ciphertexts resident in HBM",
                 "gates_per_gpu": count,
                 "sharding": "gates split across ranks, per-GPU BK/KSK replica, no collective",
             },
-            "ms_per_gate_throughput": 1e3 * elapsed / (count * args.steps),
+            "ms_per_gate_throughput": 1e3 * elapsed / (gates_per_step * args.steps) * WORLD,
             "ms_per_gate_latency_single_gate": latency_ms,
-            "roofline": {
-                "bound": "hbm", "kernel": "blind_rotate_lvl2_kernel" if lvl2 else "blind_rotate_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src,
-                "launch_ms": br_ms, "rotations_per_launch": rotations,
-                "algorithmic_bytes_per_rotation": bk_bytes,
-                "keyswitch_launch_ms": ks_ms,
-            },
+            "roofline": roofline(wl, br_ms, ks_ms),
         }
-        if not args.no_cpu_baseline and WORLD == 1 and args.workload == "nand":
-            gpu_out = dout.download().reshape(count, ol.n + 1)
-            import oracle_lib                 # the only leg that touches the CPU oracle
-            res["cpu_baseline"] = cpu_baseline(eng, oracle_lib, bk, ksk, in0, in1, gpu_out)
-        if not args.no_cpu_baseline and WORLD == 1 and lvl2:
-            gpu_out = dout.download().reshape(count, ol.n + 1)
+        main_out = dout.download().reshape(max(count, 1), ol.n + 1)[:count]
+
+        if extras_on:
+            # the reference-style per-gate API, PCIe-inclusive (host-resident ciphertexts, 256 streams,
+            # enqueue -> Synchronize): its own process, this one is idle meanwhile
+            exe = os.path.join(ROOT, "tools", "bench_api")
+            try:
+                out = subprocess.run([exe, "4096"], capture_output=True, text=True, timeout=300,
+                                     env=dict(os.environ, HIP_VISIBLE_DEVICES=str(DEV)) if WORLD > 1 else None)
+                res["api_pcie_inclusive"] = json.loads(out.stdout.strip().splitlines()[-1])
+                res["api_pcie_inclusive"]["what"] = ("4096 cufhe::Nand(out, a, b, st) on host-resident ciphertexts over 256 streams, "
+                                                     "then Synchronize(): test/test_util.h:29-72; host_issue = recording + result delivery "
+                                                     "on the issuing thread, host_worker = the device's launch thread")
+            except Exception as e:      # the figure is auxiliary: never lose the headline line to it
+                res["api_pcie_inclusive"] = {"error": repr(e)}
+
+        if not args.no_cpu_baseline and WORLD == 1 and not strong:
+            import oracle_lib                 # the only leg that touches oracle/: checker and timed CPU baseline
+            L = oracle_lib.load()
+            oek = L.orc_evalkey_create(bk, ksk)
+            if wl == "nand":
+                res["cpu_baseline"] = cpu_baseline(ol, L, bk, ksk, in0, in1, main_out, oek)
+            elif wl in ("mux", "mixed"):
+                idx = np.arange(1, count, max(1, count // 16))[:16]
+                ops = {"mux": api.MUX, "mixed": mixed_ops}[wl]
+                res["gpu_words_match_oracle"] = oracle_check(ol, L, oek, ops, in0, in1, in2, main_out, idx)
+            if extras_on and wl == "nand":
+                extra = {}
+                for w2 in ("mux", "mixed"):
+                    dt = timed(w2, 2, 1)
+                    b2, k2 = kernel_times(w2, 1)
+                    out2 = dout.download().reshape(count, ol.n + 1)
+                    idx = np.arange(1, count, max(1, count // 16))[:16]
+                    ops = {"mux": api.MUX, "mixed": mixed_ops}[w2]
+                    rf = roofline(w2, b2, k2)
+                    extra[w2] = {"value": count * 2 / dt, "unit": "gates/s", "ms_per_step": 1e3 * dt / 2,
+                                 "blind_rotate_launch_ms": b2, "keyswitch_launch_ms": k2, "roofline_frac": rf["frac"],
+                                 "baseline_config": {"mux": "configs[3]", "mixed": "configs[2] op mix on one GPU"}[w2],
+                                 "gpu_words_match_oracle": oracle_check(ol, L, oek, ops, in0, in1, in2, out2, idx)}
+                try:
+                    init_lvl2()
+                    dt = timed("nand_lvl2", 2, 1)
+                    b2, k2 = kernel_times("nand_lvl2", 1)
+                    out2 = dout.download().reshape(count, ol.n + 1)
+                    ek2 = L.orc2_evalkey_create(bk2, ksk2)
+                    idx = np.arange(1, count, max(1, count // 8))[:8]
+                    want = np.zeros(idx.size * (ol.n + 1), np.uint32)
+                    L.orc2_gate_batch(ek2, np.array([0], np.int32), 0, idx.size, want, np.ascontiguousarray(in0[idx]).ravel(),
+                                      np.ascontiguousarray(in1[idx]).ctypes.data, None, min(L.orc_max_threads(), 32))
+                    L.orc2_evalkey_destroy(ek2)
+                    rf = roofline("nand_lvl2", b2, k2)
+                    extra["nand_lvl2"] = {"value": count * 2 / dt, "unit": "gate-bootstraps/s", "ms_per_step": 1e3 * dt / 2,
+                                          "blind_rotate_launch_ms": b2, "keyswitch_launch_ms": k2, "roofline_frac": rf["frac"],
+                                          "roofline_traffic": rf["traffic"], "baseline_config": "configs[4]",
+                                          "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, -1), out2[idx]))}
+                except Exception as e:
+                    extra["nand_lvl2"] = {"error": repr(e)}
+                res["extra_workloads"] = extra
+            L.orc_evalkey_destroy(oek)
+        if lvl2 and not args.no_cpu_baseline and WORLD == 1:
             import oracle_lib
-            res["cpu_baseline"] = cpu_baseline_lvl2(oracle_lib, bk, ksk, in0, in1, gpu_out)
+            L = oracle_lib.load()
+            ek2 = L.orc2_evalkey_create(bk2, ksk2)
+            threads = min(L.orc_max_threads(), 32)
+            n_chk = 2 * threads
+            want = np.zeros(n_chk * (ol.n + 1), np.uint32)
+            t0 = time.perf_counter()
+            L.orc2_gate_batch(ek2, np.array([0], np.int32), 0, n_chk, want, np.ascontiguousarray(in0[:n_chk]).ravel(),
+                              np.ascontiguousarray(in1[:n_chk]).ctypes.data, None, threads)
+            dt = time.perf_counter() - t0
+            L.orc2_evalkey_destroy(ek2)
+            res["cpu_baseline"] = {"value": n_chk / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
+                                   "implementation": "oracle/tfhe_oracle_lvl2.c (the checker itself; no optimised CPU path for this ring)",
+                                   "sample": f"{n_chk} of the batch's NAND gates, {dt:.1f} s",
+                                   "gpu_words_match_oracle": bool(np.array_equal(want.reshape(n_chk, -1), main_out[:n_chk]))}
         print(json.dumps(res), flush=True)
 
     st.Destroy()

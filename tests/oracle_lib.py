@@ -24,7 +24,7 @@ _u64 = np.ctypeslib.ndpointer(np.uint64, flags="C")
 
 
 def build():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tfhe_oracle.c", "tfhe_oracle.h", "tfhe_oracle_lvl2.c", "tfhe_oracle_lvl2.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("tfhe_oracle.c", "tfhe_oracle.h", "tfhe_oracle_lvl2.c", "tfhe_oracle_lvl2.h", "cpu_fast.c")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     if not os.path.exists(REF_LIB) and os.path.exists("/root/reference/test/plain.h"):
@@ -61,6 +61,11 @@ def load():
     L.orc_refresh.argtypes = [ctypes.c_void_p, _u32, _u32]
     L.orc_truth.argtypes = [ctypes.c_int] * 4
     L.orc_gate_coeffs.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
+    # optimised CPU baseline (oracle/cpu_fast.c): same words as orc_gate_batch at level 0
+    L.fast_evalkey_create.restype = ctypes.c_void_p
+    L.fast_evalkey_create.argtypes = [_u32, _u32]
+    L.fast_evalkey_destroy.argtypes = [ctypes.c_void_p]
+    L.fast_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_size_t, _u32, _u32, _u32, ctypes.c_int]
     # N = 2048 / 64-bit torus (oracle/tfhe_oracle_lvl2.h)
     L.orc2_keygen.argtypes = [ctypes.c_uint64, _u32]
     L.orc2_bkgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u64]

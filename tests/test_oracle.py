@@ -171,3 +171,24 @@ def test_golden_vectors(keys, oracle):
             assert [int(x) for x in keys.decrypt(out, level)] == lv["ops"][name]["decrypt"]
             if "out_words_gate0" in lv["ops"][name]:
                 assert [int(x) for x in out[0]] == lv["ops"][name]["out_words_gate0"]
+
+
+def test_fast_cpu_baseline_words_match_oracle(keys, oracle):
+    """oracle/cpu_fast.c (the optimised CPU gate bench.py times as `cpu_baseline`) computes the oracle's
+    words: every two-input op, inputs on both sides of the rotation wrap-around, ragged block sizes."""
+    rng = np.random.default_rng(77)
+    count = 21                                   # one full block of 16 and a ragged one
+    bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=770 + i) for i in range(2)]
+    ins[0][0, :] = 0                             # abar = 0 steps, bbar from the gate offset alone
+    ins[1][1, ol.n] = 0xFFFFFFFF
+    ops = np.array([g % 10 for g in range(count)], np.int32)
+    fek = oracle.fast_evalkey_create(keys.bk, keys.ksk)
+    try:
+        out = np.zeros(count * (ol.n + 1), np.uint32)
+        assert oracle.fast_gate_batch(fek, ops, 1, count, out, ins[0].ravel(), ins[1].ravel(), 4) == 0
+        want = keys.gate_batch(ops, 0, ins[0], ins[1])
+        assert np.array_equal(out.reshape(count, -1), want)
+        assert oracle.fast_gate_batch(fek, np.array([10], np.int32), 0, 1, out, ins[0].ravel(), ins[1].ravel(), 1) == -1   # MUX: not a two-input op
+    finally:
+        oracle.fast_evalkey_destroy(fek)
