@@ -14,9 +14,13 @@
 //     thread of its API makes issue order a legal execution of every race-free program);
 //   * `out.tlwehost` holds a gate's result once Synchronize() returned or StreamQuery(st) returned
 //     true for the stream the gate was issued on;
-//   * non-g gates take their inputs from `tlwehost` in stream order: the memory as of the call, or,
-//     when an earlier gate's result is still on its way to that `tlwehost`, that result -- the
-//     reference's D2H of the earlier gate precedes this gate's H2D on the stream;
+//   * non-g gates take their inputs from `tlwehost` in stream order: the memory, or, when an earlier
+//     gate's result is still on its way to that `tlwehost`, that result -- the reference's D2H of
+//     the earlier gate precedes this gate's H2D on the stream.  As in the reference (whose H2D is an
+//     asynchronous copy from the pinned `tlwehost`, src/cufhe_gates_gpu.cu:148-158) the memory is
+//     read some time after the call, by the device's launch thread: the caller must not modify an
+//     input before it has observed completion of the gates reading it.  A ciphertext may be
+//     DESTROYED right after the call (its words are saved first);
 //   * g-gates touch device buffers only; CtxtCopyH2D / CtxtCopyD2H move data in issue order;
 //   * `out` may alias an input (test/test_api_gpu.cu:141); inputs may be shared by any number of
 //     gates on any streams (test/test_intensive.cc:103-107).
@@ -89,18 +93,25 @@ struct cufhe_amd_ctxt {
         uint32_t wdepth = 0;        // depth of the newest recorded write of `dev` (0: none on record)
         bool w_upload = false;      // ... which was an upload (runs before the gates of its level)
         uint64_t version = 0;       // bumps at every recorded write of `dev`
-        std::vector<uint32_t> rdepths;   // levels that read `dev` since that write
+        uint32_t last_use = 0;      // newest level naming this buffer in any way (keeps a destroyed ciphertext alive)
+        // levels that read `dev` since that write: a few inline, the rest (rare) in a vector
+        uint32_t rd[4] = {0, 0, 0, 0};
+        uint32_t nrd = 0;
+        std::vector<uint32_t> rd_more;
         // the newest upload host -> dev, kept to recognise an unchanged shared input
-        void* snap_plan = nullptr;
+        void* snap_plan = nullptr;   // the (unretired) level whose staging block holds that upload
         size_t snap_off = 0;
         uint64_t snap_version = 0;
         uint32_t snap_hits = 0;
+        uint32_t last_upload = 0;   // depth of the newest recorded upload (its copy out of tlwehost happens at launch)
         bool snap_owned = false;
         std::vector<uint32_t> snap_own;
     };
     int level = 0;
     uint32_t* host = nullptr;       // nullptr once the caller destroyed the ciphertext
-    int refs = 0;                   // recorded / in-flight work still naming this ciphertext
+    void* owner = nullptr;          // the Scheduler that created it
+    std::atomic<int> host_reads{0};             // recorded uploads whose copy out of `host` is still to be done
+    std::atomic<uint32_t*> shadow{nullptr};     // the words of a destroyed ciphertext, for those copies
     bool destroyed = false;
     // a result on its way to `host`: produced on device host_dev as version host_version
     int host_dev = -1;
@@ -151,13 +162,18 @@ struct Plan {                         // one dependence level of the recorded pr
     std::vector<CopyRec> uploads, downloads;
     std::vector<cufhe_amd_ctxt*> upload_ctxts;     // parallel to uploads
     std::vector<Delivery> deliveries;              // parallel to downloads
-    std::vector<uint32_t> in_words;                // host snapshots of the uploads
+    size_t in_words = 0;                           // staging words of the uploads (filled by the launch thread)
     size_t out_words = 0;
     std::vector<uint32_t> dep_depths;              // earlier levels this one must follow
-    std::vector<cufhe_amd_ctxt*> touched;          // one reference per operand
     std::vector<void*> streams;                    // caller streams with work in this level
     size_t in_base = 0, out_base = 0;              // offsets in the group's staging blocks
     size_t gate_count() const { return gates[0].size() + gates[1].size(); }
+    void reset()
+    {
+        gates[0].clear(); gates[1].clear(); uploads.clear(); downloads.clear(); upload_ctxts.clear(); deliveries.clear();
+        dep_depths.clear(); streams.clear();
+        in_words = out_words = in_base = out_base = 0;
+    }
 };
 
 struct EventHolder {
@@ -193,7 +209,11 @@ class DeviceSched {
         nstreams_ = std::max(1, be_->num_streams());
         if (threaded_) worker_ = std::thread([this] { worker_loop(); });
     }
-    ~DeviceSched() { stop_worker(); }
+    ~DeviceSched()
+    {
+        stop_worker();
+        for (Plan* p : plan_pool_) delete p;
+    }
 
     void stop_worker()
     {
@@ -216,7 +236,29 @@ class DeviceSched {
     int flush(size_t max_levels = (size_t)-1);
     int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
     int synchronize();
-    void forget_stream(void* stream) { streams_.erase(stream); }
+    void forget_stream(void* stream)
+    {
+        streams_.erase(stream);
+        cached_stream_ = nullptr;
+        cached_ss_ = nullptr;
+    }
+    // returns once no launch thread of this device is in the middle of reading tlwehost memory
+    void copy_fence() { std::lock_guard<std::mutex> lk(copy_mu_); }
+    bool level_done(uint32_t depth) { return done(depth); }
+    // has the level at `depth` been launched, i.e. have its uploads been copied out of tlwehost?
+    bool uploads_copied(uint32_t depth)
+    {
+        if (depth >= base_depth_) return false;
+        Group* g = find_group(depth);
+        return !g || g->state.load(std::memory_order_acquire) >= 1;
+    }
+    // launch everything recorded and wait until the launch thread has copied its inputs
+    int flush_and_copy()
+    {
+        if (int rc = flush()) return rc;
+        wait_worker_idle();
+        return 0;
+    }
     // release every cached buffer; the device must be idle (synchronize() first)
     void release_buffers();
     // ... and the ciphertext slabs: only once no ciphertext of this scheduler is alive
@@ -248,7 +290,12 @@ class DeviceSched {
     Plan& plan_at(uint32_t depth)
     {
         while (base_depth_ + levels_.size() <= depth) {
-            Plan* p = new Plan();
+            Plan* p;
+            if (plan_pool_.empty()) p = new Plan();
+            else {
+                p = plan_pool_.back();
+                plan_pool_.pop_back();
+            }
             p->depth = base_depth_ + (uint32_t)levels_.size();
             levels_.push_back(p);
         }
@@ -277,8 +324,21 @@ class DeviceSched {
     static uint32_t max_reader(const cufhe_amd_ctxt::PerDev& pd)
     {
         uint32_t m = 0;
-        for (uint32_t r : pd.rdepths) m = std::max(m, r);
+        for (uint32_t i = 0; i < pd.nrd && i < 4; i++) m = std::max(m, pd.rd[i]);
+        for (uint32_t r : pd.rd_more) m = std::max(m, r);
         return m;
+    }
+    static bool has_readers(const cufhe_amd_ctxt::PerDev& pd) { return pd.nrd != 0; }
+    static void clear_readers(cufhe_amd_ctxt::PerDev& pd)
+    {
+        pd.nrd = 0;
+        if (!pd.rd_more.empty()) pd.rd_more.clear();
+    }
+    template <class F>
+    static void for_readers(const cufhe_amd_ctxt::PerDev& pd, F f)
+    {
+        for (uint32_t i = 0; i < pd.nrd && i < 4; i++) f(pd.rd[i]);
+        for (uint32_t r : pd.rd_more) f(r);
     }
     void add_dep(Plan& p, uint32_t depth)
     {
@@ -288,35 +348,42 @@ class DeviceSched {
     }
     void add_reader(cufhe_amd_ctxt::PerDev& pd, uint32_t depth)
     {
-        for (uint32_t r : pd.rdepths)
-            if (r == depth) return;
-        if (pd.rdepths.size() >= 8) {     // forget levels that have retired
-            size_t k = 0;
-            for (uint32_t r : pd.rdepths)
-                if (!done(r)) pd.rdepths[k++] = r;
-            pd.rdepths.resize(k);
+        bool seen = false;
+        for_readers(pd, [&](uint32_t r) { seen = seen || r == depth; });
+        if (seen) return;
+        if (pd.nrd >= 4 && (pd.nrd & 7) == 0) {     // now and then forget levels that have retired
+            uint32_t keep[4], k = 0;
+            std::vector<uint32_t> more;
+            for_readers(pd, [&](uint32_t r) {
+                if (done(r)) return;
+                if (k < 4) keep[k++] = r;
+                else more.push_back(r);
+            });
+            for (uint32_t i = 0; i < k; i++) pd.rd[i] = keep[i];
+            pd.nrd = k + (uint32_t)more.size();
+            pd.rd_more.swap(more);
         }
-        pd.rdepths.push_back(depth);
+        if (pd.nrd < 4) pd.rd[pd.nrd] = depth;
+        else pd.rd_more.push_back(depth);
+        pd.nrd++;
     }
-    void touch(Plan& p, cufhe_amd_ctxt* c)
+    static void use(cufhe_amd_ctxt::PerDev& pd, uint32_t depth) { pd.last_use = std::max(pd.last_use, depth); }
+    StreamState& stream_state(void* stream)
     {
-        c->refs++;
-        p.touched.push_back(c);
+        if (stream != cached_stream_ || !cached_ss_) {
+            cached_ss_ = &streams_[stream];      // references to map elements survive rehashing
+            cached_stream_ = stream;
+        }
+        return *cached_ss_;
     }
     void note_stream(Plan& p, void* stream, uint32_t depth)
     {
-        StreamState& ss = streams_[stream];
+        StreamState& ss = stream_state(stream);
         ss.max_depth = std::max(ss.max_depth, depth);
         if (p.streams.empty() || p.streams.back() != stream) p.streams.push_back(stream);
     }
-    const uint32_t* snapshot_words(const cufhe_amd_ctxt::PerDev& pd) const
-    {
-        if (pd.snap_owned) return pd.snap_own.data();
-        if (pd.snap_plan) return ((const Plan*)pd.snap_plan)->in_words.data() + pd.snap_off;
-        return nullptr;
-    }
     int resolve_host(cufhe_amd_ctxt* c, bool* need_upload);
-    void record_upload(cufhe_amd_ctxt* c);
+    void record_upload(cufhe_amd_ctxt* c, void* stream);
     int after_record();
     int launch(Group* g);                       // worker (or inline): submit the group's work
     int retire(Group* g);                       // issuing thread: deliver results, recycle
@@ -343,6 +410,9 @@ class DeviceSched {
     std::deque<Plan*> levels_;
     size_t pending_gates_ = 0;
     std::unordered_map<void*, StreamState> streams_;
+    void* cached_stream_ = nullptr;
+    StreamState* cached_ss_ = nullptr;
+    std::vector<Plan*> plan_pool_;              // retired levels, vectors keep their capacity
     uint64_t next_group_ = 1;
     std::deque<Group*> live_;                   // launched or queued groups, oldest first
     int sticky_error_ = 0;
@@ -350,6 +420,7 @@ class DeviceSched {
     std::vector<uint32_t*> free_slots_[2];
     std::vector<void*> slabs_;
 
+    std::mutex copy_mu_;                        // held while the launch thread copies out of tlwehost memory
     // shared with the worker
     std::mutex mu_;
     std::condition_variable cv_, cv_idle_;
@@ -400,6 +471,7 @@ class Scheduler {
                 return rc;
             }
         live_ctxts_++;
+        c->owner = this;
         *out = c;
         return 0;
     }
@@ -408,13 +480,45 @@ class Scheduler {
     // stay cheap.
     void ctxt_destroy(cufhe_amd_ctxt* c)
     {
+        if (c->host && c->host_reads.load(std::memory_order_acquire) > 0) {
+            // recorded uploads have not read tlwehost yet: save the words for them, then make sure no launch
+            // thread is still reading the caller's memory
+            const size_t words = (size_t)devs_[0]->backend()->words(c->level);
+            uint32_t* copy = new uint32_t[words];
+            memcpy(copy, c->host, words * 4);
+            c->shadow.store(copy, std::memory_order_release);
+            for (auto& d : devs_) d->copy_fence();
+        }
         c->destroyed = true;
         c->host = nullptr;
-        if (c->refs == 0) ctxt_release(c);
+        if (!collect(c)) zombies_.push_back(c);
     }
-    void ctxt_unref(cufhe_amd_ctxt* c)
+    // called when levels retire: release destroyed ciphertexts that nothing recorded names any more
+    void collect_zombies()
     {
-        if (--c->refs == 0 && c->destroyed) ctxt_release(c);
+        if (zombies_.empty()) return;
+        size_t k = 0;
+        for (cufhe_amd_ctxt* c : zombies_)
+            if (!collect(c)) zombies_[k++] = c;
+        zombies_.resize(k);
+    }
+    // A recorded result is about to be routed to c's tlwehost (a copying gate's output, CtxtCopyD2H) from
+    // `device`.  On that device launch order keeps earlier uploads of c ahead of the delivery; on the OTHER
+    // devices nothing does: their recorded uploads must have read the memory first, and what they hold can
+    // no longer be taken for "the current tlwehost".
+    int before_host_write(cufhe_amd_ctxt* c, int device)
+    {
+        for (size_t e = 0; e < devs_.size(); e++) {
+            if ((int)e == device) continue;
+            cufhe_amd_ctxt::PerDev& pe = c->d[e];
+            pe.snap_plan = nullptr;
+            pe.snap_owned = false;
+            if (pe.last_upload && !devs_[e]->uploads_copied(pe.last_upload)) {
+                devs_[device]->stats().forced_syncs++;
+                if (int rc = devs_[e]->flush_and_copy()) return rc;
+            }
+        }
+        return 0;
     }
     int synchronize_all()
     {
@@ -428,10 +532,12 @@ class Scheduler {
     }
 
    private:
+    bool collect(cufhe_amd_ctxt* c);            // release c if no recorded or in-flight level names it
     void ctxt_release(cufhe_amd_ctxt* c)
     {
         for (size_t d = 0; d < c->d.size() && d < devs_.size(); d++)
             if (c->d[d].dev) devs_[d]->slot_free(c->level, c->d[d].dev);
+        delete[] c->shadow.load();
         delete c;
         live_ctxts_--;
     }
@@ -439,7 +545,16 @@ class Scheduler {
     std::vector<std::unique_ptr<DeviceSched>> devs_;
     uint64_t token_ = 0;
     int live_ctxts_ = 0;
+    std::vector<cufhe_amd_ctxt*> zombies_;
 };
+
+inline bool Scheduler::collect(cufhe_amd_ctxt* c)
+{
+    for (size_t d = 0; d < devs_.size(); d++)
+        if (!devs_[d]->level_done(c->d[d].last_use)) return false;
+    ctxt_release(c);
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------
 
@@ -503,45 +618,52 @@ inline int DeviceSched::resolve_host(cufhe_amd_ctxt* c, bool* need_upload)
         const int other = c->host_dev;
         if (int rc = owner_->dev(other).synchronize()) return fail(rc, owner_->dev(other).error_text());
     }
-    // `tlwehost` is plain memory now.  An unchanged input that the device buffer still holds from an
-    // earlier upload is not copied again: shared inputs (test/test_intensive.cc) stay pure reads.
-    const uint32_t* snap = pd.snap_version == pd.version ? snapshot_words(pd) : nullptr;
-    if (snap && c->host && !memcmp(snap, c->host, (size_t)be_->words(c->level) * 4)) {
-        pd.snap_hits++;
-        stats_.uploads_shared++;
-        *need_upload = false;
-        return 0;
+    // `tlwehost` is plain memory now.  An input that the device buffer still holds from an earlier upload
+    // is not copied again: shared inputs (test/test_intensive.cc) stay pure reads.  While that upload has
+    // not retired the caller cannot have changed the memory (it has not observed completion of the gates
+    // reading it); afterwards the words are compared with a copy kept for inputs that were re-used.
+    if (pd.snap_version == pd.version) {
+        const bool same = pd.snap_plan != nullptr ||
+                          (pd.snap_owned && c->host && !memcmp(pd.snap_own.data(), c->host, (size_t)be_->words(c->level) * 4));
+        if (same) {
+            pd.snap_hits++;
+            stats_.uploads_shared++;
+            *need_upload = false;
+            return 0;
+        }
     }
     *need_upload = true;
     return 0;
 }
 
 // tlwehost (as of now) -> device buffer, at the earliest level that follows every recorded access
-inline void DeviceSched::record_upload(cufhe_amd_ctxt* c)
+inline void DeviceSched::record_upload(cufhe_amd_ctxt* c, void* stream)
 {
     cufhe_amd_ctxt::PerDev& pd = c->d[device_];
     uint32_t U = std::max(base_depth_, pd.ready);
     if (pd.w_upload) U = std::max(U, pd.wdepth + 1);
-    U = std::max(U, max_reader(pd) + (pd.rdepths.empty() ? 0u : 1u));
+    if (has_readers(pd)) U = std::max(U, max_reader(pd) + 1);
     Plan& p = plan_at(U);
     add_dep(p, pd.wdepth);
-    for (uint32_t r : pd.rdepths) add_dep(p, r);
-    const size_t words = (size_t)be_->words(c->level);
-    const size_t slot = p.in_words.size();
-    p.in_words.insert(p.in_words.end(), c->host, c->host + words);
+    for_readers(pd, [&](uint32_t r) { add_dep(p, r); });
+    const size_t slot = p.in_words;
+    p.in_words += (size_t)be_->words(c->level);
     p.uploads.push_back({pd.dev, slot, c->level});
     p.upload_ctxts.push_back(c);
-    touch(p, c);
+    c->host_reads.fetch_add(1, std::memory_order_relaxed);
+    use(pd, U);
     pd.version++;
     pd.wdepth = U;
     pd.w_upload = true;
     pd.ready = U;
-    pd.rdepths.clear();
+    clear_readers(pd);
     pd.snap_plan = &p;
     pd.snap_off = slot;
     pd.snap_version = pd.version;
     pd.snap_hits = 0;
     pd.snap_owned = false;
+    pd.last_upload = U;
+    note_stream(p, stream, U);       // completion of the stream implies this level has retired: tlwehost may be edited again
     stats_.uploads++;
 }
 
@@ -560,25 +682,27 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
             if (!ins[i]->host) return fail(-1, "gate on a destroyed ciphertext");
             if (int rc = resolve_host(ins[i], &need_up[i])) return rc;
         }
+    if (copying)
+        if (int rc = owner_->before_host_write(out, device_)) return fail(rc, "scheduler: flushing another device failed");
     for (int i = 0; i < 3; i++)
-        if (need_up[i]) record_upload(ins[i]);
+        if (need_up[i]) record_upload(ins[i], stream);
 
     uint32_t D = base_depth_;
     for (int i = 0; i < 3; i++)
         if (ins[i]) D = std::max(D, ins[i]->d[device_].ready);
     cufhe_amd_ctxt::PerDev& po = out->d[device_];
     D = std::max(D, po.ready);
-    if (!po.rdepths.empty()) D = std::max(D, max_reader(po) + 1);     // write after read
+    if (has_readers(po)) D = std::max(D, max_reader(po) + 1);         // write after read
 
     Plan& p = plan_at(D);
     for (int i = 0; i < 3; i++) {
         if (!ins[i]) continue;
         cufhe_amd_ctxt::PerDev& pd = ins[i]->d[device_];
         add_dep(p, pd.wdepth);
-        touch(p, ins[i]);
+        use(pd, D);
     }
     add_dep(p, po.wdepth);
-    for (uint32_t r : po.rdepths) add_dep(p, r);
+    for_readers(po, [&](uint32_t r) { add_dep(p, r); });
     for (int i = 0; i < 3; i++)
         if (ins[i]) add_reader(ins[i]->d[device_], D);
     // the write: in-place gates are safe, every kernel reads its operands before it writes
@@ -586,10 +710,10 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     po.wdepth = D;
     po.w_upload = false;
     po.ready = D + 1;
-    po.rdepths.clear();
+    clear_readers(po);
     po.snap_plan = nullptr;
     po.snap_owned = false;
-    touch(p, out);
+    use(po, D);
     p.gates[out->level].push_back(GateRef{op, po.dev, ins[0]->d[device_].dev,
                                           ins[1] ? ins[1]->d[device_].dev : nullptr,
                                           ins[2] ? ins[2]->d[device_].dev : nullptr});
@@ -599,7 +723,6 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
         p.downloads.push_back({po.dev, slot, out->level});
         const uint64_t token = owner_->new_token();
         p.deliveries.push_back({out, slot, token});
-        touch(p, out);
         out->host_dev = device_;
         out->host_version = po.version;
         out->host_token = token;
@@ -618,13 +741,11 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
         if (!c->host) return fail(-1, "copy of a destroyed ciphertext");
         bool need = false;
         if (int rc = resolve_host(c, &need)) return rc;
-        if (need) {
-            record_upload(c);
-            note_stream(plan_at(pd.wdepth), stream, pd.wdepth);
-        }
+        if (need) record_upload(c, stream);
         return 0;
     }
     // CtxtCopyD2H, :201-207: the gather of a level runs after its gates
+    if (int rc = owner_->before_host_write(c, device_)) return fail(rc, "scheduler: flushing another device failed");
     const uint32_t D = std::max(base_depth_, pd.wdepth);
     Plan& p = plan_at(D);
     add_dep(p, pd.wdepth);
@@ -634,7 +755,7 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
     p.downloads.push_back({pd.dev, slot, c->level});
     const uint64_t token = owner_->new_token();
     p.deliveries.push_back({c, slot, token});
-    touch(p, c);
+    use(pd, D);
     c->host_dev = device_;
     c->host_version = pd.version;
     c->host_token = token;
@@ -656,7 +777,8 @@ inline int DeviceSched::flush(size_t max_levels)
     while (!levels_.empty()) {
         Plan* b = levels_.back();
         if (b->gate_count() || !b->uploads.empty() || !b->downloads.empty()) break;
-        delete b;
+        b->reset();
+        plan_pool_.push_back(b);
         levels_.pop_back();
     }
     if (levels_.empty()) return 0;
@@ -672,7 +794,7 @@ inline int DeviceSched::flush(size_t max_levels)
         levels_.pop_front();
         p->in_base = g->in_words;
         p->out_base = g->out_words;
-        g->in_words += p->in_words.size();
+        g->in_words += p->in_words;
         g->out_words += p->out_words;
         g->plans.push_back(p);
         ngates += p->gate_count();
@@ -760,9 +882,19 @@ inline int DeviceSched::launch(Group* g)
         const size_t bytes = g->in_words * 4;
         if (step(get_buf(pinned_cache_, bytes, true, &g->pin_in, &g->pin_in_cap)) &&
             step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_in, &g->dev_in_cap))) {
-            for (Plan* p : g->plans)
-                if (!p->in_words.empty())
-                    memcpy((uint32_t*)g->pin_in + p->in_base, p->in_words.data(), p->in_words.size() * 4);
+            {
+                // the reference's H2D copies, gathered: tlwehost (or the saved words of a ciphertext that was
+                // destroyed meanwhile) -> the pinned staging block
+                std::lock_guard<std::mutex> lk(copy_mu_);
+                for (Plan* p : g->plans)
+                    for (size_t i = 0; i < p->uploads.size(); i++) {
+                        cufhe_amd_ctxt* c = p->upload_ctxts[i];
+                        const uint32_t* shadow = c->shadow.load(std::memory_order_acquire);
+                        memcpy((uint32_t*)g->pin_in + p->in_base + p->uploads[i].slot, shadow ? shadow : c->host,
+                               (size_t)be_->words(c->level) * 4);
+                        c->host_reads.fetch_sub(1, std::memory_order_release);
+                    }
+            }
             step(be_->h2d(s, g->dev_in, g->pin_in, bytes));
         }
     }
@@ -815,14 +947,14 @@ inline int DeviceSched::retire(Group* g)
             cufhe_amd_ctxt::PerDev& pd = p->upload_ctxts[i]->d[device_];
             if (pd.snap_plan != (void*)p || pd.snap_off != p->uploads[i].slot) continue;
             if (pd.snap_hits > 0 && pd.snap_version == pd.version) {
-                const uint32_t* w = p->in_words.data() + pd.snap_off;
+                const uint32_t* w = (const uint32_t*)g->pin_in + p->in_base + pd.snap_off;
                 pd.snap_own.assign(w, w + be_->words(p->uploads[i].level));
                 pd.snap_owned = true;
             }
             pd.snap_plan = nullptr;
         }
-        for (cufhe_amd_ctxt* c : p->touched) owner_->ctxt_unref(c);
-        delete p;
+        p->reset();
+        plan_pool_.push_back(p);
     }
     g->plans.clear();
     {
@@ -838,6 +970,7 @@ inline int DeviceSched::retire(Group* g)
         delete live_.front();
         live_.pop_front();
     }
+    owner_->collect_zombies();
     return rc;
 }
 
@@ -905,7 +1038,7 @@ inline int DeviceSched::stream_query(void* stream)
         sticky_error_ = 0;
         return rc;
     }
-    streams_.erase(stream);
+    forget_stream(stream);
     return 1;
 }
 

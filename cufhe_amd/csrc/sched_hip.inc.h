@@ -255,9 +255,8 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)
 
 static int sched_check_ctxt(sched::Scheduler* S, cufhe_amd_ctxt* c)
 {
-    auto it = g_ctxt_owner.find(c);
-    if (it == g_ctxt_owner.end()) return fail(-1, "unknown ciphertext handle");
-    if (it->second != S) return fail(-1, "ciphertext was created before SetGPUNum changed the GPU set");
+    if (c->owner != (void*)S) return fail(-1, "ciphertext was created before SetGPUNum changed the GPU set");
+    if (c->destroyed) return fail(-1, "gate on a destroyed ciphertext");
     return 0;
 }
 

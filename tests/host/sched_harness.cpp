@@ -294,6 +294,7 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
             if (!c->alive) continue;
             t.S->ctxt_destroy(c->h);
             c->alive = false;
+            for (auto& w : c->host) w = 0xDEADBEEFu;      // the caller's memory is gone: nobody may read it any more
             t.make(c->m.level);
         } else {
             t.S->dev(dev).flush();
@@ -401,8 +402,75 @@ static Shape multi_gpu(bool threaded)
     return sh;
 }
 
+// ---- host cost of the issuing thread at the real ciphertext size (no device work at all) ----
+class NullBackend : public Backend {
+   public:
+    void bind_thread() override {}
+    int num_streams() override { return 4; }
+    int words(int level) override { return level ? 1025 : 631; }
+    int alloc_device(size_t bytes, void** p) override { *p = malloc(bytes); return 0; }
+    int free_device(void* p) override { free(p); return 0; }
+    int alloc_pinned(size_t bytes, void** p) override { *p = malloc(bytes); return 0; }
+    int free_pinned(void* p) override { free(p); return 0; }
+    int h2d(int, void*, const void*, size_t) override { return 0; }
+    int d2h(int, void*, const void*, size_t) override { return 0; }
+    int copy_ctxts(int, const CopyRec*, size_t, uint32_t*, bool) override { return 0; }
+    int run_gates(int, int, const GateRef*, size_t) override { return 0; }
+    int event_create(void** ev) override { *ev = (void*)1; return 0; }
+    int event_destroy(void*) override { return 0; }
+    int event_record(int, void*) override { return 0; }
+    int event_query(void*) override { return 1; }
+    int event_sync(void*) override { return 0; }
+    int stream_wait(int, void*) override { return 0; }
+    std::string error_text() override { return ""; }
+};
+
+static void host_cost(int gpus, int gates_per_gpu)
+{
+    // what tools/bench_api.cpp does, for `gpus` devices from one issuing thread: Nand(out, a, b, st) on
+    // host-resident lvl0 ciphertexts over 256 streams per device, then Synchronize()
+    Scheduler S(gpus, true, [](int) { return new NullBackend(); });
+    const int total = gpus * gates_per_gpu, W = 631;
+    std::vector<std::vector<uint32_t>> host(3 * (size_t)total, std::vector<uint32_t>(W, 7u));
+    std::vector<cufhe_amd_ctxt*> c(3 * (size_t)total);
+    std::string err;
+    for (size_t i = 0; i < c.size(); i++) S.ctxt_create(0, host[i].data(), &c[i], &err);
+    double best = 1e30, best_rec = 0;
+    for (int rep = 0; rep < 5; rep++) {
+        for (auto& h : host) h[0]++;          // fresh inputs every round
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < total; i++) {
+            cufhe_amd_ctxt* ins[3] = {c[3 * (size_t)i + 1], c[3 * (size_t)i + 2], nullptr};
+            S.dev(i % gpus).record_gate((void*)(uintptr_t)(0x1000 + (i / gpus) % 256), 0, true, c[3 * (size_t)i], ins);
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        S.synchronize_all();
+        auto t2 = std::chrono::steady_clock::now();
+        const double tot = std::chrono::duration<double, std::micro>(t2 - t0).count();
+        if (tot < best) { best = tot; best_rec = std::chrono::duration<double, std::micro>(t1 - t0).count(); }
+    }
+    // busy time of the issuing thread (recording + delivering results) and of the busiest launch worker, from the
+    // scheduler's own clocks over all five rounds: wall time above also contains waiting for the workers
+    uint64_t rec = 0, ret = 0, worker = 0, gates = 0;
+    for (int d = 0; d < gpus; d++) {
+        const Stats& st = S.dev(d).stats();
+        rec += st.record_ns; ret += st.retire_ns; gates += st.gates;
+        worker = std::max<uint64_t>(worker, st.launch_ns.load());
+    }
+    printf("HOSTCOST {\"gpus\": %d, \"gates\": %d, \"wall_us_per_gate\": %.4f, \"enqueue_wall_us_per_gate\": %.4f, "
+           "\"issuing_thread_us_per_gate\": %.4f, \"issuing_thread_gates_per_s\": %.0f, \"worker_us_per_gate_per_device\": %.4f}\n",
+           gpus, total, best / total, best_rec / total, (rec + ret) * 1e-3 / gates, gates / ((rec + ret) * 1e-9),
+           worker * 1e-3 / (gates / gpus));
+    for (auto* x : c) S.ctxt_destroy(x);
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "hostcost")) {
+        host_cost(1, 4096);
+        host_cost(8, 4096);
+        return 0;
+    }
     const int seeds = argc > 1 ? atoi(argv[1]) : 50;
     const int gpus = argc > 2 ? atoi(argv[2]) : 2;
     const bool threaded = argc > 3 ? atoi(argv[3]) != 0 : true;
