@@ -4,6 +4,7 @@
 // replace the per-gate launchers of src/bootstrap_gpu.cu:834-1292.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -71,10 +72,12 @@ struct DeviceState {
 
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
-long g_wg_threshold = 1024;    // rotations per launch up to which the workgroup-per-rotation kernel is used
+long g_wg_threshold = 0;       // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_split_threshold = 32; // key switches per launch up to which each ciphertext is split over 8 workgroups
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
-long g_ll_threshold = 1280;    // rotations per launch up to which the 16-wave split-transform kernel is used (5 rounds of 256 workgroups = one batch-kernel launch)
+long g_ll_threshold = 640;     // rotations per launch up to which the 16-wave split-transform kernel is used (5 rounds of 256 workgroups = one batch-kernel launch)
+long g_half_threshold = 1024;  // a tail (or a whole launch) of at most this many rotations runs the batch kernel with 4 rotations per workgroup
+long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
 std::mutex g_mu;
@@ -293,18 +296,39 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLlLdsBytes));
         s.br_lds_opt_in = true;
     }
-    if ((long)count <= g_ll_threshold) {
-        // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
-        hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)count), dim3(kLlThreads), kLlLdsBytes, st, d, (int)count,
-                           s.bk_ntt, s.tables512, steps, acc_dump);
-    } else if ((long)count <= g_wg_threshold) {
-        // small batch: one workgroup per rotation (latency), see kernels.hip.h
-        hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)count), dim3(kWgThreads), kWgLdsBytes, st, d, (int)count,
-                           s.bk_ntt, s.tables, steps, acc_dump);
+    // One round of the batch kernel's grid is 256 workgroups x 8 rotations and takes ~19 ms however few of its
+    // wave slots are used, so a launch of 2049 rotations used to cost two rounds.  Launches are cut into
+    // whole rounds plus a tail, and the tail takes the cheapest of: the low-latency kernel (a CU per
+    // rotation, 3.5 ms per round of 256), the batch kernel with one rotation per SIMD (~11 ms per round of
+    // 1024), a full round.  All variants compute identical words.
+    constexpr size_t kRound = 256 * kBrWavesPerBlock;
+    auto launch_batch = [&](const LinDesc* dd, size_t n, int active, uint32_t* dump) {
+        const unsigned blocks = (unsigned)((n + active - 1) / active);
+        hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, dd, (int)n,
+                           s.bk_ntt, s.tables, steps, dump, active);
+    };
+    auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
+        if ((long)n <= g_ll_threshold) {
+            // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
+            hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)n), dim3(kLlThreads), kLlLdsBytes, st, dd, (int)n,
+                               s.bk_ntt, s.tables512, steps, dump);
+        } else if ((long)n <= g_wg_threshold) {
+            // one 8-wave workgroup per rotation (kernels.hip.h); unused with the default thresholds
+            hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)n), dim3(kWgThreads), kWgLdsBytes, st, dd, (int)n,
+                               s.bk_ntt, s.tables, steps, dump);
+        } else if ((long)n <= g_half_threshold) {
+            launch_batch(dd, n, kBrWavesPerBlock / 2, dump);
+        } else {
+            launch_batch(dd, n, kBrWavesPerBlock, dump);
+        }
+    };
+    const size_t tail = count % kRound;
+    if (g_tail_split && count > kRound && tail != 0 && (long)tail <= std::max(g_half_threshold, std::max(g_ll_threshold, g_wg_threshold))) {
+        const size_t full = count - tail;
+        launch_batch(d, full, kBrWavesPerBlock, acc_dump);
+        launch_small(d + full, tail, acc_dump ? acc_dump + full * 2 * kN : nullptr);
     } else {
-        const unsigned blocks = (unsigned)((count + kBrWavesPerBlock - 1) / kBrWavesPerBlock);
-        hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, d, (int)count,
-                           s.bk_ntt, s.tables, steps, acc_dump);
+        launch_small(d, count, acc_dump);
     }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
@@ -918,6 +942,8 @@ int cufhe_amd_set_option(const char* key, long value)
     }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
+    if (!strcmp(key, "half_threshold")) { g_half_threshold = value; return 0; }
+    if (!strcmp(key, "tail_split")) { g_tail_split = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
     if (!strcmp(key, "lvl0_ring")) {

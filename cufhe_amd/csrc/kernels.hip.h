@@ -288,22 +288,25 @@ __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&a
 // index 0).  steps < n is only used by the parity tests; acc_dump (optional) receives the
 // raw accumulator (2N words per rotation).  All 8 waves of a workgroup walk the key in
 // lock-step (one barrier per TRGSW row); waves past `count` only serve the row pipeline.
+// `active` (8 or 4) is the number of waves per workgroup that own a rotation: with 4, every SIMD
+// runs ONE rotation instead of two and a round of the grid takes about 11 ms instead of 19 -- the
+// shape for the tail of a launch that does not fill a second round (capi.hip: launch_blind_rotate).
 __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
+    const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump, int active)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tabs = (double*)(smem + kBrLdsTables);
     load_tables_to_lds(tabs, gt);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * kBrWavesPerBlock + wave;
+    const int g = blockIdx.x * active + wave;
     char* tile = smem + kBrLdsTiles + wave * kTileBytes;
     uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
     const WaveCtx ctx = make_wave_ctx(smem, kBrLdsTiles + wave * kTileBytes, kBrLdsTables, gt, lane);
     const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows, wave >= kBrWavesPerBlock / 2};
     pipe.issue(0);
-    if (g >= count) {
+    if (wave >= active || g >= count) {
         // no rotation for this wave (tail of the batch): it only keeps its share of the row
         // pipeline going -- one barrier and two LDS-DMA pieces per row -- and computes nothing
         __syncthreads();

@@ -13,21 +13,23 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["batch", "wg", "ll"])
+@pytest.fixture(params=["batch", "half", "wg", "ll"])
 def br_kernel(request, engine):
-    """Run a test once per blind-rotate kernel: wave-per-rotation (batch), workgroup-per-rotation
-    (wg) and the 16-wave split-transform kernel (ll, lowest latency).  All must give the oracle's
-    words."""
+    """Run a test once per blind-rotate kernel: wave-per-rotation (batch: two rotations per SIMD; half: one
+    per SIMD, the tail shape), workgroup-per-rotation (wg) and the 16-wave split-transform kernel (ll,
+    lowest latency).  All must give the oracle's words."""
     which = request.param
     engine.api.set_option("ll_threshold", 1 << 30 if which == "ll" else 0)
-    engine.api.set_option("wg_threshold", 0 if which == "batch" else 1 << 30)
-    engine.api.set_option("ks_wg_threshold", 0 if which == "batch" else 1 << 30)
+    engine.api.set_option("wg_threshold", 1 << 30 if which in ("wg", "ll") else 0)
+    engine.api.set_option("half_threshold", 1 << 30 if which == "half" else 0)   # "batch": two rotations per SIMD whatever the count
+    engine.api.set_option("ks_wg_threshold", 0 if which in ("batch", "half") else 1 << 30)
     engine.api.set_option("ks_split_threshold", 1 << 30 if which == "ll" else 0)   # ll: 8 workgroups per key switch
     yield which
-    engine.api.set_option("ll_threshold", 1280)
-    engine.api.set_option("wg_threshold", 1024)
+    engine.api.set_option("ll_threshold", 640)
+    engine.api.set_option("wg_threshold", 0)
     engine.api.set_option("ks_wg_threshold", 128)
     engine.api.set_option("ks_split_threshold", 32)
+    engine.api.set_option("half_threshold", 1024)
 
 
 def _upload(eng, arr):
@@ -409,12 +411,38 @@ def test_ragged_batch_sizes(engine, keys, count):
             engine.gate_batch(ol.OPS.index("XOR"), 0, dout, dins[0], dins[1], count=count)
             got = dout.download().reshape(count, -1)
         finally:
-            engine.api.set_option("wg_threshold", 1024)
+            engine.api.set_option("wg_threshold", 0)
             engine.api.set_option("ks_wg_threshold", 128)
         assert np.array_equal(keys.decrypt(got, 0), bits[0] ^ bits[1])
         idx = np.unique(np.array([0, count // 2, count - 1]))
         want = keys.gate_batch(ol.OPS.index("XOR"), 0, ins[0][idx], ins[1][idx])
         assert np.array_equal(got[idx], want)
+
+
+@pytest.mark.parametrize("count,opts", [(700, dict(ll_threshold=0, wg_threshold=0)),        # one rotation per SIMD (4 of 8 waves)
+                                        (2049, {}), (2700, {}), (4600, {})])                  # full rounds + a tail
+def test_launch_shapes_with_tails(engine, keys, count, opts):
+    """Launches that do not fill whole rounds of the blind-rotate grid are cut into full rounds plus a
+    tail on a cheaper kernel (capi.hip, launch_blind_rotate): every output must still decrypt, sampled
+    outputs -- first, last, and both sides of every cut -- must be the oracle's words."""
+    rng = np.random.default_rng(count)
+    bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=7700 + count + i) for i in range(2)]
+    dins = [_upload(engine, x) for x in ins]
+    dout = engine.api.DeviceBuffer(count * (ol.n + 1))
+    for k, v in opts.items():
+        engine.api.set_option(k, v)
+    try:
+        engine.gate_batch(ol.OPS.index("NAND"), 0, dout, dins[0], dins[1], count=count)
+        got = dout.download().reshape(count, -1)
+    finally:
+        engine.api.set_option("ll_threshold", 640)
+        engine.api.set_option("wg_threshold", 0)
+    assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
+    cut = count - count % 2048
+    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, count - 5, count - 1]), 0, count - 1))
+    want = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0][idx], ins[1][idx])
+    assert np.array_equal(got[idx], want)
 
 
 def test_empty_batch_and_errors(engine):

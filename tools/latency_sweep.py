@@ -1,25 +1,53 @@
-import sys, time, os
+"""Gate-batch time by batch size and kernel choice (1 GPU): the numbers behind the launch-shape
+thresholds of cufhe_amd/csrc/capi.hip (launch_blind_rotate).  python tools/latency_sweep.py"""
+import os
+import sys
+import time
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import numpy as np
+import torch  # noqa: F401
 import cufhe_amd as eng
 rng = np.random.default_rng(1)
 P = eng.PARAMS
 bk = rng.integers(0, 2**32, size=int(P.bk_words), dtype=np.uint64).astype(np.uint32)
 ksk = rng.integers(0, 2**32, size=int(P.ksk_words), dtype=np.uint64).astype(np.uint32)
-eng.SetGPUNum(1); eng.Initialize(bk, ksk)
+eng.SetGPUNum(1)
+eng.Initialize(bk, ksk)
 n = int(P.n)
-mx = 2048
-a = rng.integers(0, 2**32, size=(mx, n+1), dtype=np.uint64).astype(np.uint32)
-d0 = eng.api.DeviceBuffer(a.size).upload(a); d1 = eng.api.DeviceBuffer(a.size).upload(a[::-1].copy())
-dout = eng.api.DeviceBuffer(mx*(n+1))
+mx = 8192
+a = rng.integers(0, 2**32, size=(mx, n + 1), dtype=np.uint64).astype(np.uint32)
+d0 = eng.api.DeviceBuffer(a.size).upload(a)
+d1 = eng.api.DeviceBuffer(a.size).upload(a[::-1].copy())
+dout = eng.api.DeviceBuffer(mx * (n + 1))
+
+
 def t(count, reps=5):
-    ts=[]
+    ts = []
     for _ in range(reps):
-        eng.Synchronize(); t0=time.perf_counter()
+        eng.Synchronize()
+        t0 = time.perf_counter()
         eng.gate_batch(eng.api.NAND, 0, dout, d0, d1, count=count)
-        eng.Synchronize(); ts.append(1e3*(time.perf_counter()-t0))
-    return sorted(ts)[len(ts)//2]
-for name,(ll,wg) in dict(ll=(1<<30,1<<30), wg=(0,1<<30), batch=(0,0)).items():
-    eng.api.set_option("ll_threshold", ll); eng.api.set_option("wg_threshold", wg)
-    print(name, " ".join(f"{c}:{t(c):.2f}" for c in (1, 16, 64, 256, 512, 1024, 2048)), flush=True)
+        eng.Synchronize()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return sorted(ts)[len(ts) // 2]
+
+
+def opts(ll, wg, half, split):
+    eng.api.set_option("ll_threshold", ll)
+    eng.api.set_option("wg_threshold", wg)
+    eng.api.set_option("half_threshold", half)
+    eng.api.set_option("tail_split", split)
+
+
+BIG = 1 << 30
+small = (1, 16, 64, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048)
+for name, o in dict(ll=(BIG, BIG, 0, 0), wg=(0, BIG, 0, 0), half=(0, 0, BIG, 0), batch=(0, 0, 0, 0)).items():
+    opts(*o)
+    print(name, " ".join(f"{c}:{t(c):.2f}" for c in small), flush=True)
+big = (2049, 2112, 2304, 2560, 2816, 3072, 3500, 4096, 4097, 4352, 5000, 6144, 8192)
+opts(1280, 1024, 0, 0)
+print("round-1 launch shapes  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
+opts(640, 0, 1024, 1)
+print("tail split (defaults)  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
+print("gates/s (defaults)     ", " ".join(f"{c}:{c / t(c, 3) * 1e3:.0f}" for c in big), flush=True)
 eng.CleanUp()
