@@ -72,11 +72,11 @@ struct DeviceState {
 
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
-long g_wg_threshold = 0;       // rotations per launch up to which the workgroup-per-rotation kernel is used
+long g_wg_threshold = 0;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_split_threshold = 32; // key switches per launch up to which each ciphertext is split over 8 workgroups
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
-long g_ll_threshold = 640;     // rotations per launch up to which the 16-wave split-transform kernel is used (5 rounds of 256 workgroups = one batch-kernel launch)
-long g_half_threshold = 1024;  // a tail (or a whole launch) of at most this many rotations runs the batch kernel with 4 rotations per workgroup
+long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
+long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
@@ -307,8 +307,15 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, dd, (int)n,
                            s.bk_ntt, s.tables, steps, dump, active);
     };
+    // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
+    //   low-latency kernel  3.5 (n <= 64), 5.4 / 8.9 / 12.3 / 15.7 / 19.2 per started round of 256
+    //   one rotation per SIMD 13.6 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
+    // so: low-latency up to 768 and for 1025..1280, one-per-SIMD for 769..1024, a full round above.
+    const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
-        if ((long)n <= g_ll_threshold) {
+        const bool use_ll = auto_ll ? (n <= 768 || (n > 1024 && n <= 1280 && auto_half)) : (long)n <= g_ll_threshold;
+        const bool use_half = auto_half ? n <= 1024 : (long)n <= g_half_threshold;
+        if (use_ll) {
             // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
             hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)n), dim3(kLlThreads), kLlLdsBytes, st, dd, (int)n,
                                s.bk_ntt, s.tables512, steps, dump);
@@ -316,14 +323,15 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
             // one 8-wave workgroup per rotation (kernels.hip.h); unused with the default thresholds
             hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)n), dim3(kWgThreads), kWgLdsBytes, st, dd, (int)n,
                                s.bk_ntt, s.tables, steps, dump);
-        } else if ((long)n <= g_half_threshold) {
+        } else if (use_half) {
             launch_batch(dd, n, kBrWavesPerBlock / 2, dump);
         } else {
             launch_batch(dd, n, kBrWavesPerBlock, dump);
         }
     };
     const size_t tail = count % kRound;
-    if (g_tail_split && count > kRound && tail != 0 && (long)tail <= std::max(g_half_threshold, std::max(g_ll_threshold, g_wg_threshold))) {
+    const long tail_max = std::max(auto_half ? 1024L : g_half_threshold, std::max(auto_ll ? 1280L : g_ll_threshold, g_wg_threshold));
+    if (g_tail_split && count > kRound && tail != 0 && (long)tail <= tail_max) {
         const size_t full = count - tail;
         launch_batch(d, full, kBrWavesPerBlock, acc_dump);
         launch_small(d + full, tail, acc_dump ? acc_dump + full * 2 * kN : nullptr);

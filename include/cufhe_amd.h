@@ -170,12 +170,14 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
 /* ---- tuning ----
  * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process
  * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
- * "ll_threshold" (default 1280): launches of at most this many blind rotations use the 16-wave
- * workgroup-per-rotation kernel with split transforms (lowest latency: 3.5 ms for up to 64
- * rotations, 15.6 ms for 1024, where the batch kernel needs 20.7 ms for anything up to 2048);
- * "wg_threshold" (default 1024): above ll_threshold and up to this many, the 8-wave
- * workgroup-per-rotation kernel (unused with the defaults); larger launches the wave-per-rotation
- * batch kernel (highest throughput).
+ * Launch shape of the blind rotation (all variants produce identical words).  A launch is cut into whole
+ * rounds of the batch kernel's grid (2048 rotations: two per SIMD, highest throughput) plus a tail, and the
+ * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: the 16-wave
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 3.5 ms for up to 64 rotations,
+ * 5.4 / 8.9 / 12.3 ms for up to 256 / 512 / 768), the batch kernel with one rotation per SIMD (13.6 ms for
+ * up to 1024), or a full round (20.7 ms).  "ll_threshold" / "half_threshold" (default -1 = by cost) force
+ * the first / second of these up to the given count, "wg_threshold" (default 0) the older 8-wave
+ * workgroup-per-rotation kernel, "tail_split" 0 launches everything above 2048 as one grid.
  * "ks_wg_threshold" (default 128) / "ks_split_threshold" (default 32): the same choice for the key
  * switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (lowest latency), up
  * to ks_wg_threshold one workgroup per ciphertext, above that 16 ciphertexts share each step of the

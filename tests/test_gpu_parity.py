@@ -25,11 +25,11 @@ def br_kernel(request, engine):
     engine.api.set_option("ks_wg_threshold", 0 if which in ("batch", "half") else 1 << 30)
     engine.api.set_option("ks_split_threshold", 1 << 30 if which == "ll" else 0)   # ll: 8 workgroups per key switch
     yield which
-    engine.api.set_option("ll_threshold", 640)
+    engine.api.set_option("ll_threshold", -1)
     engine.api.set_option("wg_threshold", 0)
     engine.api.set_option("ks_wg_threshold", 128)
     engine.api.set_option("ks_split_threshold", 32)
-    engine.api.set_option("half_threshold", 1024)
+    engine.api.set_option("half_threshold", -1)
 
 
 def _upload(eng, arr):
@@ -436,7 +436,7 @@ def test_launch_shapes_with_tails(engine, keys, count, opts):
         engine.gate_batch(ol.OPS.index("NAND"), 0, dout, dins[0], dins[1], count=count)
         got = dout.download().reshape(count, -1)
     finally:
-        engine.api.set_option("ll_threshold", 640)
+        engine.api.set_option("ll_threshold", -1)
         engine.api.set_option("wg_threshold", 0)
     assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
     cut = count - count % 2048

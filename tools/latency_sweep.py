@@ -47,7 +47,7 @@ for name, o in dict(ll=(BIG, BIG, 0, 0), wg=(0, BIG, 0, 0), half=(0, 0, BIG, 0),
 big = (2049, 2112, 2304, 2560, 2816, 3072, 3500, 4096, 4097, 4352, 5000, 6144, 8192)
 opts(1280, 1024, 0, 0)
 print("round-1 launch shapes  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
-opts(640, 0, 1024, 1)
+opts(-1, 0, -1, 1)
 print("tail split (defaults)  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
 print("gates/s (defaults)     ", " ".join(f"{c}:{c / t(c, 3) * 1e3:.0f}" for c in big), flush=True)
 eng.CleanUp()
