@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#define CUFHE_AMD_INSECURE_TEST_KEYS      // reproducible keys: this is a test
 #include "../../include/cufhe_amd_legacy.hpp"
 
 using namespace cufhe::legacy;

@@ -71,3 +71,35 @@ def test_legacy_manual_api_host_side():
                            "-Wl,-rpath," + os.path.join(ol.ROOT, "cufhe_amd")])
     out = subprocess.run([exe, "--cpu-only"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout + out.stderr
+
+
+def test_legacy_keygen_uses_a_csprng(tmp_path):
+    """include/cufhe_amd_legacy.hpp draws keys and noise from ChaCha20 keyed by the OS: the block function
+    matches the RFC 7539 A.1 vector, two OS-keyed generators differ, and the seeded (test-only) entry point
+    does not exist unless CUFHE_AMD_INSECURE_TEST_KEYS is defined."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "kat.cpp"
+    src.write_text('''
+#include <cstdio>
+#include "cufhe_amd_legacy.hpp"
+using namespace cufhe::legacy::detail;
+int main() {
+    ChaCha c; uint8_t k[32] = {0}; c.set_key(k);
+    const uint32_t w0 = c.next32(), w1 = c.next32();          // keystream 76 b8 e0 ad a0 f1 3d 90 ...
+    ChaCha a, b;
+    int diff = 0; for (int i = 0; i < 8; i++) diff += a.next64() != b.next64();
+    std::printf("%08x %08x %d\\n", w0, w1, diff);
+    return 0;
+}''')
+    exe = tmp_path / "kat"
+    lib = os.path.join(root, "cufhe_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), "-o", str(exe), str(src),
+                           "-L" + lib, "-lcufhe_amd", "-Wl,-rpath," + lib])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60).stdout.split()
+    assert out[0] == "ade0b876" and out[1] == "903df1a0" and int(out[2]) == 8
+    bad = tmp_path / "seeded.cpp"
+    bad.write_text('#include "cufhe_amd_legacy.hpp"\nint main() { cufhe::legacy::SetSeed(1234ull); }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"), str(bad)],
+                       capture_output=True, text=True)
+    assert r.returncode != 0, "SetSeed(uint64_t) must not exist without CUFHE_AMD_INSECURE_TEST_KEYS"
