@@ -39,6 +39,13 @@ class Profile(ctypes.Structure):
                 ("keyswitch_launches", ctypes.c_uint64), ("keyswitches", ctypes.c_uint64)]
 
 
+class PsParams(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32)] + \
+               [(k, ctypes.c_uint32) for k in ("n", "N", "nbit", "k", "l", "Bgbit", "t", "basebit", "key_limbs",
+                                               "key_limb_bits", "mu", "lvl0_words", "lvl1_words")] + \
+               [(k, ctypes.c_uint64) for k in ("bk_words", "ksk_words", "bk_ntt_bytes")]
+
+
 class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
@@ -91,6 +98,13 @@ SIGNATURES = {
     "cufhe_amd_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(Profile), ctypes.c_int]),
     "cufhe_amd_polymul512_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
     "cufhe_amd_bootstrap_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_ps_count": (ctypes.c_int, []),
+    "cufhe_amd_ps_get_params": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(PsParams)]),
+    "cufhe_amd_ps_initialize": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
+    "cufhe_amd_ps_gate_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_int,
+                                               c_void, c_void, c_void, c_void, ctypes.c_size_t]),
+    "cufhe_amd_ps_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
+    "cufhe_amd_ps_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_lvl2_get_params": (ctypes.c_int, [ctypes.POINTER(Lvl2Params)]),
     "cufhe_amd_lvl2_initialize": (ctypes.c_int, [c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
     "cufhe_amd_lvl2_gate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_int,

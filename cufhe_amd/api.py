@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import lib, check, Params, Profile, Lvl2Params, SchedStats
+from ._lib import lib, check, Params, Profile, Lvl2Params, SchedStats, PsParams
 
 # op codes (include/cufhe_amd.h)
 NAND, NOR, XNOR, AND, OR, XOR, ANDNY, ANDYN, ORNY, ORYN, MUX, NMUX, NOT, COPY = range(14)
@@ -325,3 +325,49 @@ def sched_stats(device=0, reset=False):
     s = SchedStats()
     check(lib.cufhe_amd_sched_get_stats(device, ctypes.byref(s), 1 if reset else 0))
     return s
+
+
+# ---- other parameter sets (include/cufhe_amd.h: cufhe_amd_ps_*) ----
+def ps_count():
+    return lib.cufhe_amd_ps_count()
+
+
+def ps_params(ps):
+    p = PsParams()
+    check(lib.cufhe_amd_ps_get_params(int(ps), ctypes.byref(p)))
+    return p
+
+
+def ps_index(name):
+    for i in range(ps_count()):
+        if ps_params(i).name.decode() == name:
+            return i
+    raise KeyError(name)
+
+
+def ps_initialize(ps, bk, ksk):
+    bk = np.ascontiguousarray(bk, dtype=np.uint32).ravel()
+    ksk = np.ascontiguousarray(ksk, dtype=np.uint32).ravel()
+    check(lib.cufhe_amd_ps_initialize(int(ps), _ptr(bk), bk.size, _ptr(ksk), ksk.size))
+
+
+def ps_gate_batch(ps, ops, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
+    words = ps_params(ps).lvl0_words
+    if count is None:
+        count = out.words // words
+    if np.isscalar(ops):
+        ops_arr, stride = np.array([ops], dtype=np.int32), 0
+    else:
+        ops_arr, stride = np.ascontiguousarray(ops, dtype=np.int32), 1
+        assert ops_arr.size >= count
+    check(lib.cufhe_amd_ps_gate_batch(int(ps), device, stream, count, _ptr(ops_arr), stride, out.ptr, in0.ptr,
+                                      in1.ptr if in1 is not None else None,
+                                      in2.ptr if in2 is not None else None, words))
+
+
+def ps_blind_rotate_batch(ps, tlwe0, acc, count, steps=-1, device=0, stream=None):
+    check(lib.cufhe_amd_ps_blind_rotate_batch(int(ps), device, stream, count, tlwe0.ptr, acc.ptr, steps))
+
+
+def ps_keyswitch_batch(ps, tlwe1, tlwe0, count, device=0, stream=None):
+    check(lib.cufhe_amd_ps_keyswitch_batch(int(ps), device, stream, count, tlwe1.ptr, tlwe0.ptr))

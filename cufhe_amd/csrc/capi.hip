@@ -19,6 +19,7 @@
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
 #include "kernels_ll.hip.h"
+#include "kernels_ps.hip.h"
 
 using namespace cufhe_amd;
 
@@ -497,6 +498,7 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 
 #include "sched_hip.inc.h"
 #include "lvl2.inc.h"
+#include "paramsets.inc.h"
 
 extern "C" {
 
@@ -604,6 +606,7 @@ int cufhe_amd_cleanup(void)
             v->clear();
         }
         if (s.keys_ready) { HIP_TRY(hipFree(s.bk_ntt)); HIP_TRY(hipFree(s.ksk)); }
+        ps_release(i);
         if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
         s.keys2_ready = s.br2_lds_opt_in = false;

@@ -1,0 +1,350 @@
+// kernels_ps.hip.h -- the gate path templated on a PARAMETER SET.
+//
+// The reference selects its TFHE parameters at compile time (CMakeLists.txt:8-24: USE_80BIT_SECURITY,
+// USE_CGGI19, USE_CONCRETE -> TFHEpp params.hpp) and its kernels are templates over those structs, with
+// two ring sizes (N = 1024 / N = 512, include/ntt_gpu/ntt_gpuntt.cuh:232-329) and any k
+// (src/bootstrap_gpu.cu:402-421: "required for k > 1").  kernels.hip.h is hand-scheduled for the one set
+// BASELINE.json names; this file is the general path: the same algorithm written once over a `PS`
+// struct and instantiated for every set in kParamSets, including the default one (which lets the tests
+// compare the two implementations with each other and with the oracle).
+//
+//   * ring: N = 1024 (ntt_wave.h, 16 coefficients per lane) or N = 512 (the stand-alone 512-point
+//     transform of ntt_wave512.h, 8 per lane);
+//   * k + 1 components: (k+1) l TRGSW rows, k + 1 sums;
+//   * exactness: with the key read as signed 32-bit words the sum of one output coefficient is bounded by
+//     (k+1) l N (Bg/2) 2^31; a set for which that exceeds p/2 (the FP64 prime of fpfield.h) takes its key
+//     in `limbs` balanced limbs of `limb_bits` bits, one exact product per limb, recombined with shifts
+//     mod 2^32 -- the split kernels_lvl2.hip.h uses for the 64-bit torus.  static_asserts pick nothing
+//     silently: a set that does not fit does not compile.
+//
+// One workgroup of 8 waves per blind rotation (the shape of blind_rotate_wg_kernel): waves take TRGSW
+// rows round-robin (digit polynomial -> forward transform -> products with the row's (k+1) x limbs key
+// polynomials, added into LDS sums with ds_add_f64: exact integers, order-free), barrier, waves take
+// sums round-robin (inverse transform, centred lift, shifted add into the accumulator in LDS), barrier.
+#pragma once
+#include "kernels.hip.h"
+#include "ntt_wave512.h"
+
+namespace cufhe_amd {
+
+// ---- parameter sets -------------------------------------------------------------------------
+struct PsDefault {      // BASELINE.json: n = 630, N = 1024, k = 1
+    static constexpr const char* name = "default";
+    static constexpr int n = 630, Nbit = 10, k = 1, l = 3, Bgbit = 6, t = 8, basebit = 2, limbs = 1, limb_bits = 32;
+};
+struct PsK2N512 {       // k = 2 over the N = 512 ring (the shape -DUSE_CONCRETE builds in the reference)
+    static constexpr const char* name = "k2n512";
+    static constexpr int n = 630, Nbit = 9, k = 2, l = 3, Bgbit = 6, t = 8, basebit = 2, limbs = 1, limb_bits = 32;
+};
+struct PsCggi16 {       // the original TFHE 80-bit set (-DUSE_80BIT_SECURITY): l = 2, Bg = 2^10 -> two 16-bit key limbs
+    static constexpr const char* name = "cggi16";
+    static constexpr int n = 500, Nbit = 10, k = 1, l = 2, Bgbit = 10, t = 8, basebit = 2, limbs = 2, limb_bits = 16;
+};
+constexpr int kParamSets = 3;
+
+template <class PS>
+struct PsDims {
+    static constexpr int N = 1 << PS::Nbit;
+    static constexpr int R = N / 64;                        // coefficients per lane
+    static constexpr int K1 = PS::k + 1;
+    static constexpr int ROWS = K1 * PS::l;
+    static constexpr int SUMS = K1 * PS::limbs;
+    static constexpr int lvl0_words = PS::n + 1;
+    static constexpr int lvl1_words = PS::k * N + 1;
+    static constexpr size_t bk_step_polys = (size_t)ROWS * K1;                  // torus polynomials per CMux step
+    static constexpr size_t bk_words = (size_t)PS::n * bk_step_polys * N;
+    static constexpr size_t bk_ntt_step_doubles = (size_t)ROWS * SUMS * N;      // [row][out][limb][N]
+    static constexpr int ks_numbase = 1 << (PS::basebit - 1);
+    static constexpr size_t ksk_words = (size_t)PS::k * N * PS::t * ks_numbase * lvl0_words;
+    // exactness of one limb's external product and of the unreduced LDS sums
+    static constexpr double sum_bound = (double)K1 * PS::l * N * (double)(1u << (PS::Bgbit - 1)) *
+                                        (PS::limbs == 1 ? 2147483648.0 : (double)(1u << (PS::limb_bits - 1)));
+    static_assert(sum_bound < fpf::P / 2, "external product exceeds p/2: give the set more / narrower key limbs");
+    static_assert(PS::limbs * PS::limb_bits >= 32, "key limbs do not cover the torus word");
+    static_assert(ROWS * fpf::after_mulmod(0.5001) < fpf::LIM_WIDE, "row sums exceed 2^53");
+    static_assert(PS::l * PS::Bgbit <= 31 && PS::t * PS::basebit <= 32 && PS::Bgbit <= 10, "decomposition out of range");
+    static_assert(PS::Nbit == 9 || PS::Nbit == 10, "ring sizes: 512 and 1024");
+    static_assert(PS::n <= 640, "abar list is sized for n <= 640");
+};
+
+template <class PS>
+__host__ __device__ constexpr uint32_t ps_decomp_offset()
+{
+    uint32_t o = 0;
+    for (int i = 1; i <= PS::l; i++) o += (1u << (PS::Bgbit - 1)) << (32 - i * PS::Bgbit);
+    return o + (1u << (32 - PS::l * PS::Bgbit - 1));
+}
+template <class PS>
+__host__ __device__ constexpr uint32_t ps_decomp_signmask()
+{
+    uint32_t m = 0;
+    for (int i = 1; i <= PS::l; i++) m |= (1u << (PS::Bgbit - 1)) << (32 - i * PS::Bgbit);
+    return m;
+}
+
+// ---- one polynomial per wave, either ring size ------------------------------------------------
+template <int NBIT> struct Poly;
+template <> struct Poly<10> {
+    static constexpr int R = 16, tile_bytes = kTileBytes, table_bytes = kLdsTableBytes;
+    using Tables = NttTables;
+    using Ctx = WaveCtx;
+    static __device__ __forceinline__ void load_tables(char* lds, const Tables* gt) { load_tables_to_lds((double*)lds, gt); }
+    static __device__ __forceinline__ Ctx ctx(char* lds, int tile_off, int tables_off, const Tables* gt, int lane)
+    {
+        return make_wave_ctx(lds, tile_off, tables_off, gt, lane);
+    }
+    // natural order in (element lane + 64 r in register r), spectrum order out; any |x| < 2^32
+    static __device__ __forceinline__ void forward(double (&x)[R], const Ctx& c) { ntt_forward<false>(x, c); }
+    static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt_inverse(x, c); }
+};
+template <> struct Poly<9> {
+    static constexpr int R = 8, tile_bytes = kTile512Bytes, table_bytes = kLds512TableBytes;
+    using Tables = Ntt512Tables;        // the stand-alone 512-point negacyclic transform (capi.hip: tables512[2])
+    using Ctx = Wave512Ctx;
+    static __device__ __forceinline__ void load_tables(char* lds, const Tables* gt)
+    {
+        const double* src = gt->tb_fwd;          // tb_fwd .. tc_inv are contiguous
+        for (int i = threadIdx.x; i < kLds512TableDoubles; i += blockDim.x) ((double*)lds)[i] = src[i];
+    }
+    static __device__ __forceinline__ Ctx ctx(char* lds, int tile_off, int tables_off, const Tables* gt, int lane)
+    {
+        return make_wave512_ctx(lds, tile_off, tables_off, gt, lane);
+    }
+    static __device__ __forceinline__ void forward(double (&x)[R], const Ctx& c) { ntt512_forward(x, c); }
+    static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt512_inverse(x, c); }
+};
+
+constexpr int kPsWaves = 8;
+constexpr int kPsThreads = 64 * kPsWaves;
+
+template <class PS>
+struct PsLds {
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    static constexpr int tables = 0;
+    static constexpr int tiles = tables + PO::table_bytes;
+    static constexpr int acc = tiles + kPsWaves * PO::tile_bytes;              // [K1][N] u32
+    static constexpr int sums = (acc + D::K1 * D::N * 4 + 15) & ~15;           // [SUMS][R][64] f64
+    static constexpr int abar = sums + D::SUMS * D::N * 8;
+    static constexpr int bytes = abar + kAbarBytes + 16;
+    static_assert(bytes <= 160 * 1024, "parameter set does not fit the CU's LDS");
+};
+
+// ----------------------------------------------------------------------------------------------
+// BK (torus words) -> NTT domain, one wave per (polynomial, limb).
+// bk: [step][row][out][N] u32 (TFHEpp's BootstrappingKey layout, src/bootstrap_gpu.cu:43-49);
+// bk_ntt: [step][row][out][limb][R][64] doubles, scaled by N^-1, centred.
+// ----------------------------------------------------------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
+    double* __restrict__ bk_ntt, const uint32_t* __restrict__ bk, size_t polys,
+    const typename Poly<PS::Nbit>::Tables* __restrict__ gt, double n_inverse)
+{
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PO::load_tables(smem, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t w = (size_t)blockIdx.x * kNttWavesPerBlock + wave;
+    if (w >= polys * PS::limbs) return;
+    const size_t poly = w / PS::limbs;
+    const int limb = (int)(w % PS::limbs);
+    const typename PO::Ctx ctx = PO::ctx(smem, PO::table_bytes + wave * PO::tile_bytes, 0, gt, lane);
+    double x[PO::R];
+#pragma unroll
+    for (int r = 0; r < PO::R; r++) {
+        int64_t s = (int32_t)bk[poly * D::N + lane + 64 * r];
+        if (PS::limbs > 1) {      // balanced limbs: s = sum_i limb_i 2^(i limb_bits), the top limb takes the rest
+            int64_t v = 0;
+            for (int m = 0; m <= limb; m++) {
+                v = (m == PS::limbs - 1) ? s : (int64_t)((uint64_t)s << (64 - PS::limb_bits)) >> (64 - PS::limb_bits);
+                s = (s - v) >> PS::limb_bits;
+            }
+            x[r] = (double)v;
+        } else {
+            x[r] = (double)s;
+        }
+    }
+    PO::forward(x, ctx);
+    double* dst = bk_ntt + (poly * PS::limbs + limb) * D::N;
+#pragma unroll
+    for (int r = 0; r < PO::R; r++) dst[r * 64 + lane] = fpf::reduce(fpf::mulmod_wide(x[r], n_inverse));
+}
+
+// ----------------------------------------------------------------------------------------------
+// Blind rotate (+ sample extract at 0), one workgroup per rotation.
+// descs: in0/in1 lvl0 TLWEs (n + 1 words), out a lvl1 TLWE (k N + 1 words) or null; acc_dump (optional)
+// receives the raw accumulator ((k+1) N words).  include/gatebootstrapping_gpu.cuh:29-52,115-345,
+// src/bootstrap_gpu.cu:366-381.
+// ----------------------------------------------------------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const typename Poly<PS::Nbit>::Tables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
+{
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    using L = PsLds<PS>;
+    constexpr int N = D::N, R = D::R, K1 = D::K1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    PO::load_tables(smem + L::tables, gt);
+    uint32_t* accL = (uint32_t*)(smem + L::acc);
+    double* sumL = (double*)(smem + L::sums);
+    uint16_t* abar_lds = (uint16_t*)(smem + L::abar);
+    uint32_t* bbar_slot = (uint32_t*)(smem + L::abar + kAbarBytes);
+
+    const LinDesc d = descs[g];
+    for (int i = tid; i <= PS::n; i += kPsThreads) {      // pre-add and modulus switch, :316-345
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < PS::n) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - PS::Nbit))) >> (32 - 1 - PS::Nbit));
+        else *bbar_slot = 2 * N - ((c + d.off) >> (32 - 1 - PS::Nbit));
+    }
+    for (int i = tid; i < D::SUMS * N; i += kPsThreads) sumL[i] = 0.0;
+    __syncthreads();
+    {   // RotatedTestVector, :29-52: mask components zero, body +-mu
+        const uint32_t bbar = *bbar_slot;
+        for (int e = tid; e < N; e += kPsThreads) {
+            const bool neg = (bbar != 2 * N) && (((uint32_t)e < (bbar & (N - 1))) != ((bbar >> PS::Nbit) != 0));
+            for (int j = 0; j < PS::k; j++) accL[j * N + e] = 0;
+            accL[PS::k * N + e] = neg ? 0u - kMu : kMu;
+        }
+    }
+    __syncthreads();
+    const typename PO::Ctx ctx = PO::ctx(smem, L::tiles + wave * PO::tile_bytes, L::tables, gt, lane);
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        const int alo = (int)(abar & (N - 1));
+        const bool ahi = (abar >> PS::Nbit) != 0;
+#pragma unroll 1
+        for (int row = wave; row < D::ROWS; row += kPsWaves) {
+            const int j = row / PS::l, dg = row % PS::l;
+            const uint32_t* accj = accL + j * N;
+            const uint32_t pos = 32 - (dg + 1) * PS::Bgbit;
+            double x[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {        // (X^abar - 1) acc_j, decomposed: :157-181
+                const int e = lane + 64 * r;
+                const uint32_t rot = accj[(e - alo) & (N - 1)];
+                const bool neg = (e < alo) != ahi;
+                const uint32_t t = ((neg ? 0u - rot : rot) - accj[e] + ps_decomp_offset<PS>()) ^ ps_decomp_signmask<PS>();
+                x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, pos, (uint32_t)PS::Bgbit);
+            }
+            PO::forward(x, ctx);
+#pragma unroll
+            for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
+            const double* key = bk_ntt + ((size_t)i * D::ROWS + row) * (size_t)(D::SUMS * N);
+#pragma unroll 1
+            for (int s = 0; s < D::SUMS; s++) {      // :206-221, one product per (output component, key limb)
+                const double* kp = key + s * N + lane;
+                double* sp = sumL + s * N + lane;
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    __hip_atomic_fetch_add(sp + r * 64, fpf::mulmod(x[r], kp[r * 64]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = wave; s < D::SUMS; s += kPsWaves) {      // :227-284
+            double* sp = sumL + s * N + lane;
+            double A[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) { A[r] = fpf::reduce(sp[r * 64]); sp[r * 64] = 0.0; }
+            PO::inverse(A, ctx);
+            const int out = s / PS::limbs, shl = (s % PS::limbs) * PS::limb_bits;
+            uint32_t* acck = accL + out * N + lane;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t v = fpf::lift_u32(A[r]) << shl;       // the limb's exact sum, shifted, mod 2^32
+                if (PS::limbs == 1) acck[64 * r] += v;
+                else __hip_atomic_fetch_add(acck + 64 * r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * K1 * N;
+        for (int e = tid; e < K1 * N; e += kPsThreads) o[e] = accL[e];
+    }
+    if (d.out) {   // __SampleExtractIndex__<P,0>: per mask component a'[0] = a[0], a'[m] = -a[N-m]; b' = b[0]
+        uint32_t* o = d.out;
+        for (int e = tid; e < PS::k * N; e += kPsThreads) {
+            const int j = e / N, m = e % N;
+            o[e] = m == 0 ? accL[j * N] : 0u - accL[j * N + N - m];
+        }
+        if (tid == 0) o[PS::k * N] = accL[PS::k * N];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Key switch lvl1 -> lvl0 with the linear pre-add fused (include/keyswitch_gpu.cuh:83-188), one
+// workgroup (16 waves) per ciphertext: wave w takes a'_j for j in [w kN/16, (w+1) kN/16), lane L the output
+// words L, L + 64, ...; rows straight from L2; the 16 partial sums are added through LDS.
+// ksk: [kN][t][2^(basebit-1)][n + 1] u32, the reference's layout unpadded.
+// ----------------------------------------------------------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(kKsThreads) void keyswitch_ps_kernel(
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk)
+{
+    using D = PsDims<PS>;
+    constexpr int KN = PS::k * D::N, W0 = D::lvl0_words, PER = (W0 + 63) / 64;
+    __shared__ uint32_t part[kKsWaves][PER * 64];
+    __shared__ uint16_t dig[KN];
+    __shared__ uint32_t bprime_s;
+    static_assert(PS::t * PS::basebit <= 16, "digit word is 16 bits");
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const LinDesc d = descs[g];
+    uint32_t koff = (PS::t * PS::basebit < 32) ? 1u << (32 - (1 + PS::basebit * PS::t)) : 0u;     // roundoffset, :92-98
+    for (int i = 1; i <= PS::t; i++) koff += ((1u << PS::basebit) / 2) << (32 - i * PS::basebit); // iksoffsetgen, :13-23
+    for (int j = tid; j <= KN; j += kKsThreads) {
+        const uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
+        if (j == KN) bprime_s = v + d.off;
+        else dig[j] = (uint16_t)((v + koff) >> 16);
+    }
+    __syncthreads();
+    uint32_t res[PER];
+#pragma unroll
+    for (int m = 0; m < PER; m++) res[m] = 0;
+    constexpr int JW = KN / kKsWaves;
+#pragma unroll 1
+    for (int jj = 0; jj < JW; jj++) {
+        const int j = wave * JW + jj;
+        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+#pragma unroll
+        for (int kap = 0; kap < PS::t; kap++) {
+            const int val = (int)((dj >> (16 - (kap + 1) * PS::basebit)) & ((1u << PS::basebit) - 1)) - (1 << (PS::basebit - 1));
+            if (val == 0) continue;       // wave-uniform
+            const int v = val > 0 ? val : -val;
+            const uint32_t* row = ksk + (((size_t)j * PS::t + kap) * D::ks_numbase + (v - 1)) * W0;
+#pragma unroll
+            for (int m = 0; m < PER; m++) {
+                const int i = lane + 64 * m;
+                const uint32_t w = i < W0 ? row[i] : 0u;
+                res[m] = val > 0 ? res[m] - w : res[m] + w;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < PER; m++) part[wave][lane + 64 * m] = res[m];
+    __syncthreads();
+    for (int i = tid; i < W0; i += kKsThreads) {
+        uint32_t v = (i == PS::n) ? bprime_s : 0u;
+#pragma unroll
+        for (int w = 0; w < kKsWaves; w++) v += part[w][i];
+        d.out[i] = v;
+    }
+}
+
+}  // namespace cufhe_amd

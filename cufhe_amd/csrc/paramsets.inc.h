@@ -1,0 +1,248 @@
+// paramsets.inc.h -- host side of the parameter-set-generic gate path (kernels_ps.hip.h); included by
+// capi.hip.  The reference chooses its parameter set when it is built (CMakeLists.txt:8-24); here every
+// set of kernels_ps.hip.h is compiled in and chosen by index at run time.  Gates take and return lvl0
+// ciphertexts of the chosen set: blind rotate -> sample extract -> key switch (__HomGate__ br -> iks,
+// src/bootstrap_gpu.cu:402-421; Mux :515-588; Not / Copy :681-703).
+
+namespace {
+
+struct PsState {
+    bool ready = false, lds_opt_in = false;
+    double* bk_ntt = nullptr;
+    uint32_t* ksk = nullptr;
+};
+std::deque<PsState> g_ps;        // [set * max devices + device], sized on first use
+
+PsState& ps_state(int set, int device)
+{
+    if (g_ps.size() < (size_t)kParamSets * 64) g_ps.resize((size_t)kParamSets * 64);
+    return g_ps[(size_t)set * 64 + device];
+}
+
+template <class F>
+int ps_dispatch(int set, F f)
+{
+    switch (set) {
+        case 0: return f(PsDefault{});
+        case 1: return f(PsK2N512{});
+        case 2: return f(PsCggi16{});
+    }
+    return fail(-1, "unknown parameter set");
+}
+
+template <class PS>
+const typename Poly<PS::Nbit>::Tables* ps_tables(DeviceState& s)
+{
+    if constexpr (PS::Nbit == 10) return s.tables;
+    else return s.tables512 + 2;            // the stand-alone 512-point negacyclic transform
+}
+
+template <class PS>
+int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count, int steps, uint32_t* dump)
+{
+    if (count == 0) return 0;
+    if (!ps.lds_opt_in) {
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsLds<PS>::bytes));
+        ps.lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(kPsThreads), PsLds<PS>::bytes, st, d, (int)count,
+                       ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <class PS, class GetGate>
+int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
+{
+    using D = PsDims<PS>;
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    PsState& ps = ps_state(set, device);
+    if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+    if (count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t negmu = 0u - kMu;
+    size_t nrot = 0;
+    for (size_t g = 0; g < count; g++) {
+        const int op = get(g).op;
+        if (op < 0 || op >= CUFHE_AMD_NUM_OPS) return fail(-1, "unknown gate op");
+        if (op == CUFHE_AMD_MUX || op == CUFHE_AMD_NMUX) nrot += 2;
+        else if (op < CUFHE_AMD_MUX) nrot += 1;
+    }
+    Scratch sc;
+    if (int rc = open_scratch(s, st, nrot * D::lvl1_words * sizeof(uint32_t) + (count * 4 + 8) * sizeof(LinDesc) + 8192, &sc)) return rc;
+    uint32_t* tmp1 = nullptr;
+    if (nrot)
+        if (int rc = sc.alloc((void**)&tmp1, nrot * D::lvl1_words * sizeof(uint32_t))) return rc;
+    std::vector<LinDesc> rot, ks, lin;
+    size_t ir = 0;
+    for (size_t g = 0; g < count; g++) {
+        const GateRef gr = get(g);
+        if (!gr.out || !gr.in0) return fail(-1, "null ciphertext pointer");
+        if (gr.op == CUFHE_AMD_NOT || gr.op == CUFHE_AMD_COPY) {
+            lin.push_back({gr.in0, gr.in0, gr.out, gr.op == CUFHE_AMD_NOT ? -1 : 1, 0, 0u, 0u});
+            continue;
+        }
+        if (!gr.in1) return fail(-1, "gate needs a second operand");
+        if (gr.op == CUFHE_AMD_MUX || gr.op == CUFHE_AMD_NMUX) {
+            if (!gr.in2) return fail(-1, "mux needs a third operand");
+            uint32_t* ta = tmp1 + (ir + 0) * D::lvl1_words;
+            uint32_t* tb = tmp1 + (ir + 1) * D::lvl1_words;
+            const bool neg = gr.op == CUFHE_AMD_NMUX;
+            rot.push_back({gr.in0, gr.in1, ta, 1, 1, negmu, 0u});
+            rot.push_back({gr.in0, gr.in2, tb, -1, 1, negmu, 0u});
+            ks.push_back({ta, tb, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            ir += 2;
+            continue;
+        }
+        uint32_t* t1 = tmp1 + ir * D::lvl1_words;
+        rot.push_back({gr.in0, gr.in1, t1, kGateTab[gr.op][0], kGateTab[gr.op][1], (uint32_t)kGateTab[gr.op][2] * kMu, 0u});
+        ks.push_back({t1, t1, gr.out, 1, 0, 0u, 0u});
+        ir += 1;
+    }
+    LinDesc *drot, *dks, *dlin;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = upload_descs(s, sc, lin, &dlin)) return rc;
+    if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, nullptr)) return rc;
+    if (!ks.empty()) {
+        hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)ks.size()), dim3(kKsThreads), 0, st, dks, (int)ks.size(), ps.ksk);
+        HIP_TRY(hipGetLastError());
+    }
+    return launch_lincomb(st, dlin, lin.size(), D::lvl0_words);
+}
+
+void ps_release(int device)
+{
+    for (int set = 0; set < kParamSets; set++) {
+        if (g_ps.empty()) return;
+        PsState& ps = ps_state(set, device);
+        if (!ps.ready) continue;
+        (void)hipFree(ps.bk_ntt);
+        (void)hipFree(ps.ksk);
+        ps = PsState{};
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cufhe_amd_ps_count(void) { return kParamSets; }
+
+int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* p)
+{
+    if (!p) return fail(-1, "null");
+    return ps_dispatch(set, [&](auto ps) {
+        using PS = decltype(ps);
+        using D = PsDims<PS>;
+        memset(p, 0, sizeof(*p));
+        strncpy(p->name, PS::name, sizeof(p->name) - 1);
+        p->n = PS::n; p->N = D::N; p->nbit = PS::Nbit; p->k = PS::k; p->l = PS::l; p->Bgbit = PS::Bgbit;
+        p->t = PS::t; p->basebit = PS::basebit; p->key_limbs = PS::limbs; p->key_limb_bits = PS::limb_bits; p->mu = kMu;
+        p->lvl0_words = D::lvl0_words; p->lvl1_words = D::lvl1_words;
+        p->bk_words = D::bk_words; p->ksk_words = D::ksk_words;
+        p->bk_ntt_bytes = (uint64_t)PS::n * D::bk_ntt_step_doubles * sizeof(double);
+        return 0;
+    });
+}
+
+int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!bk || !ksk) return fail(-1, "null key pointer");
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        using PO = Poly<PS::Nbit>;
+        if (bk_words != D::bk_words) return fail(-1, "bootstrapping key has the wrong size for this parameter set");
+        if (ksk_words != D::ksk_words) return fail(-1, "key-switching key has the wrong size for this parameter set");
+        for (int i = 0; i < g_gpu_num; i++) {
+            if (int rc = ensure_ntt(i)) return rc;
+            DeviceState& s = g_dev[i];
+            PsState& ps = ps_state(set, i);
+            HIP_TRY(hipSetDevice(i + g_device_base));
+            if (ps.ready) {
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(ps.bk_ntt));
+                HIP_TRY(hipFree(ps.ksk));
+                ps = PsState{};
+            }
+            HIP_TRY(hipMalloc((void**)&ps.bk_ntt, (size_t)PS::n * D::bk_ntt_step_doubles * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&ps.ksk, D::ksk_words * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(ps.ksk, ksk, D::ksk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+            uint32_t* d_bk = nullptr;
+            HIP_TRY(hipMalloc((void**)&d_bk, D::bk_words * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(d_bk, bk, D::bk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+            const size_t polys = D::bk_words / D::N, waves = polys * PS::limbs;
+            const unsigned blocks = (unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+            hipLaunchKernelGGL(bk_to_ntt_ps_kernel<PS>, dim3(blocks), dim3(kNttThreads), PO::table_bytes + kNttWavesPerBlock * PO::tile_bytes, 0,
+                               ps.bk_ntt, d_bk, polys, ps_tables<PS>(s), balanced(powmod_u64(D::N, fpf::P_U64 - 2)));
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(d_bk));
+            ps.ready = true;
+        }
+        return 0;
+    });
+}
+
+int cufhe_amd_ps_gate_batch(int set, int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
+                            uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words)
+{
+    if (!ops) return fail(-1, "null ops");
+    return ps_dispatch(set, [&](auto psx) {
+        return ps_run_gates<decltype(psx)>(set, device, stream, count, [&](size_t g) {
+            return GateRef{ops[g * (size_t)ops_stride], out + g * stride_words, in0 ? in0 + g * stride_words : nullptr,
+                           in1 ? in1 + g * stride_words : nullptr, in2 ? in2 + g * stride_words : nullptr};
+        });
+    });
+}
+
+int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe0, uint32_t* acc, int steps)
+{
+    if (int rc = use_device(device)) return rc;
+    if (!tlwe0 || !acc) return fail(-1, "null pointer");
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        DeviceState& s = g_dev[device];
+        PsState& ps = ps_state(set, device);
+        if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+        const int st_steps = (steps < 0 || steps > PS::n) ? PS::n : steps;
+        hipStream_t st = (hipStream_t)stream;
+        std::vector<LinDesc> rot(count);
+        for (size_t g = 0; g < count; g++) rot[g] = {tlwe0 + g * D::lvl0_words, tlwe0 + g * D::lvl0_words, nullptr, 1, 0, 0u, 0u};
+        Scratch sc;
+        if (int rc = open_scratch(s, st, count * sizeof(LinDesc) + 4096, &sc)) return rc;
+        LinDesc* d;
+        if (int rc = upload_descs(s, sc, rot, &d)) return rc;
+        return ps_launch_blind_rotate<PS>(s, ps, st, d, count, st_steps, acc);
+    });
+}
+
+int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1, uint32_t* tlwe0)
+{
+    if (int rc = use_device(device)) return rc;
+    if (!tlwe0 || !tlwe1) return fail(-1, "null pointer");
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        DeviceState& s = g_dev[device];
+        PsState& ps = ps_state(set, device);
+        if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+        if (count == 0) return 0;
+        hipStream_t st = (hipStream_t)stream;
+        std::vector<LinDesc> ks(count);
+        for (size_t g = 0; g < count; g++) ks[g] = {tlwe1 + g * D::lvl1_words, tlwe1 + g * D::lvl1_words, tlwe0 + g * D::lvl0_words, 1, 0, 0u, 0u};
+        Scratch sc;
+        if (int rc = open_scratch(s, st, count * sizeof(LinDesc) + 4096, &sc)) return rc;
+        LinDesc* d;
+        if (int rc = upload_descs(s, sc, ks, &d)) return rc;
+        hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, ps.ksk);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+}
+
+}  // extern "C"

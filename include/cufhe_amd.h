@@ -223,6 +223,34 @@ int cufhe_amd_lvl2_blind_rotate_batch(int device, void* stream, size_t count, co
 int cufhe_amd_lvl2_keyswitch_batch(int device, void* stream, size_t count, const uint64_t* tlwe2,
                                    uint32_t* tlwe0);
 
+/* ---- other parameter sets (CMakeLists.txt:8-24: USE_80BIT_SECURITY / USE_CGGI19 / USE_CONCRETE select TFHEpp
+ * parameter headers at build time; k > 1: src/bootstrap_gpu.cu:402-421; N = 512: include/ntt_gpu/ntt_gpuntt.cuh:283-329)
+ * Every set of cufhe_amd/csrc/kernels_ps.hip.h is compiled in and chosen by index: 0 = the default set (the same
+ * numbers as cufhe_amd_get_params, computed by the generic kernels), 1 = "k2n512" (k = 2 over the N = 512 ring),
+ * 2 = "cggi16" (the original TFHE 80-bit set; its external product exceeds the exact range of the FP64 field, so
+ * the key is taken in two 16-bit limbs).  The numeric parameters of TFHEpp's headers are not in the reference tree
+ * (SURVEY.md F3): a set is what cufhe_amd_ps_get_params reports.  Gates take and return lvl0 ciphertexts of the
+ * set (n + 1 words), keys use TFHEpp's layouts with the set's dimensions. */
+typedef struct cufhe_amd_ps_params {
+    char name[32];
+    uint32_t n, N, nbit, k, l, Bgbit, t, basebit, key_limbs, key_limb_bits, mu;
+    uint32_t lvl0_words, lvl1_words;
+    uint64_t bk_words, ksk_words, bk_ntt_bytes;
+} cufhe_amd_ps_params;
+int cufhe_amd_ps_count(void);
+int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* out);
+int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
+/* same contract as cufhe_amd_gate_batch at level 0 */
+int cufhe_amd_ps_gate_batch(int set, int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
+                            uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2,
+                            size_t stride_words);
+/* tlwe0[count][n+1] -> acc[count][(k+1)N] after `steps` CMux steps (< 0: all n) */
+int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe0,
+                                    uint32_t* acc, int steps);
+/* tlwe1[count][kN+1] -> tlwe0[count][n+1] */
+int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1,
+                                 uint32_t* tlwe0);
+
 /* ---- measurement ----
  * When enabled, every blind-rotate / key-switch launch is bracketed by HIP events on the
  * stream it runs on; get_profile synchronises and returns accumulated kernel time. */

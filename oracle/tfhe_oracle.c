@@ -61,8 +61,8 @@ static uint32_t rng_gauss_torus(orc_rng* r, double alpha)
     return (uint32_t)(int64_t)llround(z * alpha * 4294967296.0);
 }
 
-static const double ALPHA0 = 1.0 / 32768.0;     /* 2^-15 */
-static const double ALPHA1 = 1.0 / 33554432.0;  /* 2^-25 */
+static const double ALPHA0 = ORC_ALPHA0;
+static const double ALPHA1 = ORC_ALPHA1;
 
 /* ------------------------------------------------------------------ */
 /* Reference NTT prime arithmetic                                     */
@@ -127,7 +127,9 @@ static void ntt_tables(void)
 #pragma omp critical(orc_tables)
     {
         if (!g_tables_ready) {
-            uint64_t psi = NTT_PSI, psi_inv = mod_pow(psi, NTT_P - 2);
+            /* the reference's psi is a 2048-th root (N = 1024); for N = 512 its square
+             * (ComputePsi, src/ntt_gpu/ntt_gpuntt.cu:40-64) */
+            uint64_t psi = mod_pow(NTT_PSI, 1024 / ORC_N), psi_inv = mod_pow(psi, NTT_P - 2);
             uint64_t f[ORC_N], v[ORC_N];
             f[0] = 1; v[0] = 1;
             for (int i = 1; i < ORC_N; i++) {
@@ -229,7 +231,7 @@ void orc_keygen(uint64_t seed, uint32_t* s0, uint32_t* s1)
     orc_rng r;
     orc_rng_seed(&r, seed);
     for (int i = 0; i < ORC_n; i++) s0[i] = (uint32_t)(orc_rng_next(&r) >> 63);
-    for (int i = 0; i < ORC_N; i++) s1[i] = (uint32_t)(orc_rng_next(&r) >> 63);
+    for (int i = 0; i < ORC_K * ORC_N; i++) s1[i] = (uint32_t)(orc_rng_next(&r) >> 63);
 }
 
 static inline int lvl_dim(int level) { return level ? ORC_K * ORC_N : ORC_n; }
@@ -270,17 +272,29 @@ void orc_tlwe_decrypt_batch(int level, const uint32_t* key, const uint32_t* cts,
     for (size_t g = 0; g < count; g++) bits[g] = (uint8_t)orc_tlwe_decrypt(level, key, cts + g * w);
 }
 
-/* TRLWE encryption of zero under s1: b = a * s1 + e (negacyclic, binary key) */
-static void trlwe_zero(orc_rng* r, const uint32_t* s1, uint32_t* a, uint32_t* b)
+/* TRLWE encryption of zero under s1 (k mask polynomials): b = sum_c a_c * s1_c + e (negacyclic, binary key);
+ * t points at the k+1 polynomials a_0 .. a_{k-1}, b */
+static void trlwe_zero(orc_rng* r, const uint32_t* s1, uint32_t* t)
 {
-    for (int i = 0; i < ORC_N; i++) {
-        a[i] = rng_u32(r);
+    uint32_t* b = t + ORC_K * ORC_N;
+#if ORC_K == 1
+    for (int i = 0; i < ORC_N; i++) {       /* the draw order the committed golden vectors were made with */
+        t[i] = rng_u32(r);
         b[i] = rng_gauss_torus(r, ALPHA1);
     }
-    for (int j = 0; j < ORC_N; j++) {
-        if (!s1[j]) continue;
-        for (int m = 0; m < j; m++) b[m] -= a[ORC_N + m - j];
-        for (int m = j; m < ORC_N; m++) b[m] += a[m - j];
+#else
+    for (int c = 0; c < ORC_K; c++)
+        for (int i = 0; i < ORC_N; i++) t[c * ORC_N + i] = rng_u32(r);
+    for (int i = 0; i < ORC_N; i++) b[i] = rng_gauss_torus(r, ALPHA1);
+#endif
+    for (int c = 0; c < ORC_K; c++) {
+        const uint32_t* a = t + c * ORC_N;
+        const uint32_t* sc = s1 + c * ORC_N;
+        for (int j = 0; j < ORC_N; j++) {
+            if (!sc[j]) continue;
+            for (int m = 0; m < j; m++) b[m] -= a[ORC_N + m - j];
+            for (int m = j; m < ORC_N; m++) b[m] += a[m - j];
+        }
     }
 }
 
@@ -292,12 +306,11 @@ void orc_bkgen(uint64_t seed, const uint32_t* s0, const uint32_t* s1, uint32_t* 
         orc_rng r;
         orc_rng_seed(&r, seed * 0x100000001b3ull + (uint64_t)i + 1);
         for (int row = 0; row < ORC_BK_ROWS; row++) {
-            uint32_t* a = bk + (((size_t)i * ORC_BK_ROWS + row) * (ORC_K + 1) + 0) * ORC_N;
-            uint32_t* b = a + ORC_N;
-            trlwe_zero(&r, s1, a, b);
+            uint32_t* t = bk + (((size_t)i * ORC_BK_ROWS + row) * (ORC_K + 1) + 0) * ORC_N;
+            trlwe_zero(&r, s1, t);
             const int j = row / ORC_L, d = row % ORC_L;
             const uint32_t h = (uint32_t)1u << (32 - (d + 1) * ORC_BGBIT);
-            (j == 0 ? a : b)[0] += s0[i] * h;   /* App. B item 4 */
+            t[j * ORC_N] += s0[i] * h;          /* App. B item 4: component j (j < k: a_j, j = k: b) */
         }
     }
 }
@@ -305,7 +318,7 @@ void orc_bkgen(uint64_t seed, const uint32_t* s0, const uint32_t* s1, uint32_t* 
 void orc_kskgen(uint64_t seed, const uint32_t* s0, const uint32_t* s1, uint32_t* ksk)
 {
 #pragma omp parallel for schedule(static)
-    for (int j = 0; j < ORC_N; j++) {
+    for (int j = 0; j < ORC_K * ORC_N; j++) {
         orc_rng r;
         orc_rng_seed(&r, seed * 0x100000001b3ull + 0x5eed0000ull + (uint64_t)j);
         for (int kap = 0; kap < ORC_T; kap++)
@@ -616,6 +629,13 @@ void orc_gate(const orc_evalkey* ek, int op, int level, uint32_t* out,
         bootstrap_lvl1_to_tlwe1(ek, t, ca, in0, cb, in1, off);
         memcpy(out, t, sizeof(t));
     }
+}
+
+const char* orc_get_params(int* out7)
+{
+    const int v[7] = {ORC_n, ORC_NBIT, ORC_K, ORC_L, ORC_BGBIT, ORC_T, ORC_BASEBIT};
+    if (out7) memcpy(out7, v, sizeof(v));
+    return ORC_SET_NAME;
 }
 
 int orc_max_threads(void)

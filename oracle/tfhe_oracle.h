@@ -34,21 +34,56 @@
 extern "C" {
 #endif
 
-enum {
-    ORC_n = 630,       /* lvl0 dimension                      */
-    ORC_NBIT = 10,
-    ORC_N = 1024,      /* lvl1 polynomial degree              */
-    ORC_K = 1,         /* TRLWE mask polynomials              */
-    ORC_L = 3,         /* gadget levels                       */
-    ORC_BGBIT = 6,
-    ORC_T = 8,         /* key-switch levels                   */
-    ORC_BASEBIT = 2,
-    ORC_KS_NUMBASE = 1 << (ORC_BASEBIT - 1),
-    ORC_LVL0_WORDS = ORC_n + 1,
-    ORC_LVL1_WORDS = ORC_K * ORC_N + 1,
-    ORC_TRLWE_WORDS = (ORC_K + 1) * ORC_N,
-    ORC_BK_ROWS = (ORC_K + 1) * ORC_L
-};
+/* Parameter set: compile-time, like the reference's TFHEpp macros (CMakeLists.txt:8-24 ->
+ * add_compile_definitions -> TFHEpp params.hpp).  The default is the set BASELINE.json names; the
+ * Makefile also builds liboracle_<set>.so for the alternative sets of cufhe_amd/csrc/kernels_ps.hip.h:
+ *   -DORC_SET_K2N512   n = 630, N = 512, k = 2, l = 3, Bgbit = 6, t = 8, basebit = 2     (the k = 2 / N = 512
+ *                      shape of src/bootstrap_gpu.cu:413-416 and include/ntt_gpu/ntt_gpuntt.cuh:283-329)
+ *   -DORC_SET_CGGI16   n = 500, N = 1024, k = 1, l = 2, Bgbit = 10, t = 8, basebit = 2   (the original
+ *                      TFHE 80-bit set, what -DUSE_80BIT_SECURITY selects)
+ * The numeric parameters of TFHEpp's headers are not in the reference tree: these sets are
+ * defined HERE, and parity for them means oracle == GPU on the same numbers. */
+#if defined(ORC_SET_K2N512)
+#define ORC_SET_NAME "k2n512"
+#define ORC_n 630
+#define ORC_NBIT 9
+#define ORC_K 2
+#define ORC_L 3
+#define ORC_BGBIT 6
+#define ORC_T 8
+#define ORC_BASEBIT 2
+#define ORC_ALPHA0 (1.0 / 32768.0)
+#define ORC_ALPHA1 (1.0 / 33554432.0)
+#elif defined(ORC_SET_CGGI16)
+#define ORC_SET_NAME "cggi16"
+#define ORC_n 500
+#define ORC_NBIT 10
+#define ORC_K 1
+#define ORC_L 2
+#define ORC_BGBIT 10
+#define ORC_T 8
+#define ORC_BASEBIT 2
+#define ORC_ALPHA0 2.44e-5
+#define ORC_ALPHA1 3.73e-9
+#else
+#define ORC_SET_NAME "default"
+#define ORC_SET_DEFAULT 1
+#define ORC_n 630          /* lvl0 dimension                      */
+#define ORC_NBIT 10
+#define ORC_K 1            /* TRLWE mask polynomials              */
+#define ORC_L 3            /* gadget levels                       */
+#define ORC_BGBIT 6
+#define ORC_T 8            /* key-switch levels                   */
+#define ORC_BASEBIT 2
+#define ORC_ALPHA0 (1.0 / 32768.0)      /* 2^-15 */
+#define ORC_ALPHA1 (1.0 / 33554432.0)   /* 2^-25 */
+#endif
+#define ORC_N (1 << ORC_NBIT)           /* lvl1 polynomial degree */
+#define ORC_KS_NUMBASE (1 << (ORC_BASEBIT - 1))
+#define ORC_LVL0_WORDS (ORC_n + 1)
+#define ORC_LVL1_WORDS (ORC_K * ORC_N + 1)
+#define ORC_TRLWE_WORDS ((ORC_K + 1) * ORC_N)
+#define ORC_BK_ROWS ((ORC_K + 1) * ORC_L)
 #define ORC_MU ((uint32_t)1u << 29)
 #define ORC_BK_WORDS ((size_t)ORC_n * ORC_BK_ROWS * (ORC_K + 1) * ORC_N)
 #define ORC_KSK_WORDS ((size_t)ORC_K * ORC_N * ORC_T * ORC_KS_NUMBASE * ORC_LVL0_WORDS)
@@ -66,7 +101,7 @@ void orc_rng_seed(orc_rng* r, uint64_t seed);
 uint64_t orc_rng_next(orc_rng* r);
 
 /* ---- keys ---- */
-/* binary secret keys; s0[ORC_n], s1[ORC_N] hold 0/1 */
+/* binary secret keys; s0[ORC_n], s1[ORC_K * ORC_N] hold 0/1 */
 void orc_keygen(uint64_t seed, uint32_t* s0, uint32_t* s1);
 /* bk[i][row][comp][N]: TRGSW_{s1}(s0[i]); layout of src/bootstrap_gpu.cu:43-49 */
 void orc_bkgen(uint64_t seed, const uint32_t* s0, const uint32_t* s1, uint32_t* bk);
@@ -130,6 +165,8 @@ void orc_gate_batch(const orc_evalkey* ek, const int32_t* ops, int ops_stride, i
                     size_t count, uint32_t* out, const uint32_t* in0,
                     const uint32_t* in1, const uint32_t* in2, int threads);
 int orc_max_threads(void);
+/* the compiled parameter set: n, Nbit, k, l, Bgbit, t, basebit (7 ints); returns its name */
+const char* orc_get_params(int* out7);
 
 /* plaintext truth table of op (own restatement; cross-checked against
  * oracle/_ref built from test/plain.h) */

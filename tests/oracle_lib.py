@@ -31,6 +31,50 @@ def build():
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
 
 
+SETS = ("default", "k2n512", "cggi16")       # parameter sets the oracle is compiled for (oracle/tfhe_oracle.h)
+
+
+def load_set(name):
+    """The oracle compiled for a named parameter set (liboracle_<name>.so; "default" = liboracle.so)."""
+    if name == "default":
+        return load()
+    path = os.path.join(ORACLE_DIR, f"liboracle_{name}.so")
+    src = os.path.join(ORACLE_DIR, "tfhe_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.basename(path)], stdout=subprocess.DEVNULL)
+    return _bind_gate_path(ctypes.CDLL(path))
+
+
+def _bind_gate_path(L):
+    L.orc_get_params.restype = ctypes.c_char_p
+    L.orc_get_params.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    L.orc_keygen.argtypes = [ctypes.c_uint64, _u32, _u32]
+    L.orc_bkgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u32]
+    L.orc_kskgen.argtypes = [ctypes.c_uint64, _u32, _u32, _u32]
+    L.orc_tlwe_encrypt_batch.argtypes = [ctypes.c_uint64, ctypes.c_int, _u32, _u8, ctypes.c_size_t, _u32]
+    L.orc_tlwe_decrypt_batch.argtypes = [ctypes.c_int, _u32, _u32, ctypes.c_size_t, _u8]
+    L.orc_evalkey_create.restype = ctypes.c_void_p
+    L.orc_evalkey_create.argtypes = [_u32, _u32]
+    L.orc_evalkey_destroy.argtypes = [ctypes.c_void_p]
+    L.orc_blind_rotate.argtypes = [ctypes.c_void_p, _u32, _u32, ctypes.c_int]
+    L.orc_sample_extract0.argtypes = [_u32, _u32]
+    L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32, _u32]
+    L.orc_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                 _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.orc_truth.argtypes = [ctypes.c_int] * 4
+    return L
+
+
+def set_params(L):
+    """(name, dict) of the parameter set a loaded oracle library was compiled for."""
+    v = (ctypes.c_int * 7)()
+    L.orc_get_params.restype = ctypes.c_char_p
+    name = L.orc_get_params(v).decode()
+    d = dict(zip(("n", "Nbit", "k", "l", "Bgbit", "t", "basebit"), list(v)))
+    d["N"] = 1 << d["Nbit"]
+    return name, d
+
+
 def load():
     build()
     L = ctypes.CDLL(LIB)
@@ -86,16 +130,22 @@ def load():
 
 
 class Keys:
-    """Seeded secret keys + evaluation key (deterministic: same seed, same words)."""
+    """Seeded secret keys + evaluation key (deterministic: same seed, same words), for the parameter
+    set the library `L` was compiled for."""
 
     def __init__(self, L, seed=1):
         self.L = L
         self.seed = seed
-        self.s0 = np.zeros(n, np.uint32)
-        self.s1 = np.zeros(N, np.uint32)
+        self.set_name, p = set_params(L)
+        self.n, self.N, self.k = p["n"], p["N"], p["k"]
+        self.words = (self.n + 1, self.k * self.N + 1)
+        self.bk_words = self.n * (self.k + 1) * p["l"] * (self.k + 1) * self.N
+        self.ksk_words = self.k * self.N * p["t"] * (1 << (p["basebit"] - 1)) * (self.n + 1)
+        self.s0 = np.zeros(self.n, np.uint32)
+        self.s1 = np.zeros(self.k * self.N, np.uint32)
         L.orc_keygen(seed, self.s0, self.s1)
-        self.bk = np.zeros(BK_WORDS, np.uint32)
-        self.ksk = np.zeros(KSK_WORDS, np.uint32)
+        self.bk = np.zeros(self.bk_words, np.uint32)
+        self.ksk = np.zeros(self.ksk_words, np.uint32)
         L.orc_bkgen(seed + 1000, self.s0, self.s1, self.bk)
         L.orc_kskgen(seed + 2000, self.s0, self.s1, self.ksk)
         self.ek = L.orc_evalkey_create(self.bk, self.ksk)
@@ -105,26 +155,25 @@ class Keys:
 
     def encrypt(self, bits, level, seed):
         bits = np.ascontiguousarray(bits, dtype=np.uint8).ravel()
-        cts = np.zeros(bits.size * LVL_WORDS[level], np.uint32)
+        cts = np.zeros(bits.size * self.words[level], np.uint32)
         self.L.orc_tlwe_encrypt_batch(seed, level, self.key(level), bits, bits.size, cts)
-        return cts.reshape(bits.size, LVL_WORDS[level])
+        return cts.reshape(bits.size, self.words[level])
 
     def decrypt(self, cts, level):
-        cts = np.ascontiguousarray(cts, dtype=np.uint32).reshape(-1, LVL_WORDS[level])
+        cts = np.ascontiguousarray(cts, dtype=np.uint32).reshape(-1, self.words[level])
         bits = np.zeros(cts.shape[0], np.uint8)
         self.L.orc_tlwe_decrypt_batch(level, self.key(level), cts.ravel(), cts.shape[0], bits)
         return bits
 
     def gate_batch(self, ops, level, in0, in1=None, in2=None, threads=None):
         in0 = np.ascontiguousarray(in0, dtype=np.uint32)
-        count = in0.reshape(-1, LVL_WORDS[level]).shape[0]
+        count = in0.reshape(-1, self.words[level]).shape[0]
         if np.isscalar(ops):
             ops_arr, stride = np.array([ops], np.int32), 0
         else:
             ops_arr, stride = np.ascontiguousarray(ops, np.int32), 1
-        out = np.zeros(count * LVL_WORDS[level], np.uint32)
-        p1 = np.ascontiguousarray(in1, np.uint32).ctypes.data if in1 is not None else None
-        p2 = np.ascontiguousarray(in2, np.uint32).ctypes.data if in2 is not None else None
+        out = np.zeros(count * self.words[level], np.uint32)
+        p1 = p2 = None
         if in1 is not None:
             in1 = np.ascontiguousarray(in1, np.uint32); p1 = in1.ctypes.data
         if in2 is not None:
@@ -132,7 +181,17 @@ class Keys:
         if threads is None:
             threads = self.L.orc_max_threads()
         self.L.orc_gate_batch(self.ek, ops_arr, stride, level, count, out, in0.ravel(), p1, p2, threads)
-        return out.reshape(count, LVL_WORDS[level])
+        return out.reshape(count, self.words[level])
+
+    def blind_rotate(self, tlwe0, steps=-1):
+        acc = np.zeros((self.k + 1) * self.N, np.uint32)
+        self.L.orc_blind_rotate(self.ek, acc, np.ascontiguousarray(tlwe0, np.uint32), steps)
+        return acc
+
+    def keyswitch(self, tlwe1):
+        out = np.zeros(self.n + 1, np.uint32)
+        self.L.orc_keyswitch(self.ek, out, np.ascontiguousarray(tlwe1, np.uint32))
+        return out
 
 
 N2 = 2048

@@ -103,3 +103,24 @@ int main() {
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"), str(bad)],
                        capture_output=True, text=True)
     assert r.returncode != 0, "SetSeed(uint64_t) must not exist without CUFHE_AMD_INSECURE_TEST_KEYS"
+
+
+def test_parameter_sets_match_the_oracle_builds():
+    """cufhe_amd_ps_get_params for every compiled set == the numbers the oracle library of that set was built with."""
+    lib = ctypes.CDLL(LIB)
+    sys_path_hack = os.path.join(ol.ROOT)
+    import sys
+    sys.path.insert(0, sys_path_hack)
+    from cufhe_amd._lib import PsParams
+    lib.cufhe_amd_ps_get_params.argtypes = [ctypes.c_int, ctypes.POINTER(PsParams)]
+    names = []
+    for i in range(lib.cufhe_amd_ps_count()):
+        p = PsParams()
+        assert lib.cufhe_amd_ps_get_params(i, ctypes.byref(p)) == 0
+        names.append(p.name.decode())
+        _, want = ol.set_params(ol.load_set(p.name.decode()))
+        assert (p.n, p.N, p.k, p.l, p.Bgbit, p.t, p.basebit) == tuple(want[k] for k in ("n", "N", "k", "l", "Bgbit", "t", "basebit"))
+        assert p.bk_words == p.n * (p.k + 1) * p.l * (p.k + 1) * p.N
+        assert p.ksk_words == p.k * p.N * p.t * (1 << (p.basebit - 1)) * (p.n + 1)
+    assert names == list(ol.SETS)
+    assert lib.cufhe_amd_ps_get_params(99, ctypes.byref(PsParams())) < 0

@@ -1,0 +1,130 @@
+"""Other parameter sets on the GPU: the generic kernels of cufhe_amd/csrc/kernels_ps.hip.h
+against the CPU oracle compiled for the same set (oracle/liboracle_<set>.so), word for word.
+
+  default   n = 630, N = 1024, k = 1, l = 3, Bg = 2^6     also == the hand-scheduled kernels' words
+  k2n512    n = 630, N = 512,  k = 2, l = 3, Bg = 2^6     the k > 1 handling of src/bootstrap_gpu.cu:402-421 and the
+                                                          512-point transform of include/ntt_gpu/ntt_gpuntt.cuh:283-329
+  cggi16    n = 500, N = 1024, k = 1, l = 2, Bg = 2^10    the external product leaves the exact range of the FP64 prime:
+                                                          two 16-bit key limbs (the fallback of kernels_lvl2.hip.h)
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=ol.SETS)
+def pset(request, engine):
+    name = request.param
+    L = ol.load_set(name)
+    K = ol.Keys(L, seed=5)
+    idx = engine.api.ps_index(name)
+    p = engine.api.ps_params(idx)
+    _, want = ol.set_params(L)
+    assert (p.n, p.N, p.k, p.l, p.Bgbit, p.t, p.basebit) == tuple(want[k] for k in ("n", "N", "k", "l", "Bgbit", "t", "basebit"))
+    assert (p.bk_words, p.ksk_words, p.lvl0_words, p.lvl1_words) == (K.bk_words, K.ksk_words, K.words[0], K.words[1])
+    engine.api.ps_initialize(idx, K.bk, K.ksk)
+    return name, idx, L, K
+
+
+def _up(eng, a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return eng.api.DeviceBuffer(a.size).upload(a)
+
+
+@pytest.mark.parametrize("steps", [0, 1, 2, 3, 41, -1])
+def test_accumulator_words(engine, pset, steps):
+    name, idx, L, K = pset
+    count = 4 if steps == -1 else 6
+    rng = np.random.default_rng(50 + steps)
+    tl = rng.integers(0, 2**32, size=(count, K.n + 1), dtype=np.uint64).astype(np.uint32)
+    tl[0, :4] = 0                      # abar = 0 steps
+    tl[1, K.n] = 0                     # bbar = 2N
+    tl[2, K.n] = 0xFFFFFFFF            # bbar = 1
+    tl[3, :8] = 0x7FFFFFFF
+    tl[3, K.n] = 0x80000000            # bbar = N
+    dacc = engine.api.DeviceBuffer(count * (K.k + 1) * K.N)
+    engine.api.ps_blind_rotate_batch(idx, _up(engine, tl), dacc, count, steps)
+    got = dacc.download().reshape(count, -1)
+    for g in range(count):
+        assert np.array_equal(got[g], K.blind_rotate(tl[g], steps)), f"{name}: accumulator {g} differs after {steps} steps"
+
+
+def test_extreme_key_words(engine, pset):
+    """Key words of maximal magnitude: the sums (per key limb) run closest to the p/2 bound."""
+    name, idx, L, K = pset
+    rng = np.random.default_rng(3)
+    ext = np.array([0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001, 0x7FFF8000, 0x8000], np.uint32)
+    bk = ext[rng.integers(0, ext.size, K.bk_words)]
+    step = K.bk_words // K.n
+    bk[: 2 * step] = 0x80000000
+    ek = L.orc_evalkey_create(bk, K.ksk)
+    engine.api.ps_initialize(idx, bk, K.ksk)
+    try:
+        count, steps = 4, 9
+        tl = rng.integers(0, 2**32, size=(count, K.n + 1), dtype=np.uint64).astype(np.uint32)
+        dacc = engine.api.DeviceBuffer(count * (K.k + 1) * K.N)
+        engine.api.ps_blind_rotate_batch(idx, _up(engine, tl), dacc, count, steps)
+        got = dacc.download().reshape(count, -1)
+        for g in range(count):
+            want = np.zeros((K.k + 1) * K.N, np.uint32)
+            L.orc_blind_rotate(ek, want, np.ascontiguousarray(tl[g]), steps)
+            assert np.array_equal(got[g], want), f"{name}: rotation {g}"
+    finally:
+        L.orc_evalkey_destroy(ek)
+        engine.api.ps_initialize(idx, K.bk, K.ksk)
+
+
+def test_keyswitch_words(engine, pset):
+    name, idx, L, K = pset
+    count = 7
+    rng = np.random.default_rng(6)
+    t1 = rng.integers(0, 2**32, size=(count, K.words[1]), dtype=np.uint64).astype(np.uint32)
+    t1[0] = 0
+    t1[1] = 0xFFFFFFFF
+    d0 = engine.api.DeviceBuffer(count * K.words[0])
+    engine.api.ps_keyswitch_batch(idx, _up(engine, t1), d0, count)
+    got = d0.download().reshape(count, -1)
+    for g in range(count):
+        assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g}"
+
+
+def test_every_gate_words_and_truth_table(engine, pset, keys):
+    name, idx, L, K = pset
+    combos = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.uint8)
+    count = len(combos)
+    ins = [K.encrypt(combos[:, i], 0, seed=900 + i) for i in range(3)]
+    dins = [_up(engine, x) for x in ins]
+    dout = engine.api.DeviceBuffer(count * K.words[0])
+    for op in range(14):
+        engine.api.ps_gate_batch(idx, op, dout, dins[0], dins[1], dins[2], count=count)
+        got = dout.download().reshape(count, -1)
+        assert np.array_equal(got, K.gate_batch(op, 0, ins[0], ins[1], ins[2])), f"{name} {ol.OPS[op]}: words differ from the oracle"
+        assert list(K.decrypt(got, 0)) == [L.orc_truth(op, *map(int, c)) for c in combos], f"{name} {ol.OPS[op]}: decrypt != truth table"
+    if name == "default":
+        # the generic kernels and the hand-scheduled ones are two implementations of one function
+        engine.Initialize(K.bk, K.ksk)
+        try:
+            for op in (0, 5, 10):
+                engine.api.ps_gate_batch(idx, op, dout, dins[0], dins[1], dins[2], count=count)
+                a = dout.download().copy()
+                engine.gate_batch(op, 0, dout, dins[0], dins[1], dins[2], count=count)
+                assert np.array_equal(a, dout.download())
+        finally:
+            engine.Initialize(keys.bk, keys.ksk)
+
+
+def test_mixed_batch(engine, pset):
+    name, idx, L, K = pset
+    count = 48
+    rng = np.random.default_rng(12)
+    bits = rng.integers(0, 2, size=(3, count)).astype(np.uint8)
+    ins = [K.encrypt(bits[i], 0, seed=1300 + i) for i in range(3)]
+    ops = np.array([[3, 4, 5, 0, 10, 12, 13, 11][g % 8] for g in range(count)], np.int32)
+    dins = [_up(engine, x) for x in ins]
+    engine.api.ps_gate_batch(idx, ops, dins[0], dins[0], dins[1], dins[2], count=count)     # out aliases in0
+    got = dins[0].download().reshape(count, -1)
+    assert np.array_equal(got, K.gate_batch(ops, 0, ins[0], ins[1], ins[2]))
+    assert list(K.decrypt(got, 0)) == [L.orc_truth(int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
