@@ -398,11 +398,15 @@ using sched::GateRef;
 
 template <class GetGate>
 int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lvl2.inc.h
+template <class GetGate>
+int run_gates_ps(int set, int device, void* stream, size_t count, GetGate get);   // paramsets.inc.h
+long g_lvl0_param_set = -1;    // >= 0: gates on lvl0 ciphertexts bootstrap through this parameter set (same n as the default)
 
 template <class GetGate>
 int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 {
     if (level == 0 && g_lvl0_ring == 2048) return run_gates_lvl2(device, stream, count, get);
+    if (level == 0 && g_lvl0_param_set >= 0) return run_gates_ps((int)g_lvl0_param_set, device, stream, count, get);
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
@@ -957,6 +961,15 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "tail_split")) { g_tail_split = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
+    if (!strcmp(key, "lvl0_param_set")) {
+        if (value >= 0) {
+            cufhe_amd_ps_params p;
+            if (int rc = cufhe_amd_ps_get_params((int)value, &p)) return rc;
+            if ((int)p.lvl0_words != kLvl0Words) return fail(-1, "lvl0_param_set: the set's lvl0 ciphertexts differ in size from the per-gate API's (n must be 630)");
+        }
+        g_lvl0_param_set = value;
+        return 0;
+    }
     if (!strcmp(key, "lvl0_ring")) {
         if (value != 1024 && value != 2048) return fail(-1, "lvl0_ring must be 1024 or 2048");
         g_lvl0_ring = value;

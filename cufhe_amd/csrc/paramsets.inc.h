@@ -112,6 +112,12 @@ int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
     return launch_lincomb(st, dlin, lin.size(), D::lvl0_words);
 }
 
+template <class GetGate>
+int run_gates_ps(int set, int device, void* stream, size_t count, GetGate get)
+{
+    return ps_dispatch(set, [&](auto psx) { return ps_run_gates<decltype(psx)>(set, device, stream, count, get); });
+}
+
 void ps_release(int device)
 {
     for (int set = 0; set < kParamSets; set++) {

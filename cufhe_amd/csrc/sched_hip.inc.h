@@ -280,7 +280,7 @@ int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_
         if (c->level != out->level) return fail(-1, "operands of one gate must have the same level");
     }
     const DeviceState& ds = g_dev[device];
-    if (!ds.keys_ready && !ds.keys2_ready && !one) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!ds.keys_ready && !ds.keys2_ready && g_lvl0_param_set < 0 && !one) return fail(-3, "Initialize(ek) has not been called for this device");
     if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins)) return sched_error(S->dev(device), rc);
     return 0;
 }

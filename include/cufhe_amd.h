@@ -186,6 +186,8 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
  * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in
  * the C++ shim) runs through the N = 2048 path.
+ * "lvl0_param_set" (default -1): index of a cufhe_amd_ps_* parameter set with n = 630 through which every level-0
+ * entry point bootstraps instead (cufhe_amd_ps_initialize first).
  * "sched_streams" (default 4): internal HIP streams per device over which independent flushes of the
  * per-gate API overlap; "sched_threads" (default 1): one launch worker thread per device (0: launches
  * happen on the issuing thread).  Both before the first ciphertext is created.

@@ -128,3 +128,38 @@ def test_mixed_batch(engine, pset):
     got = dins[0].download().reshape(count, -1)
     assert np.array_equal(got, K.gate_batch(ops, 0, ins[0], ins[1], ins[2]))
     assert list(K.decrypt(got, 0)) == [L.orc_truth(int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
+
+
+def test_per_gate_api_over_a_parameter_set(engine, pset):
+    """cufhe_amd_set_option("lvl0_param_set"): the Stream / Ctxt / Nand ... surface and its scheduler over another set
+    (sets with the default n only: the per-gate API's lvl0 ciphertexts keep their size)."""
+    name, idx, L, K = pset
+    api = engine.api
+    if K.n != ol.n:
+        with pytest.raises(engine.CufheAmdError):
+            api.set_option("lvl0_param_set", idx)
+        return
+    api.set_option("lvl0_param_set", idx)
+    try:
+        count = 24
+        rng = np.random.default_rng(31)
+        bits = rng.integers(0, 2, size=(3, count)).astype(np.uint8)
+        enc = [K.encrypt(bits[i], 0, seed=3100 + i) for i in range(3)]
+        cts = [[api.Ctxt(0) for _ in range(count)] for _ in range(3)]
+        for i in range(3):
+            for g in range(count):
+                cts[i][g].tlwehost[:] = enc[i][g]
+        outs = [api.Ctxt(0) for _ in range(count)]
+        sts = [api.Stream() for _ in range(4)]
+        for s in sts:
+            s.Create()
+        for g in range(count):
+            (api.Nand, api.Xor, api.Mux)[g % 3](outs[g], cts[0][g], cts[1][g], *((cts[2][g],) if g % 3 == 2 else ()), sts[g % 4])
+        api.Synchronize()
+        ops = np.array([[0, 5, 10][g % 3] for g in range(count)], np.int32)
+        got = np.stack([o.tlwehost for o in outs])
+        assert np.array_equal(got, K.gate_batch(ops, 0, enc[0], enc[1], enc[2]))
+        for s in sts:
+            s.Destroy()
+    finally:
+        api.set_option("lvl0_param_set", -1)
