@@ -32,6 +32,7 @@
 #endif
 
 #include "cufhe_amd.hpp"
+#include "cufhe_amd_cereal.hpp"
 
 namespace cufhe {
 namespace legacy {
@@ -299,6 +300,25 @@ inline void ReadPubKeyFromFile(PubKey& pub, const std::string& path)
     if (!f) throw std::runtime_error("cannot open " + path);
     detail::read_vec(f, pub.bk);
     detail::read_vec(f, pub.ksk);
+}
+
+// ---- TFHEpp-written files (cereal portable binary; include/cufhe_amd_cereal.hpp -- UNVERIFIED against real
+// TFHEpp output, see that header) ----
+/// the lvl01 bootstrapping key and lvl10 key-switching key out of a serialised TFHEpp::EvalKey
+inline void ReadPubKeyFromTFHEppEvalKey(PubKey& pub, const std::string& path)
+{
+    const cereal_io::KeyShape s{lvl0::n, lvl1::n, lvl1::k, lvl1::l, TFHEpp::lvl10param::t, TFHEpp::lvl10param::basebit};
+    cereal_io::LoadEvalKey(path, s, pub.bk, pub.ksk);
+}
+/// a serialised std::vector<TLWE<lvl0param>>: returns the ciphertexts' words back to back
+inline std::vector<uint32_t> ReadLvl0CtxtsFromTFHEppFile(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    cereal_io::PortableBinaryReader ar(f);
+    std::vector<uint32_t> flat;
+    cereal_io::LoadTLWEVector(ar, flat, lvl0::k * lvl0::n + 1);
+    return flat;
 }
 
 }  // namespace legacy
