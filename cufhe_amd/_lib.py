@@ -82,6 +82,7 @@ SIGNATURES = {
     "cufhe_amd_ctxt_destroy": (ctypes.c_int, [c_void]),
     "cufhe_amd_ctxt_device_ptr": (c_void, [c_void, ctypes.c_int]),
     "cufhe_amd_enqueue_gate": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "cufhe_amd_enqueue_trlwe_op": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
     "cufhe_amd_enqueue_copy": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),

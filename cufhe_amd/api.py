@@ -159,6 +159,52 @@ class Ctxt:
             pass
 
 
+class Trlwe(Ctxt):
+    """struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134: `trlwehost` ((k+1) N words) + a device buffer per GPU."""
+
+    def __init__(self):
+        self.level = 2
+        self.tlwehost = np.zeros(2 * PARAMS.N, dtype=np.uint32)
+        self.trlwehost = self.tlwehost
+        h = ctypes.c_void_p()
+        check(lib.cufhe_amd_ctxt_create(2, _ptr(self.tlwehost), ctypes.byref(h)))
+        self._h = h
+        _lib.live.add(self)
+
+
+TL_BOOTSTRAP, TL_REFRESH, TL_SEIKS = 100, 101, 102
+
+
+def _trlwe_op(op, copying, out, inp, st):
+    check(lib.cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), op, 1 if copying else 0, out._h, inp._h))
+
+
+def GateBootstrappingTLWE2TRLWElvl01NTT(out, inp, st):     # src/cufhe_gates_gpu.cu:96-104
+    _trlwe_op(TL_BOOTSTRAP, True, out, inp, st)
+
+
+def gGateBootstrappingTLWE2TRLWElvl01NTT(out, inp, st):    # :86-94
+    _trlwe_op(TL_BOOTSTRAP, False, out, inp, st)
+
+
+def Refresh(out, inp, st):                                 # :115-124
+    _trlwe_op(TL_REFRESH, True, out, inp, st)
+
+
+def gRefresh(out, inp, st):                                # :106-113
+    _trlwe_op(TL_REFRESH, False, out, inp, st)
+
+
+def gSampleExtractAndKeySwitch(out, inp, st):              # :126-135 (uploads in.trlwehost, as the reference does)
+    CtxtCopyH2D(inp, st)
+    _trlwe_op(TL_SEIKS, False, out, inp, st)
+
+
+def SampleExtractAndKeySwitch(out, inp, st):               # :137-146
+    gSampleExtractAndKeySwitch(out, inp, st)
+    CtxtCopyD2H(out, st)
+
+
 def CtxtCopyH2D(c, st):
     check(lib.cufhe_amd_enqueue_copy(st.device_id(), st.st(), c._h, 1))
 

@@ -498,6 +498,69 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
     return 0;
 }
 
+// TRLWE-level operations recorded through the scheduler (include/cufhe_gpu.cuh:124-146,209-216,282-285;
+// src/cufhe_gates_gpu.cu:86-146): any mix of
+//   CUFHE_AMD_TL_BOOTSTRAP  lvl0 TLWE -> TRLWE     __BlindRotateGlobal__, src/bootstrap_gpu.cu:317-323
+//   CUFHE_AMD_TL_REFRESH    TRLWE -> TRLWE         __SEIandBootstrap2TRLWE__, :325-364
+//   CUFHE_AMD_TL_SEIKS      TRLWE -> lvl0 TLWE     __SEIandKS__, src/keyswitch_gpu.cu:26-40
+// as ONE launch sequence: sample extracts, one key-switch launch, one blind-rotate launch, scatter.
+int run_trlwe_ops(int device, void* stream, const GateRef* g, size_t n)
+{
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    size_t n_se = 0, n_rot = 0, n_t0 = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!g[i].out || !g[i].in0) return fail(-1, "null operand");
+        switch (g[i].op) {
+            case CUFHE_AMD_TL_BOOTSTRAP: n_rot++; break;
+            case CUFHE_AMD_TL_REFRESH: n_se++; n_rot++; n_t0++; break;
+            case CUFHE_AMD_TL_SEIKS: n_se++; break;
+            default: return fail(-1, "unknown TRLWE-level op");
+        }
+    }
+    Scratch sc;
+    const size_t need = n_se * kLvl1Words * 4 + n_t0 * kLvl0Words * 4 + n_rot * 2 * kN * 4 + (3 * n + 8) * sizeof(LinDesc) + 16384;
+    if (int rc = open_scratch(s, st, need, &sc)) return rc;
+    uint32_t *t1 = nullptr, *t0 = nullptr, *dump = nullptr;
+    if (n_se) if (int rc = sc.alloc((void**)&t1, n_se * kLvl1Words * 4)) return rc;
+    if (n_t0) if (int rc = sc.alloc((void**)&t0, n_t0 * kLvl0Words * 4)) return rc;
+    if (n_rot) if (int rc = sc.alloc((void**)&dump, n_rot * 2 * kN * 4)) return rc;
+    std::vector<LinDesc> se, ks, rot, scat;
+    size_t i_se = 0, i_t0 = 0, i_rot = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (g[i].op == CUFHE_AMD_TL_BOOTSTRAP) {
+            rot.push_back({g[i].in0, g[i].in0, nullptr, 1, 0, 0u, 0u});
+        } else {
+            uint32_t* a = t1 + i_se++ * kLvl1Words;
+            se.push_back({g[i].in0, g[i].in0, a, 1, 0, 0u, 0u});
+            if (g[i].op == CUFHE_AMD_TL_SEIKS) {
+                ks.push_back({a, a, g[i].out, 1, 0, 0u, 0u});
+                continue;
+            }
+            uint32_t* b = t0 + i_t0++ * kLvl0Words;
+            ks.push_back({a, a, b, 1, 0, 0u, 0u});
+            rot.push_back({b, b, nullptr, 1, 0, 0u, 0u});
+        }
+        uint32_t* d = dump + i_rot++ * 2 * kN;
+        scat.push_back({d, d, g[i].out, 1, 0, 0u, 0u});
+    }
+    LinDesc *dse, *dks, *drot, *dscat;
+    if (int rc = upload_descs(s, sc, se, &dse)) return rc;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = upload_descs(s, sc, scat, &dscat)) return rc;
+    if (!se.empty()) {
+        hipLaunchKernelGGL(sample_extract_desc_kernel, dim3((unsigned)(se.size() < 2048 ? se.size() : 2048)), dim3(256), 0, st, dse, (int)se.size());
+        HIP_TRY(hipGetLastError());
+    }
+    if (int rc = launch_keyswitch(s, st, dks, ks.size())) return rc;
+    if (int rc = launch_blind_rotate(s, st, drot, rot.size(), kLvl0N, dump)) return rc;
+    return launch_lincomb(st, dscat, scat.size(), 2 * kN);
+}
+
 }  // namespace
 
 #include "sched_hip.inc.h"

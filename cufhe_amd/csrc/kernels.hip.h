@@ -800,6 +800,17 @@ __global__ __launch_bounds__(256) void sample_extract_kernel(uint32_t* __restric
     }
 }
 
+// the same with one descriptor per TRLWE: in0 = trlwe (2N words), out = lvl1 TLWE (N + 1 words)
+__global__ __launch_bounds__(256) void sample_extract_desc_kernel(const LinDesc* __restrict__ descs, int count)
+{
+    for (int g = blockIdx.x; g < count; g += gridDim.x) {
+        const uint32_t* in = descs[g].in0;
+        uint32_t* o = descs[g].out;
+        for (int m = threadIdx.x; m <= kN; m += blockDim.x)
+            o[m] = (m == kN) ? in[kN] : (m == 0 ? in[0] : 0u - in[kN - m]);
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // CMUX against a caller-supplied TRGSW in the NTT domain (one wave per CMUX):
 // res = c0 + trgsw [x] (c1 - c0), __CMUXNTT__ src/bootstrap_gpu.cu:197-285.  trgsw_ntt holds

@@ -51,6 +51,10 @@ namespace cufhe_amd {
 namespace sched {
 
 struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1; const uint32_t* in2; };
+// Ciphertext kinds ("levels"): 0 = lvl0 TLWE, 1 = lvl1 TLWE, 2 = lvl1 TRLWE (the cuFHETRLWElvl1 of
+// include/cufhe_gpu.cuh:124-134).  Gates are launched per kind of their OUTPUT, except the TRLWE-level
+// operations (bootstrap to TRLWE, Refresh, SampleExtractAndKeySwitch), which mix kinds and form kind 2.
+constexpr int kKinds = 3;
 struct CopyRec { uint32_t* dev; size_t slot; int level; };      // staging word offset <-> a ciphertext's device buffer
 
 // The device layer of ONE device.  Every method returns 0 or a negative status (text through
@@ -158,7 +162,7 @@ struct Delivery { cufhe_amd_ctxt* c; size_t slot; uint64_t token; };
 
 struct Plan {                         // one dependence level of the recorded program
     uint32_t depth = 0;
-    std::vector<GateRef> gates[2];
+    std::vector<GateRef> gates[kKinds];
     std::vector<CopyRec> uploads, downloads;
     std::vector<cufhe_amd_ctxt*> upload_ctxts;     // parallel to uploads
     std::vector<Delivery> deliveries;              // parallel to downloads
@@ -167,10 +171,10 @@ struct Plan {                         // one dependence level of the recorded pr
     std::vector<uint32_t> dep_depths;              // earlier levels this one must follow
     std::vector<void*> streams;                    // caller streams with work in this level
     size_t in_base = 0, out_base = 0;              // offsets in the group's staging blocks
-    size_t gate_count() const { return gates[0].size() + gates[1].size(); }
+    size_t gate_count() const { return gates[0].size() + gates[1].size() + gates[2].size(); }
     void reset()
     {
-        gates[0].clear(); gates[1].clear(); uploads.clear(); downloads.clear(); upload_ctxts.clear(); deliveries.clear();
+        gates[0].clear(); gates[1].clear(); gates[2].clear(); uploads.clear(); downloads.clear(); upload_ctxts.clear(); deliveries.clear();
         dep_depths.clear(); streams.clear();
         in_words = out_words = in_base = out_base = 0;
     }
@@ -231,7 +235,8 @@ class DeviceSched {
     const std::string& error_text() const { return err_; }
     size_t pending_levels() const { return levels_.size(); }
 
-    int record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* const (&ins)[3]);
+    // kind: which launch group the gate joins (the output's level for ordinary gates, 2 for TRLWE-level operations)
+    int record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* const (&ins)[3], int kind = -1);
     int record_copy(void* stream, cufhe_amd_ctxt* c, bool to_device);
     int flush(size_t max_levels = (size_t)-1);
     int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
@@ -266,8 +271,7 @@ class DeviceSched {
     {
         for (void* s : slabs_) be_->free_device(s);
         slabs_.clear();
-        free_slots_[0].clear();
-        free_slots_[1].clear();
+        for (auto& f : free_slots_) f.clear();
     }
 
     // one slot per ciphertext, carved from slabs (the reference pays a cudaMalloc per Ctxt per GPU,
@@ -417,7 +421,7 @@ class DeviceSched {
     std::deque<Group*> live_;                   // launched or queued groups, oldest first
     int sticky_error_ = 0;
 
-    std::vector<uint32_t*> free_slots_[2];
+    std::vector<uint32_t*> free_slots_[kKinds];
     std::vector<void*> slabs_;
 
     std::mutex copy_mu_;                        // held while the launch thread copies out of tlwehost memory
@@ -668,8 +672,9 @@ inline void DeviceSched::record_upload(cufhe_amd_ctxt* c, void* stream)
 }
 
 inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out,
-                                    cufhe_amd_ctxt* const (&ins)[3])
+                                    cufhe_amd_ctxt* const (&ins)[3], int kind)
 {
+    if (kind < 0) kind = out->level;
     ScopedNs timer(&stats_.record_ns);
     // inputs that must be refreshed from the host (may wait for another device: do it first)
     bool need_up[3] = {false, false, false};
@@ -714,7 +719,7 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     po.snap_plan = nullptr;
     po.snap_owned = false;
     use(po, D);
-    p.gates[out->level].push_back(GateRef{op, po.dev, ins[0]->d[device_].dev,
+    p.gates[kind].push_back(GateRef{op, po.dev, ins[0]->d[device_].dev,
                                           ins[1] ? ins[1]->d[device_].dev : nullptr,
                                           ins[2] ? ins[2]->d[device_].dev : nullptr});
     if (copying) {
@@ -800,7 +805,7 @@ inline int DeviceSched::flush(size_t max_levels)
         ngates += p->gate_count();
         stats_.max_level_gates = std::max<uint64_t>(stats_.max_level_gates, p->gate_count());
         if (p->gate_count()) stats_.levels++;
-        for (int l = 0; l < 2; l++)
+        for (int l = 0; l < kKinds; l++)
             if (!p->gates[l].empty()) stats_.launch_sequences++;
     }
     // dependences on levels that were launched earlier on another internal stream
@@ -906,7 +911,7 @@ inline int DeviceSched::launch(Group* g)
     for (Plan* p : g->plans) {
         if (rc) break;
         if (!p->uploads.empty()) step(be_->copy_ctxts(s, p->uploads.data(), p->uploads.size(), g->dev_in + p->in_base, true));
-        for (int l = 0; l < 2 && !rc; l++)
+        for (int l = 0; l < kKinds && !rc; l++)
             if (!p->gates[l].empty()) step(be_->run_gates(s, l, p->gates[l].data(), p->gates[l].size()));
         if (!rc && !p->downloads.empty())
             step(be_->copy_ctxts(s, p->downloads.data(), p->downloads.size(), g->dev_out + p->out_base, false));

@@ -20,7 +20,7 @@ class HipBackend : public sched::Backend {
     explicit HipBackend(int device) : device_(device) {}
     void bind_thread() override { (void)hipSetDevice(device_ + g_device_base); }
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
-    int words(int level) override { return level ? kLvl1Words : kLvl0Words; }
+    int words(int level) override { return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : 2 * kN; }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
     int free_device(void* p) override { return chk(hipFree(p), "hipFree"); }
     int alloc_pinned(size_t bytes, void** p) override { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
@@ -42,7 +42,7 @@ class HipBackend : public sched::Backend {
         hipStream_t st;
         if (int rc = stream(s, &st)) return rc;
         DeviceState& ds = g_dev[device_];
-        for (int level = 0; level < 2; level++) {     // one lincomb (COPY) launch per ciphertext kind
+        for (int level = 0; level < sched::kKinds; level++) {     // one lincomb (COPY) launch per ciphertext kind
             std::vector<LinDesc> d;
             for (size_t i = 0; i < n; i++)
                 if (recs[i].level == level) {
@@ -57,7 +57,7 @@ class HipBackend : public sched::Backend {
             if (int rc = open_scratch(ds, st, d.size() * sizeof(LinDesc) + 4096, &sc)) return keep(rc);
             LinDesc* dd;
             if (int rc = upload_descs(ds, sc, d, &dd)) return keep(rc);
-            if (int rc = launch_lincomb(st, dd, d.size(), level ? kLvl1Words : kLvl0Words)) return keep(rc);
+            if (int rc = launch_lincomb(st, dd, d.size(), words(level))) return keep(rc);
         }
         return 0;
     }
@@ -65,6 +65,7 @@ class HipBackend : public sched::Backend {
     {
         hipStream_t st;
         if (int rc = stream(s, &st)) return rc;
+        if (level == 2) return keep(run_trlwe_ops(device_, (void*)st, g, n));
         return keep(::run_gates(device_, (void*)st, level, n, [&](size_t i) { return g[i]; }));
     }
     int event_create(void** ev) override
@@ -225,7 +226,7 @@ extern "C" {
 
 int cufhe_amd_ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out)
 {
-    if (level != 0 && level != 1) return fail(-1, "level must be 0 or 1");
+    if (level < 0 || level > 2) return fail(-1, "level must be 0, 1 or 2 (TRLWE)");
     if (!host_words || !out) return fail(-1, "null pointer");
     std::lock_guard<std::mutex> lk(g_sched_mu);
     sched::Scheduler* S = scheduler();
@@ -274,6 +275,7 @@ int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_
     cufhe_amd_ctxt* ins[3] = {in0, one ? nullptr : in1, three ? in2 : nullptr};
     sched::Scheduler* S = scheduler();
     if (int rc = sched_check_ctxt(S, out)) return rc;
+    if (out->level > 1) return fail(-1, "gates take lvl0 or lvl1 ciphertexts");
     for (cufhe_amd_ctxt* c : ins) {
         if (!c) continue;
         if (int rc = sched_check_ctxt(S, c)) return rc;
@@ -282,6 +284,31 @@ int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_
     const DeviceState& ds = g_dev[device];
     if (!ds.keys_ready && !ds.keys2_ready && g_lvl0_param_set < 0 && !one) return fail(-3, "Initialize(ek) has not been called for this device");
     if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins)) return sched_error(S->dev(device), rc);
+    return 0;
+}
+
+/* gGateBootstrappingTLWE2TRLWElvl01NTT / gRefresh / gSampleExtractAndKeySwitch and their copying forms
+ * (src/cufhe_gates_gpu.cu:86-146), recorded like gates: `out` / `in` are ciphertext handles of the levels the
+ * operation maps between (level 2 = TRLWE). */
+int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* in)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!out || !in) return fail(-1, "null ciphertext");
+    int lin, lout;
+    switch (op) {
+        case CUFHE_AMD_TL_BOOTSTRAP: lin = 0; lout = 2; break;
+        case CUFHE_AMD_TL_REFRESH: lin = 2; lout = 2; break;
+        case CUFHE_AMD_TL_SEIKS: lin = 2; lout = 0; break;
+        default: return fail(-1, "unknown TRLWE-level op");
+    }
+    sched::Scheduler* S = scheduler();
+    if (int rc = sched_check_ctxt(S, out)) return rc;
+    if (int rc = sched_check_ctxt(S, in)) return rc;
+    if (in->level != lin || out->level != lout) return fail(-1, "operand levels do not fit the TRLWE-level operation");
+    if (!g_dev[device].keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    cufhe_amd_ctxt* ins[3] = {in, nullptr, nullptr};
+    if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins, 2)) return sched_error(S->dev(device), rc);
     return 0;
 }
 

@@ -112,6 +112,13 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
  * them has retired. */
 int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
                            cufhe_amd_ctxt* in0, cufhe_amd_ctxt* in1, cufhe_amd_ctxt* in2);
+/* TRLWE-level operations through the same scheduler: struct cuFHETRLWElvl1 (include/cufhe_gpu.cuh:124-134) is a
+ * ciphertext handle of level 2 ((k+1) N words; cufhe_amd_ctxt_create(2, ...)), and
+ * gGateBootstrappingTLWE2TRLWElvl01NTT / gRefresh / gSampleExtractAndKeySwitch (src/cufhe_gates_gpu.cu:86-146;
+ * copying != 0: their upload-and-fetch forms) are recorded with their dependences and launched level by level:
+ * 4096 Refresh calls on 800 streams (test/test_perf.cc:63-81) become a handful of launches. */
+enum cufhe_amd_trlwe_op { CUFHE_AMD_TL_BOOTSTRAP = 100, CUFHE_AMD_TL_REFRESH = 101, CUFHE_AMD_TL_SEIKS = 102 };
+int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* in);
 /* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207), ordered with the recorded gates */
 int cufhe_amd_enqueue_copy(int device, void* stream, cufhe_amd_ctxt* c, int to_device);
 int cufhe_amd_flush(int device);                        /* launch what is recorded, do not wait */

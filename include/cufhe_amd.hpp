@@ -203,22 +203,27 @@ CUFHE_AMD_GATE3(Mux, CUFHE_AMD_MUX)
 CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
 
 // ---- TRLWE-level primitives, include/cufhe_gpu.cuh:123-146,209-216,282-285 ----
-// Same names and operands as the reference.  They complete before returning (the reference
-// returns after enqueueing and needs Synchronize(); code written for it keeps working).
+// Same names and operands as the reference.  GateBootstrappingTLWE2TRLWElvl01NTT, Refresh and
+// SampleExtractAndKeySwitch (and their g-forms) are RECORDED like gates and launched in batches: as in the
+// reference, results are in the host members after Synchronize() or StreamQuery(st) == true.  TRGSW2NTT and
+// CMUXNTT complete before returning.
 
 /// struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134
 struct cuFHETRLWElvl1 {
     TFHEpp::TRLWE<TFHEpp::lvl1param> trlwehost;
     std::vector<TFHEpp::lvl1param::T*> trlwedevices;
+    cufhe_amd_ctxt* handle = nullptr;
     cuFHETRLWElvl1()
     {
+        CUFHE_AMD_CHECK(cufhe_amd_ctxt_create(2, trlwehost[0].data(), &handle));
         trlwedevices.resize(GetGPUNum());
-        for (int i = 0; i < GetGPUNum(); i++) CUFHE_AMD_CHECK(cufhe_amd_malloc(i, sizeof(trlwehost), (void**)&trlwedevices[i]));
+        for (int i = 0; i < GetGPUNum(); i++) trlwedevices[i] = cufhe_amd_ctxt_device_ptr(handle, i);
     }
-    ~cuFHETRLWElvl1() { for (size_t i = 0; i < trlwedevices.size(); i++) cufhe_amd_free((int)i, trlwedevices[i]); }
+    ~cuFHETRLWElvl1() { cufhe_amd_ctxt_destroy(handle); }
     cuFHETRLWElvl1(const cuFHETRLWElvl1&) = delete;
     cuFHETRLWElvl1& operator=(const cuFHETRLWElvl1&) = delete;
 };
+static_assert(sizeof(TFHEpp::TRLWE<TFHEpp::lvl1param>) == 2 * TFHEpp::lvl1param::n * sizeof(uint32_t), "TRLWE is (k+1) N contiguous words");
 
 /// struct cuFHETRGSWNTTlvl1, :136-146.  The NTT-domain words are this library's (exact
 /// residues mod a 50-bit prime carried in doubles); like the reference's FFP words they are
@@ -259,57 +264,44 @@ inline void TRGSW2NTT(cuFHETRGSWNTTlvl1& trgswntt, const TFHEpp::TRGSW<TFHEpp::l
 /// gGateBootstrappingTLWE2TRLWElvl01NTT / GateBootstrappingTLWE2TRLWElvl01NTT, src/cufhe_gates_gpu.cu:86-104
 inline void gGateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
 {
-    Synchronize();      // the input may be the result of a recorded gate
-    const int dev = st.device_id();
-    CUFHE_AMD_CHECK(cufhe_amd_blind_rotate_batch(dev, st.st(), 1, in.tlwedevices[dev], out.trlwedevices[dev], -1));
-    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), CUFHE_AMD_TL_BOOTSTRAP, 0, out.handle, in.handle));
 }
 inline void GateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
 {
-    Synchronize();
-    const int dev = st.device_id();
-    detail::h2d(st, in.tlwedevices[dev], in.tlwehost.data(), sizeof(in.tlwehost));
-    CUFHE_AMD_CHECK(cufhe_amd_blind_rotate_batch(dev, st.st(), 1, in.tlwedevices[dev], out.trlwedevices[dev], -1));
-    detail::d2h_wait(st, out.trlwehost.data(), out.trlwedevices[dev], sizeof(out.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), CUFHE_AMD_TL_BOOTSTRAP, 1, out.handle, in.handle));
 }
 /// gRefresh / Refresh, src/cufhe_gates_gpu.cu:106-124
 inline void gRefresh(cuFHETRLWElvl1& out, cuFHETRLWElvl1& in, Stream st)
 {
-    const int dev = st.device_id();
-    CUFHE_AMD_CHECK(cufhe_amd_refresh_batch(dev, st.st(), 1, in.trlwedevices[dev], out.trlwedevices[dev]));
-    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), CUFHE_AMD_TL_REFRESH, 0, out.handle, in.handle));
 }
 inline void Refresh(cuFHETRLWElvl1& out, cuFHETRLWElvl1& in, Stream st)
 {
-    const int dev = st.device_id();
-    detail::h2d(st, in.trlwedevices[dev], in.trlwehost.data(), sizeof(in.trlwehost));
-    CUFHE_AMD_CHECK(cufhe_amd_refresh_batch(dev, st.st(), 1, in.trlwedevices[dev], out.trlwedevices[dev]));
-    detail::d2h_wait(st, out.trlwehost.data(), out.trlwedevices[dev], sizeof(out.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), CUFHE_AMD_TL_REFRESH, 1, out.handle, in.handle));
 }
 /// gSampleExtractAndKeySwitch / SampleExtractAndKeySwitch, src/cufhe_gates_gpu.cu:126-146
-/// (both upload `in.trlwehost`, as the reference does)
+/// (both upload `in.trlwehost`, as the reference does; only the second fetches the result)
 inline void gSampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHETRLWElvl1& in, Stream st)
 {
-    Synchronize();
-    const int dev = st.device_id();
-    detail::h2d(st, in.trlwedevices[dev], in.trlwehost.data(), sizeof(in.trlwehost));
-    CUFHE_AMD_CHECK(cufhe_amd_sample_extract_keyswitch_batch(dev, st.st(), 1, in.trlwedevices[dev], out.tlwedevices[dev]));
-    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(dev, st.st()));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), in.handle, 1));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_trlwe_op(st.device_id(), st.st(), CUFHE_AMD_TL_SEIKS, 0, out.handle, in.handle));
 }
 inline void SampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHETRLWElvl1& in, Stream st)
 {
     gSampleExtractAndKeySwitch(out, in, st);
-    detail::d2h_wait(st, out.tlwehost.data(), out.tlwedevices[st.device_id()], sizeof(out.tlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), out.handle, 0));
 }
 /// CMUXNTT, src/cufhe_gates_gpu.cu:68-85: res = cs ? c1 : c0
 inline void CMUXNTT(cuFHETRLWElvl1& res, cuFHETRGSWNTTlvl1& cs, cuFHETRLWElvl1& c1, cuFHETRLWElvl1& c0, Stream st)
 {
+    Synchronize();      // operands may be results of recorded operations
     const int dev = st.device_id();
     detail::h2d(st, cs.trgswdevices[dev], cs.trgswhost.data(), sizeof(cs.trgswhost));
     detail::h2d(st, c1.trlwedevices[dev], c1.trlwehost.data(), sizeof(c1.trlwehost));
     detail::h2d(st, c0.trlwedevices[dev], c0.trlwehost.data(), sizeof(c0.trlwehost));
     CUFHE_AMD_CHECK(cufhe_amd_cmux_batch(dev, st.st(), 1, cs.trgswdevices[dev], c1.trlwedevices[dev], c0.trlwedevices[dev], res.trlwedevices[dev]));
     detail::d2h_wait(st, res.trlwehost.data(), res.trlwedevices[dev], sizeof(res.trlwehost));
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(dev, st.st(), res.handle, 1));     // tell the scheduler the buffer changed
 }
 
 #undef CUFHE_AMD_GATE1

@@ -254,10 +254,11 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         encrypt(in, bit);
         cuFHETRLWElvl1 t, r;
         GateBootstrappingTLWE2TRLWElvl01NTT(t, in, st);
-        bad += coeff0(t) != bit; total++;
         Refresh(r, t, st);
-        bad += coeff0(r) != bit; total++;
         SampleExtractAndKeySwitch(out0, r, st);
+        Synchronize();                       // recorded like gates: results are in the host members now (test/test_perf.cc:81)
+        bad += coeff0(t) != bit; total++;
+        bad += coeff0(r) != bit; total++;
         bad += decrypt(out0) != bit; total++;
         // CMUX: the bootstrapping key row i is a TRGSW encryption of s0[i]
         const int i = eng() % ORC_n;
@@ -269,12 +270,42 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         encrypt(other, 1 - bit);
         cuFHETRLWElvl1 t_other, res;
         GateBootstrappingTLWE2TRLWElvl01NTT(t_other, other, st);
-        CMUXNTT(res, cs, t, t_other, st);          // s0[i] ? t : t_other
+        CMUXNTT(res, cs, t, t_other, st);          // synchronises first          // s0[i] ? t : t_other
         bad += coeff0(res) != (g_s0[i] ? bit : 1 - bit); total++;
     }
     std::printf("TRLWE-level primitives: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, total);
     g_failures += bad;
     st.Destroy();
+}
+
+// test/test_perf.cc:36-87 at size: 4096 x GateBootstrappingTLWE2TRLWElvl01NTT, then 4096 x Refresh on 800 streams
+void RefreshAtSize(std::mt19937& eng)
+{
+    using namespace TFHEpp;
+    const int kNum = 4096, kStreams = 800;
+    std::vector<Ctxt<lvl0param>> in(kNum);
+    std::vector<cuFHETRLWElvl1> t(kNum), r(kNum);
+    std::vector<uint8_t> bits(kNum);
+    std::vector<Stream> st(kStreams);
+    for (auto& s : st) s.Create();
+    for (int i = 0; i < kNum; i++) { bits[i] = eng() & 1; encrypt(in[i], bits[i]); }
+    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
+    for (int i = 0; i < kNum; i++) GateBootstrappingTLWE2TRLWElvl01NTT(t[i], in[i], st[i % kStreams]);
+    for (int i = 0; i < kNum; i++) Refresh(r[i], t[i], st[i % kStreams]);
+    Synchronize();
+    cufhe_amd_sched_stats stats;
+    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
+    int bad = 0;
+    for (int i = 0; i < kNum; i++) {
+        uint32_t tl[ORC_LVL1_WORDS];
+        orc_sample_extract0(tl, r[i].trlwehost[0].data());
+        bad += orc_tlwe_decrypt(1, g_s1.data(), tl) != bits[i];
+    }
+    if (stats.launch_sequences > 8) bad++;
+    std::printf("4096 bootstraps to TRLWE + 4096 Refresh on 800 streams: %s (%d failures, %llu launch sequences)\n", bad ? "FAIL" : "PASS",
+                bad, (unsigned long long)stats.launch_sequences);
+    g_failures += bad;
+    for (auto& s : st) s.Destroy();
 }
 
 // BASELINE configs[4]: the same gates through the N = 2048 ring (no reference test exists:
@@ -335,6 +366,7 @@ int main(int argc, char** argv)
     Intensive(eng);
     DeviceResident(eng);
     TrlwePrimitives(eng, bk);
+    RefreshAtSize(eng);
     RippleAdders(eng);
     MixedAtSize(eng);
     Lvl2Gates(eng);

@@ -19,8 +19,10 @@
 
 using namespace cufhe_amd::sched;
 
-static const int kWords[2] = {37, 53};      // toy ciphertext sizes (odd on purpose)
-enum { OP_NOT = 12, OP_COPY = 13, OP_MUX = 10, OP_NMUX = 11 };
+static const int kWords[3] = {37, 53, 71};  // toy ciphertext sizes (odd on purpose): lvl0, lvl1, TRLWE
+enum { OP_NOT = 12, OP_COPY = 13, OP_MUX = 10, OP_NMUX = 11, TL_BOOT = 100, TL_REFRESH = 101, TL_SEIKS = 102 };
+static int tl_in_level(int op) { return op == TL_BOOT ? 0 : 2; }
+static int tl_out_level(int op) { return op == TL_SEIKS ? 0 : 2; }
 
 static inline uint32_t rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 static uint32_t mix(int op, uint32_t a, uint32_t b, uint32_t c, uint32_t w)
@@ -30,6 +32,13 @@ static uint32_t mix(int op, uint32_t a, uint32_t b, uint32_t c, uint32_t w)
 }
 static void toy_gate(int op, int level, uint32_t* out, const uint32_t* a, const uint32_t* b, const uint32_t* c)
 {
+    if (op >= TL_BOOT) {      // TRLWE-level operations map between ciphertext kinds
+        const int wi = kWords[tl_in_level(op)], wo = kWords[tl_out_level(op)];
+        std::vector<uint32_t> r(wo);
+        for (int w = 0; w < wo; w++) r[w] = mix(op, a[w % wi], a[(w * 7 + 3) % wi], 0u, (uint32_t)w);
+        memcpy(out, r.data(), r.size() * 4);
+        return;
+    }
     std::vector<uint32_t> r(kWords[level]);
     for (int w = 0; w < kWords[level]; w++) r[w] = mix(op, a[w], b ? b[w] : 0u, c ? c[w] : 0u, (uint32_t)w);
     memcpy(out, r.data(), r.size() * 4);
@@ -184,7 +193,7 @@ struct Test {
     {
         C* ins[3] = {a, b, c3};
         cufhe_amd_ctxt* hs[3] = {a->h, b ? b->h : nullptr, c3 ? c3->h : nullptr};
-        if (int rc = S->dev(dev).record_gate(st, op, copying, out->h, hs)) { fprintf(stderr, "record_gate rc %d: %s\n", rc, S->dev(dev).error_text().c_str()); abort(); }
+        if (int rc = S->dev(dev).record_gate(st, op, copying, out->h, hs, op >= TL_BOOT ? 2 : -1)) { fprintf(stderr, "record_gate rc %d: %s\n", rc, S->dev(dev).error_text().c_str()); abort(); }
         // model, in issue order
         if (copying)
             for (C* i : ins)
@@ -235,7 +244,7 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
     }
     const int kStreams = 6;
     auto stream_handle = [&](int dev, int s) { return (void*)(uintptr_t)(0x1000 + dev * 64 + s); };
-    for (int i = 0; i < 24; i++) t.make(i % 3 == 0 ? 1 : 0);
+    for (int i = 0; i < 30; i++) t.make(i % 5 == 4 ? 2 : i % 3 == 0 ? 1 : 0);
     const int steps = 300 + (int)(prng() % 500);
     auto pick = [&](int level) {
         for (;;) {
@@ -255,7 +264,14 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
         void* st = stream_handle(dev, (int)(prng() % kStreams));
         const int level = prng() % 4 == 0 ? 1 : 0;
         const unsigned r = (unsigned)(prng() % 100);
-        if (r < 40) {                               // copying gate
+        if (r < 8) {                                // TRLWE-level operation (copying or device-resident)
+            const int op = TL_BOOT + (int)(prng() % 3);
+            const bool copying = prng() % 2 == 0;
+            Test::C* in = copying ? pick(tl_in_level(op)) : pick_defined(tl_in_level(op), dev);
+            if (!in) continue;
+            Test::C* out = (tl_in_level(op) == tl_out_level(op) && prng() % 4 == 0) ? in : pick(tl_out_level(op));
+            t.gate(dev, st, op, copying, out, in, nullptr, nullptr);
+        } else if (r < 40) {                        // copying gate
             const int kind = (int)(prng() % 10);
             Test::C* out = pick(level);
             Test::C* a = prng() % 5 == 0 ? out : pick(level);      // in-place now and then

@@ -293,3 +293,42 @@ def test_config3_mux_4096(engine, keys, oracle, op):
     assert np.array_equal(keys.decrypt(got, 0), exp)
     idx = np.arange(3, count, count // 64)[:64]
     assert np.array_equal(got[idx], keys.gate_batch(O(op), 0, enc[0][idx], enc[1][idx], enc[2][idx]))
+
+
+def test_trlwe_level_ops_are_scheduled(engine, keys, oracle):
+    """GateBootstrappingTLWE2TRLWElvl01NTT -> Refresh -> SampleExtractAndKeySwitch chains (test/test_perf.cc:36-87,
+    src/cufhe_gates_gpu.cu:86-146) on 8 streams: recorded like gates, three launch sequences for the whole
+    program, every intermediate and final value == the oracle's words."""
+    api = engine.api
+    K = 40
+    rng = np.random.default_rng(81)
+    bits = rng.integers(0, 2, K).astype(np.uint8)
+    ins, enc = _ctxts(api, keys, bits, 0, 8100)
+    t = [api.Trlwe() for _ in range(K)]
+    r = [api.Trlwe() for _ in range(K)]
+    outs = [api.Ctxt(0) for _ in range(K)]
+    sts = [api.Stream() for _ in range(8)]
+    for s in sts:
+        s.Create()
+    api.sched_stats(reset=True)
+    for i in range(K):
+        st = sts[i % 8]
+        api.GateBootstrappingTLWE2TRLWElvl01NTT(t[i], ins[i], st)
+        api.Refresh(r[i], t[i], st)
+        api.SampleExtractAndKeySwitch(outs[i], r[i], st)
+    api.Synchronize()
+    stats = api.sched_stats()
+    assert stats.gates == 3 * K and stats.launch_sequences <= 3, (stats.gates, stats.launch_sequences)
+    for i in range(K):
+        acc = np.zeros(2 * ol.N, np.uint32)
+        oracle.orc_blind_rotate(keys.ek, acc, np.ascontiguousarray(enc[i]), -1)
+        assert np.array_equal(t[i].trlwehost, acc), i
+        ref = np.zeros(2 * ol.N, np.uint32)
+        oracle.orc_refresh(keys.ek, ref, acc)
+        assert np.array_equal(r[i].trlwehost, ref), i
+        t0 = np.zeros(ol.n + 1, np.uint32)
+        oracle.orc_sample_extract_keyswitch(keys.ek, t0, ref)
+        assert np.array_equal(outs[i].tlwehost, t0), i
+    assert np.array_equal(keys.decrypt(_host(outs), 0), bits)
+    for s in sts:
+        s.Destroy()
