@@ -106,9 +106,8 @@ def main():
         out["kernels"][k] = k_out
     dst = os.path.join(ROOT, "profiles", "kernel_facts.json")
     json.dump(out, open(dst, "w"), indent=1)
-    for f in files:      # keep the raw passes beside it, named per round
-        base = os.path.basename(os.path.dirname(f)) if os.path.basename(f).startswith(("out_", "counter")) else ""
-        shutil.copy(f, os.path.join(ROOT, "profiles", f"{args.tag}_{os.path.basename(os.path.dirname(os.path.dirname(f)))}_{os.path.basename(f)}"[-120:]))
+    for f in files:      # keep the raw passes beside it, named per round and per pass
+        shutil.copy(f, os.path.join(ROOT, "profiles", f"{args.tag}_{os.path.basename(os.path.dirname(f))}_counter_collection.csv"))
     print(json.dumps(out, indent=1))
 
 

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}_prof
 mkdir -p $OUT
 BENCH="python3 bench.py --no-extra --no-cpu-baseline"
-for WL in nand nand_lvl2; do
+for WL in ${WORKLOADS:-nand nand_lvl2}; do
   STEPS=5; [ $WL = nand_lvl2 ] && STEPS=2
   rocprofv3 --kernel-trace --stats -d $OUT/${WL}_stats -o st --output-format csv -- $BENCH --workload $WL --steps $STEPS > $OUT/${WL}_bench_under_rocprof.json
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
