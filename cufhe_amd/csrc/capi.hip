@@ -73,6 +73,13 @@ struct DeviceState {
 
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
+long g_share_devices = 0;      // 1: logical devices beyond the visible GPUs wrap around (SetGPUNum(G) rehearsed on fewer GPUs)
+int g_phys_count = 0;
+int phys_device(int device)
+{
+    if (g_share_devices && g_phys_count > 0) return (g_device_base + device) % g_phys_count;
+    return device + g_device_base;
+}
 long g_wg_threshold = 0;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_split_threshold = 32; // key switches per launch up to which each ciphertext is split over 8 workgroups
 long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
@@ -196,7 +203,7 @@ int check_device(int device)
 int use_device(int device)
 {
     if (int rc = check_device(device)) return rc;
-    HIP_TRY(hipSetDevice(device + g_device_base));
+    HIP_TRY(hipSetDevice(phys_device(device)));
     return 0;
 }
 
@@ -204,7 +211,7 @@ int ensure_ntt(int device)
 {
     DeviceState& s = g_dev[device];
     if (s.ntt_ready) return 0;
-    HIP_TRY(hipSetDevice(device + g_device_base));
+    HIP_TRY(hipSetDevice(phys_device(device)));
     NttTables host;
     build_tables(host);
     HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
@@ -597,7 +604,9 @@ int cufhe_amd_set_gpu_num(int gpu_num)
     for (auto& d : g_dev)
         if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
     int have = cufhe_amd_device_count();
-    if (gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
+    g_phys_count = have;
+    if (have < 1) return fail(-1, "no GPU visible");
+    if (!g_share_devices && gpu_num + g_device_base > have) return fail(-1, "gpu_num (plus device_base) exceeds the visible device count");
     if (gpu_num != g_gpu_num) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
         sched_retire_generation();
@@ -628,7 +637,7 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
     for (int i = 0; i < g_gpu_num; i++) {
         if (int rc = ensure_ntt(i)) return rc;
         DeviceState& s = g_dev[i];
-        HIP_TRY(hipSetDevice(i + g_device_base));
+        HIP_TRY(hipSetDevice(phys_device(i)));
         if (s.keys_ready) {
             HIP_TRY(hipFree(s.bk_ntt));
             HIP_TRY(hipFree(s.ksk));
@@ -666,7 +675,7 @@ int cufhe_amd_cleanup(void)
     for (int i = 0; i < g_gpu_num; i++) {
         DeviceState& s = g_dev[i];
         if (!s.ntt_ready && !s.keys_ready && !s.tables2) continue;
-        HIP_TRY(hipSetDevice(i + g_device_base));
+        HIP_TRY(hipSetDevice(phys_device(i)));
         HIP_TRY(hipDeviceSynchronize());
         for (auto* v : {&s.br_events, &s.ks_events}) {
             for (auto& e : *v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -698,7 +707,7 @@ int cufhe_amd_synchronize(void)
         if (int rc = sched_synchronize_all()) return rc;
     }
     for (int i = 0; i < g_gpu_num; i++) {
-        HIP_TRY(hipSetDevice(i + g_device_base));
+        HIP_TRY(hipSetDevice(phys_device(i)));
         HIP_TRY(hipDeviceSynchronize());
     }
     return 0;
@@ -1018,6 +1027,7 @@ int cufhe_amd_set_option(const char* key, long value)
             }
         return 0;
     }
+    if (!strcmp(key, "share_devices")) { g_share_devices = value; g_phys_count = cufhe_amd_device_count(); return 0; }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
     if (!strcmp(key, "half_threshold")) { g_half_threshold = value; return 0; }

@@ -32,7 +32,7 @@ int ensure_tables_lvl2(int device)
 {
     DeviceState& s = g_dev[device];
     if (s.tables2) return 0;
-    HIP_TRY(hipSetDevice(device + g_device_base));
+    HIP_TRY(hipSetDevice(phys_device(device)));
     static NttTables host[2];
     build_tables_lvl2(host);
     HIP_TRY(hipMalloc((void**)&s.tables2, sizeof(host)));
@@ -180,7 +180,7 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
     for (int i = 0; i < g_gpu_num; i++) {
         if (int rc = ensure_tables_lvl2(i)) return rc;
         DeviceState& s = g_dev[i];
-        HIP_TRY(hipSetDevice(i + g_device_base));
+        HIP_TRY(hipSetDevice(phys_device(i)));
         if (s.keys2_ready) {
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(s.bk2_ntt));

@@ -167,7 +167,7 @@ int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const 
             if (int rc = ensure_ntt(i)) return rc;
             DeviceState& s = g_dev[i];
             PsState& ps = ps_state(set, i);
-            HIP_TRY(hipSetDevice(i + g_device_base));
+            HIP_TRY(hipSetDevice(phys_device(i)));
             if (ps.ready) {
                 HIP_TRY(hipDeviceSynchronize());
                 HIP_TRY(hipFree(ps.bk_ntt));

@@ -18,7 +18,7 @@ long g_sched_total_gates = 32768;
 class HipBackend : public sched::Backend {
    public:
     explicit HipBackend(int device) : device_(device) {}
-    void bind_thread() override { (void)hipSetDevice(device_ + g_device_base); }
+    void bind_thread() override { (void)hipSetDevice(phys_device(device_)); }
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
     int words(int level) override { return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : 2 * kN; }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }

@@ -195,6 +195,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * the C++ shim) runs through the N = 2048 path.
  * "lvl0_param_set" (default -1): index of a cufhe_amd_ps_* parameter set with n = 630 through which every level-0
  * entry point bootstraps instead (cufhe_amd_ps_initialize first).
+ * "share_devices" (default 0): 1 lets SetGPUNum(G) exceed the visible GPU count, logical devices wrapping around the
+ * physical ones (every logical device keeps its own key replica, scheduler, launch thread and streams): the
+ * reference's multi-GPU programs (test/test_gate_gpu_multi.cc) rehearsed on fewer GPUs.
  * "sched_streams" (default 4): internal HIP streams per device over which independent flushes of the
  * per-gate API overlap; "sched_threads" (default 1): one launch worker thread per device (0: launches
  * happen on the issuing thread).  Both before the first ciphertext is created.

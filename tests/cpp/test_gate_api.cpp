@@ -22,6 +22,18 @@ static std::vector<uint32_t> g_s0(ORC_n), g_s1(ORC_N);
 static orc_rng g_rng;
 static int g_failures = 0;
 
+// scheduler counters summed over the devices, reset
+static cufhe_amd_sched_stats all_stats()
+{
+    cufhe_amd_sched_stats sum{};
+    for (int d = 0; d < GetGPUNum(); d++) {
+        cufhe_amd_sched_stats s;
+        CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(d, &s, 1));
+        sum.gates += s.gates; sum.launch_sequences += s.launch_sequences; sum.levels += s.levels; sum.groups += s.groups;
+    }
+    return sum;
+}
+
 template <class P> const uint32_t* key() { return detail::level_of<P>() ? g_s1.data() : g_s0.data(); }
 template <class P> void encrypt(Ctxt<P>& c, int bit) { orc_tlwe_encrypt(&g_rng, detail::level_of<P>(), key<P>(), bit, c.tlwehost.data()); }
 template <class P> int decrypt(Ctxt<P>& c) { return orc_tlwe_decrypt(detail::level_of<P>(), key<P>(), c.tlwehost.data()); }
@@ -80,7 +92,7 @@ void Chained(std::mt19937& eng)
         pa[i] = eng() & 1; pb[i] = eng() & 1; pc[i] = eng() & 1;
         encrypt(a[i], pa[i]); encrypt(b[i], pb[i]); encrypt(c[i], pc[i]);
     }
-    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
+    all_stats();
     for (int i = 0; i < kNumTests; i++) {
         Stream s = st[i % kNumSMs];
         Nand(a[i], a[i], b[i], s); pa[i] = 1 - pa[i] * pb[i];
@@ -93,9 +105,8 @@ void Chained(std::mt19937& eng)
     int bad = 0;
     for (int i = 0; i < kNumTests; i++) bad += decrypt(a[i]) != pa[i];
     // five dependence levels, however the 64 chains were interleaved: not 320 one-gate launches
-    cufhe_amd_sched_stats stats;
-    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
-    if (stats.launch_sequences > 6) bad++;
+    cufhe_amd_sched_stats stats = all_stats();
+    if (stats.launch_sequences > 6 * (uint64_t)GetGPUNum()) bad++;
     std::printf("chained in-place gates: %s (%d/%d failures, %llu launch sequences for %llu gates)\n", bad ? "FAIL" : "PASS", bad,
                 kNumTests, (unsigned long long)stats.launch_sequences, (unsigned long long)stats.gates);
     g_failures += bad;
@@ -175,7 +186,7 @@ void RippleAdders(std::mt19937& eng)
         for (int k = 0; k < kBits; k++) { encrypt(a[i * kBits + k], (va[i] >> k) & 1); encrypt(b[i * kBits + k], (vb[i] >> k) & 1); }
         encrypt(carry[i], 0);
     }
-    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
+    all_stats();
     for (int k = 0; k < kBits; k++)
         for (int i = 0; i < kAdders; i++) {
             Ctxt<P>&x = a[i * kBits + k], &y = b[i * kBits + k], &s = sum[i * kBits + k], &c = carry[i];
@@ -193,9 +204,8 @@ void RippleAdders(std::mt19937& eng)
         got |= (unsigned)decrypt(carry[i]) << kBits;
         bad += got != va[i] + vb[i];
     }
-    cufhe_amd_sched_stats stats;
-    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
-    if (stats.launch_sequences > 40) bad++;
+    cufhe_amd_sched_stats stats = all_stats();
+    if (stats.launch_sequences > 40 * (uint64_t)GetGPUNum()) bad++;
     std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums, %llu launch sequences)\n",
                 bad ? "FAIL" : "PASS", bad, kAdders, (unsigned long long)stats.launch_sequences);
     g_failures += bad;
@@ -289,19 +299,18 @@ void RefreshAtSize(std::mt19937& eng)
     std::vector<Stream> st(kStreams);
     for (auto& s : st) s.Create();
     for (int i = 0; i < kNum; i++) { bits[i] = eng() & 1; encrypt(in[i], bits[i]); }
-    { cufhe_amd_sched_stats reset; CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &reset, 1)); }
+    all_stats();
     for (int i = 0; i < kNum; i++) GateBootstrappingTLWE2TRLWElvl01NTT(t[i], in[i], st[i % kStreams]);
     for (int i = 0; i < kNum; i++) Refresh(r[i], t[i], st[i % kStreams]);
     Synchronize();
-    cufhe_amd_sched_stats stats;
-    CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &stats, 1));
+    cufhe_amd_sched_stats stats = all_stats();
     int bad = 0;
     for (int i = 0; i < kNum; i++) {
         uint32_t tl[ORC_LVL1_WORDS];
         orc_sample_extract0(tl, r[i].trlwehost[0].data());
         bad += orc_tlwe_decrypt(1, g_s1.data(), tl) != bits[i];
     }
-    if (stats.launch_sequences > 8) bad++;
+    if (stats.launch_sequences > 8 * (uint64_t)GetGPUNum()) bad++;
     std::printf("4096 bootstraps to TRLWE + 4096 Refresh on 800 streams: %s (%d failures, %llu launch sequences)\n", bad ? "FAIL" : "PASS",
                 bad, (unsigned long long)stats.launch_sequences);
     g_failures += bad;
@@ -358,6 +367,9 @@ int main(int argc, char** argv)
     orc_bkgen(1001, g_s0.data(), g_s1.data(), bk.data());
     orc_kskgen(2001, g_s0.data(), g_s1.data(), ksk.data());
 
+    // more logical GPUs than the box has (test/test_gate_gpu_multi.cc hard-codes gpuNum = 2): every logical device
+    // keeps its own keys, scheduler, launch thread and streams, several of them on one physical GPU
+    if (getenv("CUFHE_AMD_SHARE_DEVICES")) CUFHE_AMD_CHECK(cufhe_amd_set_option("share_devices", 1));
     SetGPUNum(gpus);
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc

@@ -298,6 +298,26 @@ def test_cpp_gate_api_mirror(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+def test_cpp_gate_api_three_logical_gpus(engine):
+    """The same program with SetGPUNum(3) (test/test_gate_gpu_multi.cc:36-93: default-constructed streams
+    round-robin the devices, include/cufhe_gpu.cuh:154-159): per-device key replicas, schedulers, launch threads
+    and ciphertext buffers.  The box has one GPU, so the three logical devices share it ("share_devices")."""
+    import os
+    import subprocess
+    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api")
+    assert os.path.exists(exe), "built by test_cpp_gate_api_mirror"
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=900, env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1"))
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
+
+
 def test_plain_bootstrap(engine, keys, oracle, br_kernel):
     """Bootstrap (src/bootstrap_gpu.cu:290-301): blind rotate -> extract -> key switch of one TLWE."""
     rng = np.random.default_rng(31)
