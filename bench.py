@@ -339,7 +339,10 @@ def main():
             try:
                 out = subprocess.run([exe, "4096"], capture_output=True, text=True, timeout=300,
                                      env=dict(os.environ, HIP_VISIBLE_DEVICES=str(DEV)) if WORLD > 1 else None)
-                res["api_pcie_inclusive"] = json.loads(out.stdout.strip().splitlines()[-1])
+                lines = [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
+                res["api_pcie_inclusive"] = lines[0]
+                if len(lines) > 1:
+                    res["api_pcie_inclusive"]["depth_first_netlist"] = lines[1]
                 res["api_pcie_inclusive"]["what"] = ("4096 cufhe::Nand(out, a, b, st) on host-resident ciphertexts over 256 streams, "
                                                      "then Synchronize(): test/test_util.h:29-72; host_issue = recording + result delivery "
                                                      "on the issuing thread, host_worker = the device's launch thread")

@@ -1,6 +1,7 @@
 // bench_api.cpp -- PCIe-inclusive rate of the reference-style per-gate API (not the headline metric).
 // 4096 cufhe::Nand(out, a, b, st) calls on host-resident ciphertexts over 256 streams, then
 // Synchronize(): what test/test_util.h:29-72 times in the reference ("Throughput: ms/gate").
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <random>
@@ -50,6 +51,42 @@ int main(int argc, char** argv)
                 "\"launch_sequences\": %llu}\n",
                 kNumTests, kNumStreams, best_tot, best_enq, kNumTests / (best_tot * 1e-3), issue_us, worker_us, 1e6 / issue_us,
                 (unsigned long long)ss.launch_sequences);
+    // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
+    // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
+    // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders.
+    {
+        const int kAdders = 256, kBits = 16;
+        std::vector<Ctxt<P>> x(kAdders * kBits), y(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);
+        for (auto* v : {&x, &y})
+            for (auto& c : *v)
+                for (auto& w : c.tlwehost) w = eng();
+        for (auto& c : carry)
+            for (auto& w : c.tlwehost) w = eng();
+        double best = 1e30;
+        cufhe_amd_sched_stats ns{};
+        for (int rep = 0; rep < 2; rep++) {
+            CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ns, 1));
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < kAdders; i++) {
+                Stream s = st[i % kNumStreams];
+                for (int k = 0; k < kBits; k++) {
+                    Ctxt<P>&X = x[i * kBits + k], &Y = y[i * kBits + k], &S = sum[i * kBits + k], &C = carry[i];
+                    Xor(t1[i], X, Y, s);
+                    Xor(S, t1[i], C, s);
+                    And(t2[i], t1[i], C, s);
+                    And(t1[i], X, Y, s);
+                    Or(C, t1[i], t2[i], s);
+                }
+            }
+            Synchronize();
+            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ns, 0));
+        }
+        std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"gates\": %llu, \"total_ms\": %.2f, "
+                    "\"gates_per_s\": %.0f, \"dependence_levels\": %llu, \"launch_sequences\": %llu, \"max_level_gates\": %llu}\n",
+                    (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
+                    (unsigned long long)ns.launch_sequences, (unsigned long long)ns.max_level_gates);
+    }
     for (auto& s : st) s.Destroy();
     CleanUp();
     return 0;
