@@ -118,7 +118,7 @@ void Chained(std::mt19937& eng)
 void Intensive(std::mt19937& eng)
 {
     using P = TFHEpp::lvl0param;
-    const int kNumStreams = 200, kRounds = 4;
+    const int kNumStreams = 1000, kRounds = 20;      // the reference's sizes (test/test_intensive.cc:21-24)
     Ctxt<P> in0, in1, inc;
     int p0 = eng() & 1, p1 = eng() & 1, pcb = eng() & 1;
     encrypt(in0, p0); encrypt(in1, p1); encrypt(inc, pcb);
