@@ -62,8 +62,8 @@ def source_hash():
     """sha256 over the kernel / host sources: recorded PMC facts are only valid for the exact code."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cufhe_amd", "csrc")
-    # the device code of the profiled kernels (host-side files do not change what a launch executes)
-    for f in ("fpfield.h", "ntt_wave.h", "ntt_wave512.h", "kernels.hip.h", "kernels_ll.hip.h", "kernels_lvl2.hip.h"):
+    # the device code of the two profiled kernels and what they include (host-side files do not change what a launch executes)
+    for f in ("fpfield.h", "ntt_wave.h", "kernels.hip.h", "kernels_lvl2.hip.h"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcufhe_amd.so")
+# CUFHE_AMD_LIBRARY: load another build of the same library (the diagnostic builds of cufhe_amd/build.py)
+LIB_PATH = os.environ.get("CUFHE_AMD_LIBRARY") or os.path.join(_HERE, "libcufhe_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

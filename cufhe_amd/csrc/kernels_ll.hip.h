@@ -91,6 +91,13 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     };
     if (row_wave && steps > 0) load_row(0);
 
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    // timing-only: cycles this wave spends in each phase of a step (phase = work up to the next barrier, then the barrier)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define CUFHE_AMD_PHASE(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
+#else
+#define CUFHE_AMD_PHASE(k)
+#endif
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
@@ -124,7 +131,9 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
                     __hip_atomic_fetch_add(s0 + o * kN + (2 * cc + 1) * 64, fpf::mulmod_wide(x[2 * cc + 1], b[4 * o + cc].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
         }
+        CUFHE_AMD_PHASE(0)
         __syncthreads();
+        CUFHE_AMD_PHASE(1)
         double u[kRegs8];
         if (row_wave) {
             if (i + 1 < steps) load_row(i + 1);               // in flight during the inverse transforms
@@ -137,7 +146,9 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) hd[r * 64] = u[r];
         }
+        CUFHE_AMD_PHASE(2)
         __syncthreads();
+        CUFHE_AMD_PHASE(3)
         if (!row_wave) {
             // last inverse stage (u0, u1) -> (u0 + u1, (u0 - u1) I^-1), I^-1 = -I; wave h finishes
             // coefficients e + 512 h
@@ -152,8 +163,17 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
                 *(uint32_t*)(acck + 256 * r + 4096) = w;
             }
         }
+        CUFHE_AMD_PHASE(4)
         __syncthreads();
+        CUFHE_AMD_PHASE(5)
     }
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    if (acc_dump && lane == 0 && g == 0) {
+        __syncthreads();
+        unsigned long long* o = (unsigned long long*)acc_dump + 16 + wave * 8;      // overwrites part of the dump: timing only
+        for (int k = 0; k < 6; k++) o[k] = ph[k];
+    }
+#endif
 
     if (acc_dump) {
         uint32_t* o = acc_dump + (size_t)g * 2 * kN;
