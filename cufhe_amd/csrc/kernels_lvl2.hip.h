@@ -241,6 +241,14 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     const bool inv_wave = wave < k2Prods;
     const int sh = k2Bgbit * wd;
 
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    // timing-only: cycles of this wave per phase: [0] decompose, [1 + 4h] forward, [2 + 4h] products, [3 + 4h] barrier,
+    // [4 + 4h] inverse (+ recombination), [9] barriers after the inverse phases
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define CUFHE_AMD_PHASE2(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
+#else
+#define CUFHE_AMD_PHASE2(k)
+#endif
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 ab[r] = (a & 0xffffu) | (b << 16);
             }
         }
+        CUFHE_AMD_PHASE2(0)
         double R0[kRegs];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
             ntt_forward<false>(x, ctx);
 #pragma unroll
             for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
+            CUFHE_AMD_PHASE2(1 + 4 * h)
             const double* kh = key + (size_t)h * (k2BkRows * k2Prods * k2Half);
 #pragma unroll
             for (int pp = 0; pp < k2Prods; pp += 2) {
@@ -310,7 +320,9 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 else if (h == 0) load_key_poly(bA, key + (size_t)(k2BkRows * k2Prods * k2Half), lane);   // half 1, first polynomial
                 accumulate_poly(sumL + (pp + 1) * k2Half, x, bB, lane);
             }
+            CUFHE_AMD_PHASE2(2 + 4 * h)
             __syncthreads();
+            CUFHE_AMD_PHASE2(3 + 4 * h)
             if (inv_wave) {
                 double* s = sumL + wave * k2Half + lane;
                 double A[kRegs];
@@ -334,7 +346,9 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                     }
                 }
             }
+            CUFHE_AMD_PHASE2(4 + 4 * h)
             __syncthreads();
+            CUFHE_AMD_PHASE2(9)
         }
     }
 
@@ -342,6 +356,13 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         uint64_t* o = acc_dump + (size_t)g * 2 * k2N;
         for (int e = tid; e < 2 * k2N; e += k2Threads) o[e] = accL[e];
     }
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    if (acc_dump && lane == 0 && g == 0) {
+        __syncthreads();
+        unsigned long long* o = (unsigned long long*)acc_dump + 2048 + wave * 16;     // overwrites part of the dump: timing only
+        for (int k = 0; k < 10; k++) o[k] = ph[k];
+    }
+#endif
     if (d.out) {   // __SampleExtractIndex__<lvl2param,0>, src/bootstrap_gpu.cu:366-381
         uint64_t* o = d.out;
         for (int e = tid; e < k2N; e += k2Threads) {

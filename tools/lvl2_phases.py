@@ -1,0 +1,29 @@
+"""Cycles per phase of blind_rotate_lvl2_kernel (diagnostic build with CUFHE_AMD_ABL_PHASES):
+   CUFHE_AMD_LIBRARY=cufhe_amd/libcufhe_amd_diag.so python tools/lvl2_phases.py"""
+import os
+import sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch  # noqa: F401
+import cufhe_amd as eng
+rng = np.random.default_rng(1)
+p2 = eng.api.lvl2_params()
+bk = rng.integers(0, 2**64, size=int(p2.bk_words), dtype=np.uint64)
+ksk = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.uint32)
+eng.SetGPUNum(1)
+eng.api.lvl2_initialize(bk, ksk)
+n, N = int(p2.n), int(p2.N)
+names = ["decompose", "fwd h0", "prod h0", "barrier", "inverse h0", "fwd h1", "prod h1", "barrier", "inv h1+recombine", "barriers after inverse"]
+for count in (1, 4096):
+    tl = rng.integers(0, 2**32, size=(count, n + 1), dtype=np.uint64).astype(np.uint32)
+    d = eng.api.DeviceBuffer(tl.size).upload(tl)
+    acc = eng.api.DeviceBuffer(count * 2 * N * 2)
+    eng.api.lvl2_blind_rotate_batch(d, acc, count)
+    eng.api.lvl2_blind_rotate_batch(d, acc, count)
+    eng.Synchronize()
+    w = acc.download()[: 2 * N * 2].view(np.uint64)
+    print(f"--- {count} rotation(s): cycles per step (630 steps), workgroup 0, by wave")
+    for wave in range(8):
+        c = w[2048 + wave * 16: 2048 + wave * 16 + 10] / 630.0
+        print(f"wave {wave}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, c)) + f"   total {c.sum():7.0f}")
+eng.CleanUp()
