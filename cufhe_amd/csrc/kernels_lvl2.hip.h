@@ -239,7 +239,12 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     const int wj = wave / k2L, wd = wave % k2L;               // this wave's TRGSW row = wj * l + wd
     const WaveCtx ctx_tile = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
     const bool inv_wave = wave < k2Prods;
-    const int sh = k2Bgbit * wd;
+    // digit wd is the 9-bit field at bit dpos = 64 - 9 (wd + 1) of the decomposed word: wd = 0..2 lie in the high word
+    // (alignbit of (hi, hi) by dpos - 32 is a rotate: the field lands at bit 0), wd = 3 straddles the words (alignbit of
+    // (hi, lo) by dpos = 28)
+    const int dpos = 64 - k2Bgbit * (wd + 1);
+    const bool dlo = dpos < 32;
+    const uint32_t dsh = (uint32_t)(dlo ? dpos : dpos - 32);
 
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     // timing-only: cycles of this wave per phase: [0] decompose, [1 + 4h] forward, [2 + 4h] products, [3 + 4h] barrier,
@@ -259,26 +264,47 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
 #else
         const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
 #endif
-        double2 bA[8], bB[8];
-        load_key_poly(bA, key, lane);                         // in flight during the decomposition + NTT
+        // Key polynomials of this row, step i: P0..P5 (half 0: out x limb), P6..P11 (half 1).  Three register buffers,
+        // loads issued two polynomials ahead of their use: one ahead left the product phase waiting on L2 for twice its
+        // issue time (tools/lvl2_phases.py).
+        double2 kb[3][8];
+#define CUFHE_AMD_KEYPOLY(k) (key + (size_t)((k) / k2Prods) * (k2BkRows * k2Prods * k2Half) + ((k) % k2Prods) * k2Half)
+        load_key_poly(kb[0], CUFHE_AMD_KEYPOLY(0), lane);     // in flight during the decomposition + NTT
+        load_key_poly(kb[1], CUFHE_AMD_KEYPOLY(1), lane);
 
         // digit wd of (X^abar - 1) acc_wj at e (low half-word) and e + 1024 (high half-word);
-        // kept packed across the two halves: 16 registers instead of 64
+        // kept packed across the two halves: 16 registers instead of 64.  The LDS reads of eight register slots
+        // are issued together (32 ds_read_b64 in flight), then consumed: four at a time cost a round trip per slot.
         uint32_t ab[kRegs];
         {
             const char* accj = (const char*)(accL + wj * k2N);
+            const char* cbase = accj + opaque(8 * lane);
+            const int rb = (lane - alo) & (k2N - 1);
 #pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                const int e0 = lane + 64 * r;
-                const int i0 = (e0 - alo) & (k2N - 1), i1 = i0 ^ k2Half;
-                const uint64_t rot0 = *(const uint64_t*)(accj + 8 * i0), rot1 = *(const uint64_t*)(accj + 8 * i1);
-                const uint64_t cur0 = *(const uint64_t*)(accj + 8 * e0), cur1 = *(const uint64_t*)(accj + 8 * (e0 + k2Half));
-                const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
-                const uint64_t t0 = ((neg0 ? 0ull - rot0 : rot0) - cur0 + decomp_offset2()) ^ decomp_signmask2();
-                const uint64_t t1 = ((neg1 ? 0ull - rot1 : rot1) - cur1 + decomp_offset2()) ^ decomp_signmask2();
-                const uint32_t a = (uint32_t)((int64_t)(t0 << sh) >> (64 - k2Bgbit));
-                const uint32_t b = (uint32_t)((int64_t)(t1 << sh) >> (64 - k2Bgbit));
-                ab[r] = (a & 0xffffu) | (b << 16);
+            for (int r0 = 0; r0 < kRegs; r0 += 8) {
+                uint64_t rot0[8], rot1[8], cur0[8], cur1[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int r = r0 + q;
+                    const int i0 = (rb + 64 * r) & (k2N - 1);
+                    rot0[q] = *(const uint64_t*)(accj + 8 * i0);
+                    rot1[q] = *(const uint64_t*)(accj + 8 * (i0 ^ k2Half));
+                    cur0[q] = *(const uint64_t*)(cbase + 512 * r);
+                    cur1[q] = *(const uint64_t*)(cbase + 512 * r + 8 * k2Half);
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int e0 = lane + 64 * (r0 + q);
+                    const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
+                    const uint64_t t0 = ((neg0 ? 0ull - rot0[q] : rot0[q]) - cur0[q] + decomp_offset2()) ^ decomp_signmask2();
+                    const uint64_t t1 = ((neg1 ? 0ull - rot1[q] : rot1[q]) - cur1[q] + decomp_offset2()) ^ decomp_signmask2();
+                    // the 9-bit field at bit `dpos` of t, sign-extended, with 32-bit operations (64-bit shifts are slow):
+                    // v_alignbit_b32 brings the field to bit 0 whichever word(s) it sits in, v_bfe_i32 sign-extends it
+                    const uint32_t a = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t0 >> 32), dlo ? (uint32_t)t0 : (uint32_t)(t0 >> 32), dsh), 0u, (uint32_t)k2Bgbit);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), dlo ? (uint32_t)t1 : (uint32_t)(t1 >> 32), dsh), 0u, (uint32_t)k2Bgbit);
+                    ab[r0 + q] = (a & 0xffffu) | (b << 16);
+                }
             }
         }
         CUFHE_AMD_PHASE2(0)
@@ -311,14 +337,11 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
 #pragma unroll
             for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
             CUFHE_AMD_PHASE2(1 + 4 * h)
-            const double* kh = key + (size_t)h * (k2BkRows * k2Prods * k2Half);
 #pragma unroll
-            for (int pp = 0; pp < k2Prods; pp += 2) {
-                load_key_poly(bB, kh + (pp + 1) * k2Half, lane);
-                accumulate_poly(sumL + pp * k2Half, x, bA, lane);
-                if (pp + 2 < k2Prods) load_key_poly(bA, kh + (pp + 2) * k2Half, lane);
-                else if (h == 0) load_key_poly(bA, key + (size_t)(k2BkRows * k2Prods * k2Half), lane);   // half 1, first polynomial
-                accumulate_poly(sumL + (pp + 1) * k2Half, x, bB, lane);
+            for (int pp = 0; pp < k2Prods; pp++) {
+                const int k = k2Prods * h + pp;            // compile-time: both loops are unrolled
+                if (k + 2 < 2 * k2Prods) load_key_poly(kb[(k + 2) % 3], CUFHE_AMD_KEYPOLY(k + 2), lane);
+                accumulate_poly(sumL + pp * k2Half, x, kb[k % 3], lane);
             }
             CUFHE_AMD_PHASE2(2 + 4 * h)
             __syncthreads();
