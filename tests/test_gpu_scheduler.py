@@ -332,3 +332,122 @@ def test_trlwe_level_ops_are_scheduled(engine, keys, oracle):
     assert np.array_equal(keys.decrypt(_host(outs), 0), bits)
     for s in sts:
         s.Destroy()
+
+
+def test_per_gate_api_error_paths(engine, keys):
+    """Misuse is reported as a negative status (an exception here, print + exit(-1) in the C++ shim like the reference's
+    CuSafeCall, include/details/error_gpu.cuh:40-60), never as a crash or a silently wrong launch."""
+    api = engine.api
+    st = api.Stream()
+    st.Create()
+    a0, b0, o0 = api.Ctxt(0), api.Ctxt(0), api.Ctxt(0)
+    a1 = api.Ctxt(1)
+    t = api.Trlwe()
+    with pytest.raises(engine.CufheAmdError):
+        api.Nand(o0, a0, a1, st)                               # operands of different levels
+    with pytest.raises(engine.CufheAmdError):
+        api._gate(99, True, o0, [a0, b0], st)                  # unknown op
+    with pytest.raises(engine.CufheAmdError):
+        api._trlwe_op(api.TL_REFRESH, True, t, a0, st)         # Refresh takes a TRLWE
+    with pytest.raises(engine.CufheAmdError):
+        api.Nand(t, a0, b0, st)                                # gates do not write TRLWEs
+    o0.release()
+    with pytest.raises(Exception):
+        api.Nand(o0, a0, b0, st)                               # released handle (None)
+    # the scheduler is still healthy afterwards
+    a0.tlwehost[:] = keys.encrypt([1], 0, seed=1)[0]
+    b0.tlwehost[:] = keys.encrypt([1], 0, seed=2)[0]
+    o = api.Ctxt(0)
+    api.Nand(o, a0, b0, st)
+    api.Synchronize()
+    assert keys.decrypt(o.tlwehost, 0)[0] == 0
+    st.Destroy()
+
+
+def test_random_program_matches_in_order_oracle(engine, keys, oracle):
+    """A seeded random program through the per-gate API on the real device -- copying gates and g-gates of both levels,
+    in-place outputs, shared inputs, explicit copies, Flush, StreamQuery polls -- against an in-order interpreter whose
+    gates are the CPU oracle's: every tlwehost must hold the oracle's words at the end (the CPU twin of this test,
+    with a stubbed device, is tests/test_sched_model.py)."""
+    api = engine.api
+    rng = np.random.default_rng(2025)
+    nct = 14
+    cts = {0: [api.Ctxt(0) for _ in range(nct)], 1: [api.Ctxt(1) for _ in range(nct // 2)]}
+    host = {}     # model: the eventual tlwehost of every ciphertext
+    dev = {}      # model: its device buffer (None = undefined)
+    for lvl, lst in cts.items():
+        enc = keys.encrypt(rng.integers(0, 2, len(lst)).astype(np.uint8), lvl, seed=9000 + lvl)
+        for c, e in zip(lst, enc):
+            c.tlwehost[:] = e
+            host[id(c)] = e.copy()
+            dev[id(c)] = None
+    sts = [api.Stream() for _ in range(5)]
+    for s in sts:
+        s.Create()
+    two = ["NAND", "NOR", "XNOR", "AND", "OR", "XOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+    fn = {n: (getattr(api, n[0] + n[1:].lower().replace("ny", "NY").replace("yn", "YN")),
+              getattr(api, "g" + n[0] + n[1:].lower().replace("ny", "NY").replace("yn", "YN"))) for n in two}
+
+    def run_oracle(op, lvl, ins):
+        arrs = [np.ascontiguousarray(x).reshape(1, -1) for x in ins] + [None] * (3 - len(ins))
+        return keys.gate_batch(op, lvl, arrs[0], arrs[1], arrs[2], threads=1)[0]
+
+    for step in range(110):
+        lvl = 1 if rng.random() < 0.25 else 0
+        pool = cts[lvl]
+        st = sts[rng.integers(len(sts))]
+        r = rng.random()
+        if r < 0.55:                                              # copying gate
+            out = pool[rng.integers(len(pool))]
+            a = out if rng.random() < 0.2 else pool[rng.integers(len(pool))]
+            b, c = pool[rng.integers(len(pool))], pool[rng.integers(len(pool))]
+            kind = rng.random()
+            for x in (a, b, c):
+                pass
+            if kind < 0.12:
+                dev[id(a)] = host[id(a)].copy()
+                res = run_oracle(ol.OPS.index("NOT"), lvl, [dev[id(a)]])
+                api.Not(out, a, st)
+            elif kind < 0.3:
+                for x in (a, b, c):
+                    dev[id(x)] = host[id(x)].copy()
+                res = run_oracle(ol.OPS.index("MUX"), lvl, [dev[id(a)], dev[id(b)], dev[id(c)]])
+                api.Mux(out, a, b, c, st)
+            else:
+                name = two[rng.integers(len(two))]
+                for x in (a, b):
+                    dev[id(x)] = host[id(x)].copy()
+                res = run_oracle(ol.OPS.index(name), lvl, [dev[id(a)], dev[id(b)]])
+                fn[name][0](out, a, b, st)
+            dev[id(out)] = res
+            host[id(out)] = res.copy()
+        elif r < 0.75:                                            # g-gate on defined device buffers
+            defined = [x for x in pool if dev[id(x)] is not None]
+            if len(defined) < 2:
+                continue
+            a, b = defined[rng.integers(len(defined))], defined[rng.integers(len(defined))]
+            out = a if rng.random() < 0.25 else pool[rng.integers(len(pool))]
+            name = two[rng.integers(len(two))]
+            res = run_oracle(ol.OPS.index(name), lvl, [dev[id(a)], dev[id(b)]])
+            fn[name][1](out, a, b, st)
+            dev[id(out)] = res
+        elif r < 0.82:
+            x = pool[rng.integers(len(pool))]
+            api.CtxtCopyH2D(x, st)
+            dev[id(x)] = host[id(x)].copy()
+        elif r < 0.9:
+            defined = [x for x in pool if dev[id(x)] is not None]
+            if defined:
+                x = defined[rng.integers(len(defined))]
+                api.CtxtCopyD2H(x, st)
+                host[id(x)] = dev[id(x)].copy()
+        elif r < 0.96:
+            api.StreamQuery(st)
+        else:
+            api.Flush(0)
+    api.Synchronize()
+    for lvl, lst in cts.items():
+        for i, c in enumerate(lst):
+            assert np.array_equal(c.tlwehost, host[id(c)]), f"level {lvl} ciphertext {i}"
+    for s in sts:
+        s.Destroy()
