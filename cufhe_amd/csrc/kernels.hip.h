@@ -223,6 +223,16 @@ __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double
 // cost 21 % of the kernel in lock-step).  Three buffers make this safe: buffer (R+1) % 3
 // last held row R-2, whose last reader (a late wave's pointwise) precedes that wave's
 // barrier R-1.
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+// timing-only: cycles a wave spends inside the row barrier (tools/br_phases.py)
+#define CUFHE_AMD_DIAG_ARG , unsigned long long& diag_wait
+#define CUFHE_AMD_DIAG_PASS , diag_wait
+#define CUFHE_AMD_ROW_SYNC(R) { const unsigned long long t0_ = __builtin_readcyclecounter(); pipe.sync(R); diag_wait += __builtin_readcyclecounter() - t0_; }
+#else
+#define CUFHE_AMD_DIAG_ARG
+#define CUFHE_AMD_DIAG_PASS
+#define CUFHE_AMD_ROW_SYNC(R) pipe.sync(R);
+#endif
 struct RowPipe {
     const char* bk;          // NTT-domain key, bytes
     char* buf;               // LDS: kBkRowBuffers x kBkRowBytes
@@ -256,7 +266,7 @@ struct RowPipe {
 __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)[kRegs],
                                                const uint32_t (&accj)[kRegs], const WaveCtx& ctx,
                                                char* tile, int lane, uint32_t abar,
-                                               const RowPipe& pipe, int first_row)
+                                               const RowPipe& pipe, int first_row CUFHE_AMD_DIAG_ARG)
 {
     uint32_t temp[kRegs];
     rotate_sub(temp, accj, tile, lane, abar);
@@ -268,9 +278,9 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
         ntt_forward_a<true>(x, ctx);
-        if (pipe.late) pipe.sync(first_row + d);
+        if (pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
         ntt_forward_bc<false>(x, ctx);
-        if (!pipe.late) pipe.sync(first_row + d);
+        if (!pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
         pointwise_accumulate(A0, A1, x, pipe.row(first_row + d));
     }
 }
@@ -339,6 +349,10 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
         acc1[r] = neg ? 0u - kMu : kMu;
     }
     __syncthreads();          // tables staged; abar list visible (own wave only, but cheap)
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    unsigned long long diag_wait = 0;
+    const unsigned long long diag_t0 = __builtin_readcyclecounter();
+#endif
 
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
@@ -348,8 +362,8 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
         // six wide products of at most 1.702 p each: 10.21 p < 2^53, no reduction in between
-        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows);
-        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL);
+        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows CUFHE_AMD_DIAG_PASS);
+        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL CUFHE_AMD_DIAG_PASS);
         inverse_and_add(A0, acc0, ctx);
         inverse_and_add(A1, acc1, ctx);
     }
@@ -361,6 +375,12 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
             o[lane + 64 * r] = acc0[r];
             o[kN + lane + 64 * r] = acc1[r];
         }
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+        if (lane == 0) {      // overwrites the first words of this rotation's dump: timing only
+            ((unsigned long long*)o)[0] = __builtin_readcyclecounter() - diag_t0;
+            ((unsigned long long*)o)[1] = diag_wait;
+        }
+#endif
     }
     if (d.out) {
         // __SampleExtractIndex__<P,0>: out[0] = a[0], out[m] = -a[N-m], out[N] = b[0]
