@@ -18,6 +18,7 @@
 #include "sched_core.h"
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
+#include "kernels_ks2.hip.h"
 #include "kernels_ll.hip.h"
 #include "kernels_ps.hip.h"
 
@@ -60,7 +61,7 @@ struct DeviceState {
     bool profiling = false;
     bool br_lds_opt_in = false, ks_lds_opt_in = false;
     // N = 2048 / 64-bit torus (lvl2.inc.h)
-    bool keys2_ready = false, br2_lds_opt_in = false;
+    bool keys2_ready = false, br2_lds_opt_in = false, ks2_lds_opt_in = false;
     NttTables* tables2 = nullptr;      // [2]: the two half transforms
     double* bk2_ntt = nullptr;
     uint32_t* ksk2 = nullptr;
@@ -685,7 +686,7 @@ int cufhe_amd_cleanup(void)
         ps_release(i);
         if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
-        s.keys2_ready = s.br2_lds_opt_in = false;
+        s.keys2_ready = s.br2_lds_opt_in = s.ks2_lds_opt_in = false;
         s.tables2 = nullptr; s.bk2_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables512)); }
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }

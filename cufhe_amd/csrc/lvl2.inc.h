@@ -74,7 +74,17 @@ int launch_keyswitch_lvl2(DeviceState& s, hipStream_t st, const LinDesc64* d, si
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    hipLaunchKernelGGL(keyswitch_lvl2_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk2);
+    if ((long)count <= g_ks_wg_threshold) {
+        // a workgroup per ciphertext, rows from L2: lowest latency for a handful of ciphertexts
+        hipLaunchKernelGGL(keyswitch_lvl2_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk2);
+    } else {
+        if (!s.ks2_lds_opt_in) {
+            HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_lvl2_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2KsLdsBytes));
+            s.ks2_lds_opt_in = true;
+        }
+        const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
+        hipLaunchKernelGGL(keyswitch_lvl2_shared_kernel, dim3(blocks), dim3(kKsThreads), k2KsLdsBytes, st, d, (int)count, s.ksk2);
+    }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
