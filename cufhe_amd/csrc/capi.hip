@@ -82,8 +82,14 @@ int phys_device(int device)
     return device + g_device_base;
 }
 long g_wg_threshold = 0;    // rotations per launch up to which the workgroup-per-rotation kernel is used
-long g_ks_split_threshold = 32; // key switches per launch up to which each ciphertext is split over 8 workgroups
-long g_ks_wg_threshold = 128;  // key switches per launch up to which the workgroup-per-ciphertext kernel is used
+long g_ks_split_threshold = -1; // key switches per launch up to which each ciphertext is split over 8 workgroups
+// Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, MI355X, ms per launch of n key switches):
+//   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.66 (2048)
+//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.18 (1536)  1.57 (2048)  3.10 (4096)
+//   16 ciphertexts per workgroup, table through LDS: 1.5 - 1.6 whatever n <= 4096 (1024 dependent steps)
+// so: split up to 192, one workgroup per ciphertext up to 1900, the shared-table kernel above.
+constexpr long kKsAutoSplit = 192, kKsAutoWg = 1900;
+long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
@@ -317,8 +323,8 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
                            s.bk_ntt, s.tables, steps, dump, active);
     };
     // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
-    //   low-latency kernel  3.5 (n <= 64), 5.4 / 8.9 / 12.3 / 15.7 / 19.2 per started round of 256
-    //   one rotation per SIMD 13.6 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
+    //   low-latency kernel  3.5 (n <= 64), 3.9 / 7.5 / 11.2 / 14.9 / 18.5 per started round of 256 (key switch included)
+    //   one rotation per SIMD 12.7 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
     // so: low-latency up to 768 and for 1025..1280, one-per-SIMD for 769..1024, a full round above.
     const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
@@ -369,10 +375,12 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
         s.ks_lds_opt_in = true;
     }
-    if ((long)count <= g_ks_split_threshold) {
+    const long split_max = g_ks_split_threshold < 0 ? kKsAutoSplit : g_ks_split_threshold;
+    const long wg_max = g_ks_wg_threshold < 0 ? kKsAutoWg : g_ks_wg_threshold;
+    if ((long)count <= split_max) {
         hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
         hipLaunchKernelGGL(keyswitch_split_kernel, dim3((unsigned)count * kKsSplit), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
-    } else if ((long)count <= g_ks_wg_threshold) {
+    } else if ((long)count <= wg_max) {
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
         const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);

@@ -181,14 +181,15 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * rounds of the batch kernel's grid (2048 rotations: two per SIMD, highest throughput) plus a tail, and the
  * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: the 16-wave
  * workgroup-per-rotation kernel with split transforms (lowest latency: 3.5 ms for up to 64 rotations,
- * 5.4 / 8.9 / 12.3 ms for up to 256 / 512 / 768), the batch kernel with one rotation per SIMD (13.6 ms for
+ * 3.9 / 7.5 / 11.2 ms for up to 256 / 512 / 768), the batch kernel with one rotation per SIMD (12.7 ms for
  * up to 1024), or a full round (20.7 ms).  "ll_threshold" / "half_threshold" (default -1 = by cost) force
  * the first / second of these up to the given count, "wg_threshold" (default 0) the older 8-wave
  * workgroup-per-rotation kernel, "tail_split" 0 launches everything above 2048 as one grid.
- * "ks_wg_threshold" (default 128) / "ks_split_threshold" (default 32): the same choice for the key
- * switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (lowest latency), up
- * to ks_wg_threshold one workgroup per ciphertext, above that 16 ciphertexts share each step of the
- * key in LDS.  All variants produce identical words.
+ * "ks_wg_threshold" / "ks_split_threshold" (default -1 = by measured cost: 1900 / 192): the same choice
+ * for the key switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (0.05 ms
+ * up to 32, 0.19 ms at 192), up to ks_wg_threshold one workgroup per ciphertext (0.22 ms up to 256,
+ * 0.8 ms at 1024), above that 16 ciphertexts share each step of the key in LDS (1.5 ms whatever the
+ * count up to 4096).  All variants produce identical words.
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
  * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in

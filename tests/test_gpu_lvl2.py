@@ -73,9 +73,9 @@ def test_keyswitch_words(engine2, keys2):
 
 @pytest.mark.parametrize("count", [129, 203])
 def test_keyswitch_words_shared_table_kernel(engine2, keys2, count):
-    """Above ks_wg_threshold (128) the launch uses keyswitch_lvl2_shared_kernel (16 ciphertexts per workgroup, table
-    rows through LDS); 129 and 203 leave a ragged last workgroup.  Same words as the oracle and as the
-    workgroup-per-ciphertext kernel."""
+    """keyswitch_lvl2_shared_kernel (16 ciphertexts per workgroup, table rows through LDS; the default above 1400
+    ciphertexts per launch, forced here); 129 and 203 leave a ragged last workgroup.  Same words as the oracle and as
+    the workgroup-per-ciphertext kernel."""
     rng = np.random.default_rng(count)
     t2 = rng.integers(0, 2**64, size=(count, ol.LVL2_WORDS), dtype=np.uint64)
     t2[0] = 0
@@ -84,16 +84,17 @@ def test_keyswitch_words_shared_table_kernel(engine2, keys2, count):
     t2[3, : ol.N2] = np.uint64(0x8000000000000000)      # every digit at its extreme
     d2 = _upload(engine2, t2)
     d0 = engine2.api.DeviceBuffer(count * (ol.n + 1))
-    engine2.lvl2_keyswitch_batch(d2, d0, count)
-    got = d0.download().reshape(count, ol.n + 1).copy()
-    for g in list(range(20)) + list(range(count - 20, count)):
-        assert np.array_equal(got[g], keys2.keyswitch(t2[g])), f"key switch {g} differs"
-    engine2.api.set_option("ks_wg_threshold", 1 << 20)
+    engine2.api.set_option("ks_wg_threshold", 0)
     try:
+        engine2.lvl2_keyswitch_batch(d2, d0, count)
+        got = d0.download().reshape(count, ol.n + 1).copy()
+        for g in list(range(20)) + list(range(count - 20, count)):
+            assert np.array_equal(got[g], keys2.keyswitch(t2[g])), f"key switch {g} differs"
+        engine2.api.set_option("ks_wg_threshold", 1 << 20)
         engine2.lvl2_keyswitch_batch(d2, d0, count)
         assert np.array_equal(d0.download().reshape(count, ol.n + 1), got)
     finally:
-        engine2.api.set_option("ks_wg_threshold", 128)
+        engine2.api.set_option("ks_wg_threshold", -1)
 
 
 def test_every_gate_words_and_truth(engine2, keys, keys2, oracle):

@@ -27,8 +27,8 @@ def br_kernel(request, engine):
     yield which
     engine.api.set_option("ll_threshold", -1)
     engine.api.set_option("wg_threshold", 0)
-    engine.api.set_option("ks_wg_threshold", 128)
-    engine.api.set_option("ks_split_threshold", 32)
+    engine.api.set_option("ks_wg_threshold", -1)
+    engine.api.set_option("ks_split_threshold", -1)
     engine.api.set_option("half_threshold", -1)
 
 
@@ -432,7 +432,7 @@ def test_ragged_batch_sizes(engine, keys, count):
             got = dout.download().reshape(count, -1)
         finally:
             engine.api.set_option("wg_threshold", 0)
-            engine.api.set_option("ks_wg_threshold", 128)
+            engine.api.set_option("ks_wg_threshold", -1)
         assert np.array_equal(keys.decrypt(got, 0), bits[0] ^ bits[1])
         idx = np.unique(np.array([0, count // 2, count - 1]))
         want = keys.gate_batch(ol.OPS.index("XOR"), 0, ins[0][idx], ins[1][idx])

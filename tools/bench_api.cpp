@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../include/cufhe_amd.hpp"
@@ -15,6 +16,13 @@ using P = TFHEpp::lvl0param;
 int main(int argc, char** argv)
 {
     const int kNumTests = argc > 1 ? atoi(argv[1]) : 4096, kNumStreams = 256;
+    // further arguments: library options as key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
+    for (int i = 2; i < argc; i++) {
+        std::string kv(argv[i]);
+        const size_t eq = kv.find('=');
+        if (eq == std::string::npos) continue;
+        CUFHE_AMD_CHECK(cufhe_amd_set_option(kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1)));
+    }
     std::mt19937 eng(1);
     std::vector<uint32_t> bk((size_t)630 * 6 * 2 * 1024), ksk((size_t)1024 * 8 * 2 * 631);
     for (auto& v : bk) v = eng();
