@@ -24,7 +24,7 @@
 // it decomposes digit d of (X^abar - 1) acc_j, transforms it, multiplies by its 6 key
 // polynomials (2 outputs x 3 limbs) and adds the products into six LDS sums with ds_add_f64;
 // waves 0-5 then each inverse-transform one sum and add their limb of the result into the
-// 64-bit accumulator in LDS with ds_add_u64.  Four workgroup barriers per CMux step.
+// 64-bit accumulator in LDS with ds_add_u64.  Five workgroup barriers per CMux step.
 // LDS: 8 transpose tiles (66 KiB), accumulator 2 x 2048 x u64 (32 KiB), sums 6 x 1024 x f64
 // (48 KiB), abar list, the per-lane twiddles of stages 4-7 (7.5 KiB).  The stage 8-9 twiddle
 // tables of the two halves (24 KiB) do not fit beside that and are read from global memory
@@ -57,6 +57,7 @@ constexpr int k2KsNumBase = 1 << (k2KsBasebit - 1);
 constexpr double k2LimbSumBound = 2.0 * k2L * k2N * (double)(1u << (k2Bgbit - 1)) * (double)(1u << (k2LimbBits - 1));
 static_assert(k2LimbSumBound < fpf::P / 2, "lvl2 limb products do not fit the FP64 prime: use narrower limbs");
 static_assert(k2Limbs * k2LimbBits >= 64, "limbs do not cover the 64-bit key word");
+static_assert(k2L == 4 && k2N == 4 * 512, "the decomposition is shared by the l = 4 waves of a row group, 256 pairs (e, e + 1024) each");
 // digits of magnitude Bg/2 through the first (exact) split stage and a full reducing half transform,
 // reduced before the products: each product <= 0.5 + 0.0973 * 0.5, 2 l rows accumulate in LDS
 static_assert((double)(1u << (k2Bgbit - 1)) * (1.0 + fpf::ROOT4) < 9007199254740992.0 / 1024.0, "first split stage is not exact");
@@ -239,13 +240,6 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     const int wj = wave / k2L, wd = wave % k2L;               // this wave's TRGSW row = wj * l + wd
     const WaveCtx ctx_tile = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
     const bool inv_wave = wave < k2Prods;
-    // digit wd is the 9-bit field at bit dpos = 64 - 9 (wd + 1) of the decomposed word: wd = 0..2 lie in the high word
-    // (alignbit of (hi, hi) by dpos - 32 is a rotate: the field lands at bit 0), wd = 3 straddles the words (alignbit of
-    // (hi, lo) by dpos = 28)
-    const int dpos = 64 - k2Bgbit * (wd + 1);
-    const bool dlo = dpos < 32;
-    const uint32_t dsh = (uint32_t)(dlo ? dpos : dpos - 32);
-
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     // timing-only: cycles of this wave per phase: [0] decompose, [1 + 4h] forward, [2 + 4h] products, [3 + 4h] barrier,
     // [4 + 4h] inverse (+ recombination), [9] barriers after the inverse phases
@@ -272,40 +266,53 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         load_key_poly(kb[0], CUFHE_AMD_KEYPOLY(0), lane);     // in flight during the decomposition + NTT
         load_key_poly(kb[1], CUFHE_AMD_KEYPOLY(1), lane);
 
-        // digit wd of (X^abar - 1) acc_wj at e (low half-word) and e + 1024 (high half-word);
-        // kept packed across the two halves: 16 registers instead of 64.  The LDS reads of eight register slots
-        // are issued together (32 ds_read_b64 in flight), then consumed: four at a time cost a round trip per slot.
+        // Decomposition of (X^abar - 1) acc_wj, shared by the four waves of group wj: this wave forms the words at the
+        // pairs (e, e + 1024), e = 256 wd + lane + 64 m, extracts all four digits and writes digit d, packed per pair,
+        // into the transpose tile of wave (wj, d) -- free at this point of the step; after the barrier every wave
+        // picks up its own digit for all of e.  (Each wave used to read all of acc_wj for its one digit.)
         uint32_t ab[kRegs];
         {
             const char* accj = (const char*)(accL + wj * k2N);
-            const char* cbase = accj + opaque(8 * lane);
-            const int rb = (lane - alo) & (k2N - 1);
+            const int e_first = 256 * wd + lane;
+            const int rb = (e_first - alo) & (k2N - 1);
+            const char* cbase = accj + opaque(8 * e_first);
+            uint64_t rot0[4], rot1[4], cur0[4], cur1[4];
 #pragma unroll
-            for (int r0 = 0; r0 < kRegs; r0 += 8) {
-                uint64_t rot0[8], rot1[8], cur0[8], cur1[8];
+            for (int m = 0; m < 4; m++) {
+                const int i0 = (rb + 64 * m) & (k2N - 1);
+                rot0[m] = *(const uint64_t*)(accj + 8 * i0);
+                rot1[m] = *(const uint64_t*)(accj + 8 * (i0 ^ k2Half));
+                cur0[m] = *(const uint64_t*)(cbase + 512 * m);
+                cur1[m] = *(const uint64_t*)(cbase + 512 * m + 8 * k2Half);
+            }
+            char* dig_out = smem + opaque(k2LdsTiles + (wj * k2L) * kTileBytes + 4 * e_first);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int r = r0 + q;
-                    const int i0 = (rb + 64 * r) & (k2N - 1);
-                    rot0[q] = *(const uint64_t*)(accj + 8 * i0);
-                    rot1[q] = *(const uint64_t*)(accj + 8 * (i0 ^ k2Half));
-                    cur0[q] = *(const uint64_t*)(cbase + 512 * r);
-                    cur1[q] = *(const uint64_t*)(cbase + 512 * r + 8 * k2Half);
-                }
-                asm volatile("" ::: "memory");
+            for (int m = 0; m < 4; m++) {
+                const int e0 = e_first + 64 * m;
+                const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
+                const uint64_t t0 = ((neg0 ? 0ull - rot0[m] : rot0[m]) - cur0[m] + decomp_offset2()) ^ decomp_signmask2();
+                const uint64_t t1 = ((neg1 ? 0ull - rot1[m] : rot1[m]) - cur1[m] + decomp_offset2()) ^ decomp_signmask2();
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int e0 = lane + 64 * (r0 + q);
-                    const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
-                    const uint64_t t0 = ((neg0 ? 0ull - rot0[q] : rot0[q]) - cur0[q] + decomp_offset2()) ^ decomp_signmask2();
-                    const uint64_t t1 = ((neg1 ? 0ull - rot1[q] : rot1[q]) - cur1[q] + decomp_offset2()) ^ decomp_signmask2();
-                    // the 9-bit field at bit `dpos` of t, sign-extended, with 32-bit operations (64-bit shifts are slow):
-                    // v_alignbit_b32 brings the field to bit 0 whichever word(s) it sits in, v_bfe_i32 sign-extends it
-                    const uint32_t a = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t0 >> 32), dlo ? (uint32_t)t0 : (uint32_t)(t0 >> 32), dsh), 0u, (uint32_t)k2Bgbit);
-                    const uint32_t b = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), dlo ? (uint32_t)t1 : (uint32_t)(t1 >> 32), dsh), 0u, (uint32_t)k2Bgbit);
-                    ab[r0 + q] = (a & 0xffffu) | (b << 16);
+                for (int dd = 0; dd < k2L; dd++) {
+                    // the 9-bit field at bit 64 - 9 (dd + 1) of t, sign-extended, with 32-bit operations: dd = 0..2 lie in the
+                    // high word, dd = 3 straddles the words (v_alignbit brings it to bit 0)
+                    constexpr int kTop = 64 - k2Bgbit;
+                    const int pos = kTop - k2Bgbit * dd;
+                    uint32_t a, b;
+                    if (pos >= 32) {
+                        a = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t0 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
+                        b = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t1 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
+                    } else {
+                        a = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t0 >> 32), (uint32_t)t0, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
+                        b = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), (uint32_t)t1, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
+                    }
+                    *(uint32_t*)(dig_out + dd * kTileBytes + 256 * m) = __builtin_amdgcn_perm(b, a, 0x05040100u);   // (a & 0xffff) | (b << 16)
                 }
             }
+            __syncthreads();
+            const char* dig_in = smem + opaque(k2LdsTiles + wave * kTileBytes + 4 * lane);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) ab[r] = *(const uint32_t*)(dig_in + 256 * r);
         }
         CUFHE_AMD_PHASE2(0)
         double R0[kRegs];
