@@ -16,18 +16,22 @@ using P = TFHEpp::lvl0param;
 int main(int argc, char** argv)
 {
     const int kNumTests = argc > 1 ? atoi(argv[1]) : 4096, kNumStreams = 256;
-    // further arguments: library options as key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
+    // further arguments: gpus=G (SetGPUNum(G): streams and gates round-robin the devices like the reference's
+    // test_gate_gpu_multi.cc; with share_devices=1 the G logical devices share the visible GPUs) and library options as
+    // key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
+    int gpus = 1;
     for (int i = 2; i < argc; i++) {
         std::string kv(argv[i]);
         const size_t eq = kv.find('=');
         if (eq == std::string::npos) continue;
+        if (kv.substr(0, eq) == "gpus") { gpus = atoi(kv.c_str() + eq + 1); continue; }
         CUFHE_AMD_CHECK(cufhe_amd_set_option(kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1)));
     }
     std::mt19937 eng(1);
     std::vector<uint32_t> bk((size_t)630 * 6 * 2 * 1024), ksk((size_t)1024 * 8 * 2 * 631);
     for (auto& v : bk) v = eng();
     for (auto& v : ksk) v = eng();
-    SetGPUNum(1);
+    SetGPUNum(gpus);
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     std::vector<Ctxt<P>> a(kNumTests), b(kNumTests), o(kNumTests);
     for (int i = 0; i < kNumTests; i++)
@@ -37,8 +41,18 @@ int main(int argc, char** argv)
     for (auto& s : st) s.Create();
     double best_tot = 1e30, best_enq = 0;
     cufhe_amd_sched_stats ss{};
+    auto all_stats = [&](cufhe_amd_sched_stats& sum, int reset) {      // summed over the devices
+        sum = cufhe_amd_sched_stats{};
+        for (int dev = 0; dev < gpus; dev++) {
+            cufhe_amd_sched_stats one{};
+            CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(dev, &one, reset));
+            sum.gates += one.gates; sum.levels += one.levels; sum.launch_sequences += one.launch_sequences;
+            sum.record_ns += one.record_ns; sum.retire_ns += one.retire_ns; sum.launch_ns += one.launch_ns;
+            sum.max_level_gates = std::max(sum.max_level_gates, one.max_level_gates);
+        }
+    };
     for (int rep = 0; rep < 4; rep++) {
-        CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ss, 1));
+        all_stats(ss, 1);
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < kNumTests; i++) Nand(o[i], a[i], b[i], st[i % kNumStreams]);
         auto t1 = std::chrono::steady_clock::now();
@@ -49,15 +63,15 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "rep %d: %d Nand via per-gate API: enqueue %.2f ms, total %.2f ms, %.0f gates/s, %.4f ms/gate\n", rep,
                      kNumTests, enq, tot, kNumTests / (tot * 1e-3), tot / kNumTests);
         if (rep && tot < best_tot) { best_tot = tot; best_enq = enq; }
-        CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ss, 0));
+        all_stats(ss, 0);
     }
     // one JSON line (bench.py reads it): the PCIe-inclusive per-gate API rate and the host cost per gate --
     // on the issuing thread (record + deliver) and on the device's launch worker
     const double issue_us = (ss.record_ns + ss.retire_ns) * 1e-3 / kNumTests, worker_us = ss.launch_ns * 1e-3 / kNumTests;
-    std::printf("{\"gates\": %d, \"streams\": %d, \"total_ms\": %.3f, \"enqueue_ms\": %.3f, \"gates_per_s\": %.1f, "
+    std::printf("{\"gates\": %d, \"devices\": %d, \"streams\": %d, \"total_ms\": %.3f, \"enqueue_ms\": %.3f, \"gates_per_s\": %.1f, "
                 "\"host_issue_us_per_gate\": %.4f, \"host_worker_us_per_gate\": %.4f, \"host_issue_gates_per_s\": %.0f, "
                 "\"launch_sequences\": %llu}\n",
-                kNumTests, kNumStreams, best_tot, best_enq, kNumTests / (best_tot * 1e-3), issue_us, worker_us, 1e6 / issue_us,
+                kNumTests, gpus, kNumStreams, best_tot, best_enq, kNumTests / (best_tot * 1e-3), issue_us, worker_us, 1e6 / issue_us,
                 (unsigned long long)ss.launch_sequences);
     // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
     // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
@@ -73,7 +87,7 @@ int main(int argc, char** argv)
         double best = 1e30;
         cufhe_amd_sched_stats ns{};
         for (int rep = 0; rep < 2; rep++) {
-            CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ns, 1));
+            all_stats(ns, 1);
             auto t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < kAdders; i++) {
                 Stream s = st[i % kNumStreams];
@@ -88,7 +102,7 @@ int main(int argc, char** argv)
             }
             Synchronize();
             best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-            CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(0, &ns, 0));
+            all_stats(ns, 0);
         }
         std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"gates\": %llu, \"total_ms\": %.2f, "
                     "\"gates_per_s\": %.0f, \"dependence_levels\": %llu, \"launch_sequences\": %llu, \"max_level_gates\": %llu}\n",
