@@ -325,15 +325,25 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
     //   low-latency kernel  3.5 (n <= 64), 3.9 / 7.5 / 11.2 / 14.9 / 18.5 per started round of 256 (key switch included)
     //   one rotation per SIMD 12.7 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
-    // so: low-latency up to 768 and for 1025..1280, one-per-SIMD for 769..1024, a full round above.
+    // so: low-latency up to 768, one-per-SIMD for 769..1024, both for 1025..1280, a full round above.
     const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
+    auto launch_ll = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
+        // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
+        hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)n), dim3(kLlThreads), kLlLdsBytes, st, dd, (int)n,
+                           s.bk_ntt, s.tables512, steps, dump);
+    };
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
-        const bool use_ll = auto_ll ? (n <= 768 || (n > 1024 && n <= 1280 && auto_half)) : (long)n <= g_ll_threshold;
+        if (auto_ll && auto_half && n > 1024 && n <= 1280) {
+            // 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.6): 15.6 ms against
+            // 18.5 for five rounds of the low-latency kernel and 20 for a full round
+            launch_batch(dd, 1024, kBrWavesPerBlock / 2, dump);
+            launch_ll(dd + 1024, n - 1024, dump ? dump + (size_t)1024 * 2 * kN : nullptr);
+            return;
+        }
+        const bool use_ll = auto_ll ? n <= 768 : (long)n <= g_ll_threshold;
         const bool use_half = auto_half ? n <= 1024 : (long)n <= g_half_threshold;
         if (use_ll) {
-            // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
-            hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)n), dim3(kLlThreads), kLlLdsBytes, st, dd, (int)n,
-                               s.bk_ntt, s.tables512, steps, dump);
+            launch_ll(dd, n, dump);
         } else if ((long)n <= g_wg_threshold) {
             // one 8-wave workgroup per rotation (kernels.hip.h); unused with the default thresholds
             hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)n), dim3(kWgThreads), kWgLdsBytes, st, dd, (int)n,

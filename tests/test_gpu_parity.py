@@ -440,6 +440,7 @@ def test_ragged_batch_sizes(engine, keys, count):
 
 
 @pytest.mark.parametrize("count,opts", [(700, dict(ll_threshold=0, wg_threshold=0)),        # one rotation per SIMD (4 of 8 waves)
+                                        (1100, {}), (3200, {}),                               # (rounds +) 1024 at one per SIMD + low-latency kernel
                                         (2049, {}), (2700, {}), (4600, {})])                  # full rounds + a tail
 def test_launch_shapes_with_tails(engine, keys, count, opts):
     """Launches that do not fill whole rounds of the blind-rotate grid are cut into full rounds plus a
@@ -460,7 +461,8 @@ def test_launch_shapes_with_tails(engine, keys, count, opts):
         engine.api.set_option("wg_threshold", 0)
     assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
     cut = count - count % 2048
-    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, count - 5, count - 1]), 0, count - 1))
+    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, cut + 1023, cut + 1024, cut + 1027,
+                                      count - 5, count - 1]), 0, count - 1))
     want = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0][idx], ins[1][idx])
     assert np.array_equal(got[idx], want)
 
