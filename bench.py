@@ -21,7 +21,8 @@ Prints ONE JSON line (rank 0):
                            streams, enqueue -> Synchronize (test/test_util.h:29-72), and the host cost
                            per gate of that path
   extra_workloads          mux (configs[3]), mixed (configs[2] op mix), nand_lvl2 (configs[4]): rate,
-                           roofline fraction and a word-for-word oracle check each
+                           roofline fraction and a word-for-word oracle check each; param_sets: the other
+                           compiled parameter sets through the generic kernels
   cpu_baseline             an optimised CPU implementation of the same gate (oracle/cpu_fast.c: same
                            exact FP64 field, AVX-512/AVX2, OpenMP over gates) timed on this box's host
                            cores on a bounded sample; the CPU oracle checks both its words and the GPU's
@@ -391,6 +392,49 @@ def main():
                                           "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, -1), out2[idx]))}
                 except Exception as e:
                     extra["nand_lvl2"] = {"error": repr(e)}
+                # the other compiled parameter sets through the generic kernels (kernels_ps.hip.h),
+                # 4096 NAND on random keys, sampled words against the oracle compiled for the set
+                psets = {}
+                for ps in range(api.ps_count()):
+                    pp = api.ps_params(ps)
+                    name = pp.name.decode()
+                    try:
+                        prng = np.random.default_rng(100 + ps)
+                        pbk = prng.integers(0, 2**32, size=int(pp.bk_words), dtype=np.uint64).astype(np.uint32)
+                        pksk = prng.integers(0, 2**32, size=int(pp.ksk_words), dtype=np.uint64).astype(np.uint32)
+                        api.ps_initialize(ps, pbk, pksk)
+                        w = int(pp.lvl0_words)
+                        pin = [prng.integers(0, 2**32, size=(count, w), dtype=np.uint64).astype(np.uint32) for _ in range(2)]
+                        pd = [api.DeviceBuffer(count * w).upload(x) for x in pin]
+                        pout = api.DeviceBuffer(count * w)
+
+                        def ps_step():
+                            api.ps_gate_batch(ps, api.NAND, pout, pd[0], pd[1], count=count, stream=st.st())
+                        ps_step()
+                        eng.Synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(2):
+                            ps_step()
+                        eng.Synchronize()
+                        dt = (time.perf_counter() - t0) / 2
+                        got = pout.download().reshape(count, w)
+                        Ls = oracle_lib.load_set(name)
+                        eks = Ls.orc_evalkey_create(pbk, pksk)
+                        idx = np.arange(1, count, max(1, count // 8))[:8]
+                        want = np.zeros(idx.size * w, np.uint32)
+                        a_s, b_s = np.ascontiguousarray(pin[0][idx]).ravel(), np.ascontiguousarray(pin[1][idx]).ravel()
+                        Ls.orc_gate_batch(eks, np.array([0], np.int32), 0, 0, idx.size, want, a_s, b_s.ctypes.data, None,
+                                          min(Ls.orc_max_threads(), 32))
+                        Ls.orc_evalkey_destroy(eks)
+                        bk_bytes = int(pp.bk_ntt_bytes)        # n (k+1)^2 l N 8 x key limbs: one sweep of the NTT-domain key
+                        psets[name] = {"params": f"n={pp.n} N={pp.N} k={pp.k} l={pp.l} Bgbit={pp.Bgbit} key_limbs={pp.key_limbs}",
+                                       "value": count / dt, "unit": "gate-bootstraps/s", "ms_per_step": 1e3 * dt,
+                                       "kernel": "blind_rotate_ps_batch_kernel<PS> (wave per rotation, written once over the set; not hand-scheduled)",
+                                       "bk_sweep_frac_of_hbm_peak": count * bk_bytes / dt / 8e12,
+                                       "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, w), got[idx]))}
+                    except Exception as e:
+                        psets[name] = {"error": repr(e)}
+                extra["param_sets"] = psets
                 res["extra_workloads"] = extra
             L.orc_evalkey_destroy(oek)
         if lvl2 and not args.no_cpu_baseline and WORLD == 1:

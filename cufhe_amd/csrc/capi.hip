@@ -1053,6 +1053,7 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "tail_split")) { g_tail_split = value; return 0; }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
+    if (!strcmp(key, "ps_batch_threshold")) { g_ps_batch_threshold = value; return 0; }
     if (!strcmp(key, "lvl0_param_set")) {
         if (value >= 0) {
             cufhe_amd_ps_params p;

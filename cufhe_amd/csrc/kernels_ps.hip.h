@@ -17,10 +17,16 @@
 //     mod 2^32 -- the split kernels_lvl2.hip.h uses for the 64-bit torus.  static_asserts pick nothing
 //     silently: a set that does not fit does not compile.
 //
-// One workgroup of 8 waves per blind rotation (the shape of blind_rotate_wg_kernel): waves take TRGSW
-// rows round-robin (digit polynomial -> forward transform -> products with the row's (k+1) x limbs key
-// polynomials, added into LDS sums with ds_add_f64: exact integers, order-free), barrier, waves take
-// sums round-robin (inverse transform, centred lift, shifted add into the accumulator in LDS), barrier.
+// Two launch shapes, as in kernels.hip.h, both reading ONE NTT-domain key:
+//   blind_rotate_ps_kernel        one workgroup of 8 waves per rotation (small launches): waves take TRGSW rows
+//       round-robin (digit polynomial -> forward transform -> products with the row's (k+1) x limbs key
+//       polynomials, added into LDS sums with ds_add_f64: exact integers, order-free), barrier, waves take
+//       sums round-robin (inverse transform, centred lift, shifted add into the accumulator in LDS), barrier;
+//   blind_rotate_ps_batch_kernel  one WAVE per rotation, 8 rotations per workgroup walking the key together
+//       (large launches): the shape of blind_rotate_kernel -- accumulator and sums in registers, key rows
+//       staged once per workgroup in LDS by LDS-DMA one row ahead, one barrier per row -- written over PS.
+// NTT-domain key: [step][limb][row][out][q < R/2][lane][2] doubles: a TRGSW row of one limb is one contiguous
+// block of (k+1) polynomials, each in the spectrum order of the wave transform (registers 2q, 2q+1 of a lane).
 #pragma once
 #include "kernels.hip.h"
 #include "ntt_wave512.h"
@@ -133,7 +139,7 @@ struct PsLds {
 // ----------------------------------------------------------------------------------------------
 // BK (torus words) -> NTT domain, one wave per (polynomial, limb).
 // bk: [step][row][out][N] u32 (TFHEpp's BootstrappingKey layout, src/bootstrap_gpu.cu:43-49);
-// bk_ntt: [step][row][out][limb][R][64] doubles, scaled by N^-1, centred.
+// bk_ntt: [step][limb][row][out][R/2][64][2] doubles, scaled by N^-1, centred.
 // ----------------------------------------------------------------------------------------------
 template <class PS>
 __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
@@ -167,9 +173,15 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
         }
     }
     PO::forward(x, ctx);
-    double* dst = bk_ntt + (poly * PS::limbs + limb) * D::N;
+    const size_t step = poly / D::bk_step_polys, in_step = poly % D::bk_step_polys;       // in_step = row * K1 + out
+    double2* dst = (double2*)(bk_ntt + ((step * PS::limbs + limb) * D::bk_step_polys + in_step) * D::N);
 #pragma unroll
-    for (int r = 0; r < PO::R; r++) dst[r * 64 + lane] = fpf::reduce(fpf::mulmod_wide(x[r], n_inverse));
+    for (int q = 0; q < PO::R / 2; q++) {
+        double2 v;
+        v.x = fpf::reduce(fpf::mulmod_wide(x[2 * q], n_inverse));
+        v.y = fpf::reduce(fpf::mulmod_wide(x[2 * q + 1], n_inverse));
+        dst[q * 64 + lane] = v;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -240,14 +252,19 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
             PO::forward(x, ctx);
 #pragma unroll
             for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
-            const double* key = bk_ntt + ((size_t)i * D::ROWS + row) * (size_t)(D::SUMS * N);
 #pragma unroll 1
             for (int s = 0; s < D::SUMS; s++) {      // :206-221, one product per (output component, key limb)
-                const double* kp = key + s * N + lane;
+                const int out = s / PS::limbs, limb = s % PS::limbs;
+                const double2* kp = (const double2*)(bk_ntt + ((((size_t)i * PS::limbs + limb) * D::ROWS + row) * K1 + out) * N) + lane;
                 double* sp = sumL + s * N + lane;
+                double2 b[R / 2];
 #pragma unroll
-                for (int r = 0; r < R; r++)
-                    __hip_atomic_fetch_add(sp + r * 64, fpf::mulmod(x[r], kp[r * 64]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int q = 0; q < R / 2; q++) b[q] = kp[q * 64];
+#pragma unroll
+                for (int q = 0; q < R / 2; q++) {
+                    __hip_atomic_fetch_add(sp + (2 * q) * 64, fpf::mulmod(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(sp + (2 * q + 1) * 64, fpf::mulmod(x[2 * q + 1], b[q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         __syncthreads();
@@ -281,6 +298,234 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
             o[e] = m == 0 ? accL[j * N] : 0u - accL[j * N + N - m];
         }
         if (tid == 0) o[PS::k * N] = accL[PS::k * N];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Blind rotate (+ sample extract at 0), one WAVE per rotation, 8 rotations per workgroup: the design of
+// blind_rotate_kernel (kernels.hip.h) over PS.  Per wave: the accumulator ((k+1) x R words) and the k+1 sums
+// ((k+1) x R doubles) live in registers; X^abar acc_j goes through the wave's tile (rotate_sub); a TRGSW row of
+// the current key limb ((k+1) polynomials, 16 or 12 KiB) is copied once per workgroup into one of three LDS
+// buffers by LDS-DMA, one row ahead, and every wave takes exactly one barrier per row -- waves 4-7 before the
+// forward transform of the row, waves 0-3 after it, so that the two waves of a SIMD are half a row apart
+// (kernels.hip.h, RowPipe).  A set with key limbs walks the rows of a step once per limb: the digits are
+// decomposed again from the unchanged accumulator and the limb's exact sums, lifted and shifted, are collected
+// in `delta` until the last limb is done.
+// ----------------------------------------------------------------------------------------------
+// rotations (waves) per workgroup: 8 = two per SIMD.  The N = 512 sets need only 145 VGPRs and could run 12 (three per
+// SIMD): measured 107.8 k against 102 k gates/s at multiples of 3072 rotations, but a launch of 4096 then pays a second
+// round a third full (76.9 k), so every set keeps rounds of 2048.
+template <class PS> constexpr int kPsbWavesOf = 8;
+constexpr int kPsbRowBuffers = 3;
+
+template <class PS>
+struct PsbLds {
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    static constexpr int waves = kPsbWavesOf<PS>;
+    static constexpr int threads = 64 * waves;
+    static constexpr int row_bytes = D::K1 * D::N * 8;
+    static constexpr int row_pieces = row_bytes / 1024;                        // LDS-DMA pieces of 1 KiB
+    static constexpr int rows = 0;                                             // row buffers first: DS offsets < 64 KiB
+    static constexpr int tables = rows + kPsbRowBuffers * row_bytes;
+    static constexpr int tiles = tables + PO::table_bytes;
+    static constexpr int abar = tiles + waves * PO::tile_bytes;
+    static constexpr int bytes = abar + waves * kAbarBytes;
+    static_assert(row_bytes % 1024 == 0, "row is moved in 1 KiB pieces");
+    static_assert(2 * D::N * 4 <= PO::tile_bytes, "rotate_sub needs 2N words of the wave's tile");
+    static_assert(bytes <= 160 * 1024, "parameter set does not fit the CU's LDS");
+};
+
+template <int ROW_BYTES, int WAVES>
+struct PsRowPipe {
+    const char* bk;
+    char* buf;
+    int wave, lane, total_rows;
+    bool late;
+    __device__ __forceinline__ void issue(int R) const
+    {
+        if (R >= total_rows) return;
+        const char* src = bk + (size_t)R * ROW_BYTES + lane * 16;
+        char* dst = buf + (R % kPsbRowBuffers) * ROW_BYTES;
+        constexpr int pieces = ROW_BYTES / 1024;
+#pragma unroll
+        for (int c = 0; c < (pieces + WAVES - 1) / WAVES; c++) {
+            const int piece = wave + WAVES * c;
+            if (piece < pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void sync(int R) const
+    {
+        __syncthreads();     // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier: every wave's pieces of row R have landed
+        issue(R + 1);        // into the buffer of row R - 2, whose last reader passed its barrier R - 1
+    }
+    __device__ __forceinline__ const char* row(int R) const
+    {
+        return buf + opaque((R % kPsbRowBuffers) * ROW_BYTES + lane * 16);
+    }
+};
+
+// acc_j -> (X^abar - 1) acc_j + gadget offset, through the wave's tile (kernels.hip.h, rotate_sub)
+template <class PS, int R>
+__device__ __forceinline__ void ps_rotate_sub(uint32_t (&temp)[R], const uint32_t (&acc)[R], char* tile, int lane, uint32_t abar)
+{
+    constexpr int N = 1 << PS::Nbit;
+    const int alo = (int)(abar & (N - 1));
+    const bool ahi = (abar >> PS::Nbit) != 0;
+    char* wpos = tile + opaque(4 * lane + (ahi ? 0 : 4 * N));
+    char* wneg = tile + opaque(4 * lane + (ahi ? 4 * N : 0));
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        *(uint32_t*)(wpos + 256 * r) = acc[r];
+        *(uint32_t*)(wneg + 256 * r) = 0u - acc[r];
+    }
+    asm volatile("" ::: "memory");
+    const char* rbase = tile + opaque(4 * (lane - alo + N));
+    uint32_t rot[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; r++) temp[r] = (rot[r] - acc[r] + ps_decomp_offset<PS>()) ^ ps_decomp_signmask<PS>();
+}
+
+template <class PS>
+__global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void blind_rotate_ps_batch_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const typename Poly<PS::Nbit>::Tables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
+{
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    using L = PsbLds<PS>;
+    constexpr int N = D::N, R = D::R, K1 = D::K1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PO::load_tables(smem + L::tables, gt);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * L::waves + wave;
+    char* tile = smem + L::tiles + wave * PO::tile_bytes;
+    uint16_t* abar_lds = (uint16_t*)(smem + L::abar + wave * kAbarBytes);
+    const typename PO::Ctx ctx = PO::ctx(smem, L::tiles + wave * PO::tile_bytes, L::tables, gt, lane);
+    const PsRowPipe<L::row_bytes, L::waves> pipe{(const char*)bk_ntt, smem + L::rows, wave, lane, steps * PS::limbs * D::ROWS, wave >= L::waves / 2};
+    pipe.issue(0);
+    if (g >= count) {
+        // no rotation for this wave (tail of the batch): it only keeps its share of the row pipeline going
+        __syncthreads();
+#pragma unroll 1
+        for (int Rr = 0; Rr < pipe.total_rows; Rr++) pipe.sync(Rr);
+        return;
+    }
+
+    const LinDesc d = descs[g];
+    uint32_t bword = 0;       // pre-add and modulus switch, :316-345
+    for (int i = lane; i <= PS::n; i += 64) {
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < PS::n) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - PS::Nbit))) >> (32 - 1 - PS::Nbit));
+        else bword = c;
+    }
+    bword = __builtin_amdgcn_readlane(bword, PS::n % 64) + d.off;
+    const uint32_t bbar = 2 * N - (bword >> (32 - 1 - PS::Nbit));
+    uint32_t acc[K1][R];      // RotatedTestVector, :29-52: mask components zero, body +-mu
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t e = lane + 64 * r;
+        const bool neg = (bbar != 2 * N) && ((e < (bbar & (N - 1))) != ((bbar >> PS::Nbit) != 0));
+#pragma unroll
+        for (int j = 0; j < PS::k; j++) acc[j][r] = 0;
+        acc[PS::k][r] = neg ? 0u - kMu : kMu;
+    }
+    __syncthreads();          // tables staged; abar list visible
+
+    int row_id = 0;
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        uint32_t delta[K1][R];      // only live for sets with key limbs
+        if (PS::limbs > 1) {
+#pragma unroll
+            for (int o = 0; o < K1; o++)
+#pragma unroll
+                for (int r = 0; r < R; r++) delta[o][r] = 0;
+        }
+#pragma unroll 1
+        for (int limb = 0; limb < PS::limbs; limb++) {
+            double A[K1][R];
+#pragma unroll
+            for (int o = 0; o < K1; o++)
+#pragma unroll
+                for (int r = 0; r < R; r++) A[o][r] = 0.0;
+#pragma unroll
+            for (int j = 0; j < K1; j++) {       // include/gatebootstrapping_gpu.cuh:153-224
+                uint32_t temp[R];
+                ps_rotate_sub<PS, R>(temp, acc[j], tile, lane, abar);
+#pragma unroll 1
+                for (int dg = 0; dg < PS::l; dg++, row_id++) {
+                    const uint32_t pos = 32 - (dg + 1) * PS::Bgbit;
+                    double x[R];
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)PS::Bgbit);
+                    if (pipe.late) pipe.sync(row_id);
+                    PO::forward(x, ctx);
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
+                    if (!pipe.late) pipe.sync(row_id);
+                    const char* rowp = pipe.row(row_id);
+#pragma unroll
+                    for (int o = 0; o < K1; o++) {       // :206-221; each product <= 0.55 p, ROWS of them stay below 2^53
+                        double2 b[R / 2];
+#pragma unroll
+                        for (int q = 0; q < R / 2; q++) b[q] = *(const double2*)(rowp + (o * (R / 2) + q) * 1024);
+#pragma unroll
+                        for (int q = 0; q < R / 2; q++) {
+                            A[o][2 * q] += fpf::mulmod(x[2 * q], b[q].x);
+                            A[o][2 * q + 1] += fpf::mulmod(x[2 * q + 1], b[q].y);
+                        }
+                    }
+                }
+            }
+            const int shl = limb * PS::limb_bits;
+#pragma unroll
+            for (int o = 0; o < K1; o++) {               // :227-284
+#pragma unroll
+                for (int r = 0; r < R; r++) A[o][r] = fpf::reduce(A[o][r]);
+                PO::inverse(A[o], ctx);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t v = fpf::lift_u32(A[o][r]);     // the limb's exact sum mod 2^32
+                    if (PS::limbs == 1) acc[o][r] += v;
+                    else delta[o][r] += v << shl;
+                }
+            }
+        }
+        if (PS::limbs > 1) {
+#pragma unroll
+            for (int o = 0; o < K1; o++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[o][r] += delta[o][r];
+        }
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * K1 * N;
+#pragma unroll
+        for (int j = 0; j < K1; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) o[j * N + lane + 64 * r] = acc[j][r];
+    }
+    if (d.out) {   // __SampleExtractIndex__<P,0>: per mask component a'[0] = a[0], a'[m] = -a[N-m]; b' = b[0]
+        uint32_t* o = d.out;
+#pragma unroll
+        for (int j = 0; j < PS::k; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int e = lane + 64 * r;
+                if (e == 0) o[j * N] = acc[j][r];
+                else o[j * N + N - e] = 0u - acc[j][r];
+            }
+        if (lane == 0) o[PS::k * N] = acc[PS::k][0];
     }
 }
 

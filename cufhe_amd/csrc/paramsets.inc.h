@@ -6,6 +6,9 @@
 
 namespace {
 
+long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-per-rotation kernel is used (-1: by cost)
+constexpr long kPsAutoBatch = 600;
+
 struct PsState {
     bool ready = false, lds_opt_in = false;
     double* bk_ntt = nullptr;
@@ -43,10 +46,19 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
     if (count == 0) return 0;
     if (!ps.lds_opt_in) {
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsLds<PS>::bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_batch_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsbLds<PS>::bytes));
         ps.lds_opt_in = true;
     }
-    hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(kPsThreads), PsLds<PS>::bytes, st, d, (int)count,
-                       ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+    if ((long)count >= (g_ps_batch_threshold < 0 ? kPsAutoBatch : g_ps_batch_threshold)) {
+        // one wave per rotation, 8 rotations per workgroup share the key rows (throughput shape)
+        const unsigned blocks = (unsigned)((count + PsbLds<PS>::waves - 1) / PsbLds<PS>::waves);
+        hipLaunchKernelGGL(blind_rotate_ps_batch_kernel<PS>, dim3(blocks), dim3(PsbLds<PS>::threads), PsbLds<PS>::bytes, st, d, (int)count,
+                           ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+    } else {
+        // one workgroup per rotation (latency shape)
+        hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(kPsThreads), PsLds<PS>::bytes, st, d, (int)count,
+                           ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

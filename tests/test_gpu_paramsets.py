@@ -29,6 +29,15 @@ def pset(request, engine):
     return name, idx, L, K
 
 
+@pytest.fixture(autouse=True, params=["wg", "batch"])
+def ps_kernel(request, engine):
+    """Both launch shapes of the blind rotation: a workgroup per rotation (small launches) and a wave per rotation with
+    eight rotations per workgroup sharing the key rows (from 600 rotations on); forced here for every count."""
+    engine.api.set_option("ps_batch_threshold", 1 << 30 if request.param == "wg" else 1)
+    yield request.param
+    engine.api.set_option("ps_batch_threshold", -1)
+
+
 def _up(eng, a):
     a = np.ascontiguousarray(a, dtype=np.uint32)
     return eng.api.DeviceBuffer(a.size).upload(a)
@@ -37,7 +46,7 @@ def _up(eng, a):
 @pytest.mark.parametrize("steps", [0, 1, 2, 3, 41, -1])
 def test_accumulator_words(engine, pset, steps):
     name, idx, L, K = pset
-    count = 4 if steps == -1 else 6
+    count = 4 if steps == -1 else 13       # 13: a second workgroup with idle waves in the batch shape (8 or 12 rotations per workgroup)
     rng = np.random.default_rng(50 + steps)
     tl = rng.integers(0, 2**32, size=(count, K.n + 1), dtype=np.uint64).astype(np.uint32)
     tl[0, :4] = 0                      # abar = 0 steps
