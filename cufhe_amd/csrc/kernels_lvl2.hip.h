@@ -22,9 +22,9 @@
 //
 // Work split.  One 8-wave workgroup per blind rotation.  Wave w owns TRGSW row w = (j, d):
 // it decomposes digit d of (X^abar - 1) acc_j, transforms it, multiplies by its 6 key
-// polynomials (2 outputs x 3 limbs) and adds the products into six LDS sums with ds_add_f64;
-// waves 0-5 then each inverse-transform one sum and add their limb of the result into the
-// 64-bit accumulator in LDS with ds_add_u64.  Five workgroup barriers per CMux step.
+// polynomials (2 outputs x 3 limbs) and adds the products into six LDS sums with ds_add_f64, per half;
+// the twelve inverse half-transforms of the step then run three per SIMD in two phases, and waves 0-5 add
+// their limb of the result into the 64-bit accumulator in LDS with ds_add_u64.  Six workgroup barriers per CMux step.
 // LDS: 8 transpose tiles (66 KiB), accumulator 2 x 2048 x u64 (32 KiB), sums 6 x 1024 x f64
 // (48 KiB), abar list, the per-lane twiddles of stages 4-7 (7.5 KiB).  The stage 8-9 twiddle
 // tables of the two halves (24 KiB) do not fit beside that and are read from global memory
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     const bool inv_wave = wave < k2Prods;
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     // timing-only: cycles of this wave per phase: [0] decompose, [1 + 4h] forward, [2 + 4h] products, [3 + 4h] barrier,
-    // [4 + 4h] inverse (+ recombination), [9] barriers after the inverse phases
-    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+    // [4] sums of half 0 to registers + barrier, [8] inverse phase A, [9] barrier, [10] inverse phase B + recombination, [11] barrier
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
 #define CUFHE_AMD_PHASE2(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
 #else
 #define CUFHE_AMD_PHASE2(k)
@@ -315,22 +315,24 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
             for (int r = 0; r < kRegs; r++) ab[r] = *(const uint32_t*)(dig_in + 256 * r);
         }
         CUFHE_AMD_PHASE2(0)
-        double R0[kRegs];
+        // table addresses of half hh, rebuilt where needed (a few address adds) instead of being carried in 16
+        // registers through the whole step
+        auto half_ctx = [&](int hh) {
+            WaveCtx c = ctx_tile;
+            int o16 = 8 * (lane & 15), o64 = 8 * lane;
+            asm volatile("" : "+v"(o16), "+v"(o64));
+            const NttTables* gth = gt2 + hh;
+            c.tb_fwd = smem + (k2LdsTb + hh * k2TbBytes) + o16;
+            c.tb_inv = c.tb_fwd + 8 * kTbCount * 16;
+            c.tc_fwd = (const char*)gth->tc_fwd + o64;
+            c.tc_inv = (const char*)gth->tc_inv + o64;
+            c.gt = gth;
+            return c;
+        };
+        double S0[kRegs];         // waves 0-5: half 0 of sum `wave`, first as read from LDS, then inverse-transformed
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            // table addresses of this half, rebuilt here (a few address adds) instead of being
-            // carried in 16 registers through the whole step
-            WaveCtx ctx = ctx_tile;
-            {
-                int o16 = 8 * (lane & 15), o64 = 8 * lane;
-                asm volatile("" : "+v"(o16), "+v"(o64));
-                const NttTables* gth = gt2 + h;
-                ctx.tb_fwd = smem + (k2LdsTb + h * k2TbBytes) + o16;
-                ctx.tb_inv = ctx.tb_fwd + 8 * kTbCount * 16;
-                ctx.tc_fwd = (const char*)gth->tc_fwd + o64;
-                ctx.tc_inv = (const char*)gth->tc_inv + o64;
-                ctx.gt = gth;
-            }
+            const WaveCtx ctx = half_ctx(h);
             double x[kRegs];
 #pragma unroll
             for (int r = 0; r < kRegs; r++) {
@@ -351,35 +353,69 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 accumulate_poly(sumL + pp * k2Half, x, kb[k % 3], lane);
             }
             CUFHE_AMD_PHASE2(2 + 4 * h)
-            __syncthreads();
+            __syncthreads();              // the six sums of half h are complete
             CUFHE_AMD_PHASE2(3 + 4 * h)
-            if (inv_wave) {
-                double* s = sumL + wave * k2Half + lane;
-                double A[kRegs];
+            if (h == 0) {
+                // The sums of half 0 only move into registers here; their inverse transforms wait for those of half 1,
+                // so that the twelve inverse jobs of the step can be spread evenly over the four SIMDs (below).
+                if (inv_wave) {
+                    double* s = sumL + wave * k2Half + lane;
+#pragma unroll
+                    for (int r = 0; r < kRegs; r++) { S0[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
+                }
+                __syncthreads();          // the sums are zero again before any wave adds products of half 1
+                CUFHE_AMD_PHASE2(4)
+            }
+        }
+        // Twelve inverse half-transforms (6 sums x 2 halves) on 8 waves = 4 SIMDs x 2: three per SIMD.
+        //   phase A: waves 0-5 transform half 0 of their sum (from registers), waves 6-7 half 1 of sums 4 and 5, which they
+        //            leave in the sum's LDS slot for waves 4-5;
+        //   phase B: waves 0-3 transform half 1 of their sum and recombine; waves 4-5 only recombine.
+        // (Before: six jobs per phase, two on each of SIMDs 0-1 and one on each of SIMDs 2-3, twice per step.)
+        {
+            const bool own = inv_wave;
+            const WaveCtx ctx = half_ctx(own ? 0 : 1);
+            double* s = sumL + (own ? wave : wave - 2) * k2Half + lane;
+            double A[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) A[r] = own ? S0[r] : fpf::reduce(s[r * 64]);
+            ntt_inverse(A, ctx);                               // |A| <= 2 p, natural order
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                if (own) S0[r] = A[r];
+                else s[r * 64] = A[r];
+            }
+        }
+        CUFHE_AMD_PHASE2(8)
+        __syncthreads();
+        CUFHE_AMD_PHASE2(9)
+        if (inv_wave) {
+            double* s = sumL + wave * k2Half + lane;
+            double A[kRegs];
+            if (wave < 4) {
+                const WaveCtx ctx = half_ctx(1);
 #pragma unroll
                 for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-                ntt_inverse(A, ctx);                           // |A| <= 2 p, natural order
-                if (h == 0) {
+                ntt_inverse(A, ctx);
+            } else {
 #pragma unroll
-                    for (int r = 0; r < kRegs; r++) R0[r] = A[r];
-                } else {
-                    // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, then each wave
-                    // adds its limb of the exact sum, shifted, into the 64-bit accumulator
-                    const int out = wave / k2Limbs, shl = k2LimbBits * (wave % k2Limbs);
-                    unsigned long long* acck = (unsigned long long*)(accL + out * k2N) + lane;
-#pragma unroll
-                    for (int r = 0; r < kRegs; r++) {
-                        const double lo = fpf::reduce(R0[r] + A[r]);
-                        const double hi = fpf::reduce(fpf::mulmod(R0[r] - A[r], -fpf::ROOT4));
-                        __hip_atomic_fetch_add(acck + 64 * r, to_u64(lo) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(acck + k2Half + 64 * r, to_u64(hi) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
+                for (int r = 0; r < kRegs; r++) { A[r] = s[r * 64]; s[r * 64] = 0.0; }     // transformed by wave + 2
             }
-            CUFHE_AMD_PHASE2(4 + 4 * h)
-            __syncthreads();
-            CUFHE_AMD_PHASE2(9)
+            // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, then each wave adds its limb of
+            // the exact sum, shifted, into the 64-bit accumulator
+            const int out = wave / k2Limbs, shl = k2LimbBits * (wave % k2Limbs);
+            unsigned long long* acck = (unsigned long long*)(accL + out * k2N) + lane;
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                const double lo = fpf::reduce(S0[r] + A[r]);
+                const double hi = fpf::reduce(fpf::mulmod(S0[r] - A[r], -fpf::ROOT4));
+                __hip_atomic_fetch_add(acck + 64 * r, to_u64(lo) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acck + k2Half + 64 * r, to_u64(hi) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        CUFHE_AMD_PHASE2(10)
+        __syncthreads();
+        CUFHE_AMD_PHASE2(11)
     }
 
     if (acc_dump) {
@@ -390,7 +426,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     if (acc_dump && lane == 0 && g == 0) {
         __syncthreads();
         unsigned long long* o = (unsigned long long*)acc_dump + 2048 + wave * 16;     // overwrites part of the dump: timing only
-        for (int k = 0; k < 10; k++) o[k] = ph[k];
+        for (int k = 0; k < 12; k++) o[k] = ph[k];
     }
 #endif
     if (d.out) {   // __SampleExtractIndex__<lvl2param,0>, src/bootstrap_gpu.cu:366-381
