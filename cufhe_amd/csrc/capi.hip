@@ -94,6 +94,7 @@ long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave s
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
+constexpr int kMaxLogicalDevices = 64;    // SetGPUNum bound (per-device tables of fixed size: paramsets.inc.h)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
 std::mutex g_mu;
 
@@ -620,6 +621,7 @@ int cufhe_amd_set_gpu_num(int gpu_num)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (gpu_num < 1) return fail(-1, "gpu_num must be >= 1");
+    if (gpu_num > kMaxLogicalDevices) return fail(-1, "gpu_num exceeds the 64 logical devices this build is sized for");
     for (auto& d : g_dev)
         if (d.ntt_ready || d.keys_ready || d.tables2) return fail(-1, "SetGPUNum after Initialize: call CleanUp first");
     int have = cufhe_amd_device_count();

@@ -14,13 +14,9 @@ struct PsState {
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
 };
-std::deque<PsState> g_ps;        // [set * max devices + device], sized on first use
+PsState g_ps[kParamSets][kMaxLogicalDevices];
 
-PsState& ps_state(int set, int device)
-{
-    if (g_ps.size() < (size_t)kParamSets * 64) g_ps.resize((size_t)kParamSets * 64);
-    return g_ps[(size_t)set * 64 + device];
-}
+PsState& ps_state(int set, int device) { return g_ps[set][device]; }
 
 template <class F>
 int ps_dispatch(int set, F f)
@@ -133,7 +129,6 @@ int run_gates_ps(int set, int device, void* stream, size_t count, GetGate get)
 void ps_release(int device)
 {
     for (int set = 0; set < kParamSets; set++) {
-        if (g_ps.empty()) return;
         PsState& ps = ps_state(set, device);
         if (!ps.ready) continue;
         (void)hipFree(ps.bk_ntt);

@@ -53,6 +53,7 @@ def test_errors_are_reported_not_fatal():
     rc = lib.cufhe_amd_initialize(buf, 4, buf, 4)
     assert rc < 0 and b"wrong size" in lib.cufhe_amd_last_error()
     assert lib.cufhe_amd_set_gpu_num(0) < 0
+    assert lib.cufhe_amd_set_gpu_num(65) < 0 and b"64 logical devices" in lib.cufhe_amd_last_error()
     # a gate before Initialize(ek) / on a bad device index fails with a status
     assert lib.cufhe_amd_gate(5, None, 0, 0, None, None, None, None) < 0
     with pytest.raises(cufhe_amd.CufheAmdError):
