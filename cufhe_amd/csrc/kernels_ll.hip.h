@@ -7,13 +7,17 @@
 // pointwise -> inverse NTT -> accumulate".
 //
 //   waves 0-11   (row, h) = (w / 2, w % 2): digit row `row` of the step, half h of its transform:
-//                decompose, first stage u_h = a[e] +- I a[e + 512] (exact), 512-point forward
-//                transform, 16 products against the two key polynomials of the row, ds_add_f64
-//                into the sums -- three such waves per SIMD
+//                first stage u_h = a[e] +- I a[e + 512] (exact) on the digits the inverse waves left
+//                in LDS, 512-point forward transform, 16 products against the two key polynomials of
+//                the row, ds_add_f64 into the sums -- three such waves per SIMD
 //   waves 12-15  (out, h): inverse 512-point transform of half h of sum `out` -- one per SIMD;
 //                the halves meet in LDS for the last stage (u0 + u1, (u0 - u1) I^-1), then the
-//                centred lift into the accumulator
-// Three workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
+//                centred lift into the accumulator; then, with the new accumulator words of their 512
+//                coefficients still in registers, the gadget decomposition of the NEXT step for those
+//                coefficients, all l digits, packed eight to a 64-bit word per lane (each row wave used to
+//                recompute the decomposed word of its coefficients: six times the same arithmetic, on the
+//                waves that set the length of the step)
+// Four workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
 #pragma once
 #include "kernels.hip.h"
 #include "ntt_wave512.h"
@@ -27,8 +31,10 @@ constexpr int kLlLdsTiles = kLlLdsTables + 2 * kLds512TableBytes;             //
 constexpr int kLlLdsAcc = kLlLdsTiles + 16 * kTile512Bytes;                   // + 72704
 constexpr int kLlLdsSum = kLlLdsAcc + 2 * 2 * kN * 4;                         // + 16384   [j][copy][N] u32
 constexpr int kLlLdsHand = kLlLdsSum + 2 * kN * 8;                            // + 16384   [out][h][c][lane] f64
-constexpr int kLlLdsAbar = kLlLdsHand + 2 * kN * 8;                           // + 16384   [out][h][e] f64
-constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 139280
+constexpr int kLlLdsDig = kLlLdsHand + 2 * kN * 8;                            // + 16384   [out][h][e] f64
+constexpr int kLlLdsAbar = kLlLdsDig + kBkRows * 2 * 64 * 8;                  // + 6144    [row][h][lane] 8 digits x i8
+constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 145424
+static_assert(kBgbit <= 8, "digits are packed as signed bytes");
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     }
     __syncthreads();
 
+    uint2* digL = (uint2*)(smem + kLlLdsDig);                 // [row][h][lane]
     const bool row_wave = wave < kLlRowWaves;
     const int h = wave & 1;                                   // half transform of this wave (both roles)
     const int row = wave >> 1;                                // row waves: TRGSW row = wj * l + wd
@@ -90,35 +97,59 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
     };
     if (row_wave && steps > 0) load_row(0);
+    // inverse wave (out, h): digits of (X^abar - 1) acc_out at its coefficients e + 512 h, e = lane + 64 r, for the CMux
+    // step `step`; w[r] = the accumulator word at that coefficient (include/gatebootstrapping_gpu.cuh:157-181)
+    auto decompose = [&](int step, const uint32_t (&w)[kRegs8]) {
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[step]);
+        const int alo = (int)(abar & (kN - 1));
+        const bool ahi = (abar >> kNbit) != 0;
+        const char* rbase = (const char*)(accL + out * 2 * kN) + opaque(4 * ((lane + h * kH - alo) & (kN - 1)));
+        uint32_t rot[kRegs8];
+#pragma unroll
+        for (int r = 0; r < kRegs8; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);
+        uint32_t lo[kL], hi[kL];
+#pragma unroll
+        for (int dg = 0; dg < kL; dg++) { lo[dg] = 0; hi[dg] = 0; }
+#pragma unroll
+        for (int r = 0; r < kRegs8; r++) {
+            const bool neg = (lane + 64 * r + h * kH < alo) != ahi;
+            const uint32_t t = ((neg ? 0u - rot[r] : rot[r]) - w[r] + decomp_offset()) ^ decomp_signmask();
+#pragma unroll
+            for (int dg = 0; dg < kL; dg++) {
+                const uint32_t b = (uint32_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit) & 0xffu;
+                if (r < 4) lo[dg] |= b << (8 * r);
+                else hi[dg] |= b << (8 * (r - 4));
+            }
+        }
+#pragma unroll
+        for (int dg = 0; dg < kL; dg++) digL[((out * kL + dg) * 2 + h) * 64 + lane] = make_uint2(lo[dg], hi[dg]);
+    };
+    if (!row_wave && steps > 0) {
+        uint32_t w[kRegs8];
+#pragma unroll
+        for (int r = 0; r < kRegs8; r++) w[r] = accL[out * 2 * kN + h * kH + lane + 64 * r];
+        decompose(0, w);
+    }
+    __syncthreads();
 
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     // timing-only: cycles this wave spends in each phase of a step (phase = work up to the next barrier, then the barrier)
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
 #define CUFHE_AMD_PHASE(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
 #else
 #define CUFHE_AMD_PHASE(k)
 #endif
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
-        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
         if (row_wave) {
-            const char* accj = (const char*)(accL + wj * 2 * kN);
-            const int alo = (int)(abar & (kN - 1));
-            const bool ahi = (abar >> kNbit) != 0;
-            const char* rbase = accj + opaque(4 * ((lane - alo) & (kN - 1)));
-            const char* cbase = accj + opaque(4 * lane);
-            const uint32_t pos = 32 - (wd + 1) * kBgbit;
+            // digits of this row at e = lane + 64 r (word 0) and e + 512 (word 1), a signed byte each, left by the
+            // inverse waves (out = wj); then the first stage of the transform
+            const uint2 q0 = digL[(row * 2 + 0) * 64 + lane], q1 = digL[(row * 2 + 1) * 64 + lane];
             double x[kRegs8];
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) {
-                // digits at e = lane + 64 r and e + 512, then the first stage of the transform
-                const uint32_t rot0 = *(const uint32_t*)(rbase + 256 * r), rot1 = *(const uint32_t*)(rbase + 256 * (r + 8));
-                const uint32_t cur0 = *(const uint32_t*)(cbase + 256 * r), cur1 = *(const uint32_t*)(cbase + 256 * (r + 8));
-                const bool neg0 = (lane < alo - 64 * r) != ahi, neg1 = (lane < alo - 64 * (r + 8)) != ahi;
-                const uint32_t t0 = ((neg0 ? 0u - rot0 : rot0) - cur0 + decomp_offset()) ^ decomp_signmask();
-                const uint32_t t1 = ((neg1 ? 0u - rot1 : rot1) - cur1 + decomp_offset()) ^ decomp_signmask();
-                const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(t0, pos, (uint32_t)kBgbit);
-                const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(t1, pos, (uint32_t)kBgbit);
+                const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(r < 4 ? q0.x : q0.y, 8u * (r & 3), 8u);
+                const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(r < 4 ? q1.x : q1.y, 8u * (r & 3), 8u);
                 x[r] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);       // exact: |I a| < 2^30
             }
             ntt512_forward(x, ctx);
@@ -149,6 +180,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         CUFHE_AMD_PHASE(2)
         __syncthreads();
         CUFHE_AMD_PHASE(3)
+        uint32_t wnew[kRegs8];
         if (!row_wave) {
             // last inverse stage (u0, u1) -> (u0 + u1, (u0 - u1) I^-1), I^-1 = -I; wave h finishes
             // coefficients e + 512 h
@@ -161,17 +193,22 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
                 const uint32_t w = *(const uint32_t*)(acck + 256 * r) + fpf::lift_u32_small(y);
                 *(uint32_t*)(acck + 256 * r) = w;
                 *(uint32_t*)(acck + 256 * r + 4096) = w;
+                wnew[r] = w;
             }
         }
         CUFHE_AMD_PHASE(4)
         __syncthreads();
         CUFHE_AMD_PHASE(5)
+        if (!row_wave && i + 1 < steps) decompose(i + 1, wnew);     // reads the other half's new words: after the barrier
+        CUFHE_AMD_PHASE(6)
+        __syncthreads();
+        CUFHE_AMD_PHASE(7)
     }
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     if (acc_dump && lane == 0 && g == 0) {
         __syncthreads();
         unsigned long long* o = (unsigned long long*)acc_dump + 16 + wave * 8;      // overwrites part of the dump: timing only
-        for (int k = 0; k < 6; k++) o[k] = ph[k];
+        for (int k = 0; k < 8; k++) o[k] = ph[k];
     }
 #endif
 
