@@ -324,7 +324,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
                            s.bk_ntt, s.tables, steps, dump, active);
     };
     // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
-    //   low-latency kernel  3.3 (n <= 64), 3.9 / 7.0 / 10.4 / 13.8 / 17.3 per started round of 256 (key switch included)
+    //   low-latency kernel  3.1 (n <= 64), 3.6 / 6.7 / 10.0 / 13.3 / 16.6 per started round of 256 (key switch included)
     //   one rotation per SIMD 12.7 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
     // so: low-latency up to 768, one-per-SIMD for 769..1024, both for 1025..1280, a full round above.
     const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
@@ -335,8 +335,8 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     };
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
         if (auto_ll && auto_half && n > 1024 && n <= 1280) {
-            // 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.4): 15.6 ms against
-            // 17.3 for five rounds of the low-latency kernel and 20 for a full round
+            // 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.2): 15.5 ms against
+            // 16.6 for five rounds of the low-latency kernel and 20 for a full round
             launch_batch(dd, 1024, kBrWavesPerBlock / 2, dump);
             launch_ll(dd + 1024, n - 1024, dump ? dump + (size_t)1024 * 2 * kN : nullptr);
             return;

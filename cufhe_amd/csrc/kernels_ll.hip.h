@@ -10,13 +10,13 @@
 //                first stage u_h = a[e] +- I a[e + 512] (exact) on the digits the inverse waves left
 //                in LDS, 512-point forward transform, 16 products against the two key polynomials of
 //                the row, ds_add_f64 into the sums -- three such waves per SIMD
-//   waves 12-15  (out, h): inverse 512-point transform of half h of sum `out` -- one per SIMD;
-//                the halves meet in LDS for the last stage (u0 + u1, (u0 - u1) I^-1), then the
-//                centred lift into the accumulator; then, with the new accumulator words of their 512
-//                coefficients still in registers, the gadget decomposition of the NEXT step for those
-//                coefficients, all l digits, packed eight to a 64-bit word per lane (each row wave used to
-//                recompute the decomposed word of its coefficients: six times the same arithmetic, on the
-//                waves that set the length of the step)
+//   waves 12-15  (out, h): inverse 512-point transform of half h of sum `out` -- one per SIMD -- left in LDS
+//   all 16 waves the coefficient-wise tail of the step, 128 coefficients (two slices of 64) each: the last
+//                inverse stage (u0 + u1, (u0 - u1) I^-1) on the two halves, the centred lift into the
+//                accumulator, and -- after a barrier, the rotated operand comes from other waves' slices --
+//                the gadget decomposition of the NEXT step, all l digits as signed bytes (each row wave
+//                used to recompute the decomposed word of its coefficients: six times the same arithmetic,
+//                on the waves that set the length of the step)
 // Four workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
 #pragma once
 #include "kernels.hip.h"
@@ -97,37 +97,33 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
     };
     if (row_wave && steps > 0) load_row(0);
-    // inverse wave (out, h): digits of (X^abar - 1) acc_out at its coefficients e + 512 h, e = lane + 64 r, for the CMux
-    // step `step`; w[r] = the accumulator word at that coefficient (include/gatebootstrapping_gpu.cuh:157-181)
-    auto decompose = [&](int step, const uint32_t (&w)[kRegs8]) {
+    // The coefficient-wise tail of a step is spread over all 16 waves: wave k owns the slices (out, hh, rr) =
+    // (m, k >> 3, k & 7), m = 0, 1, i.e. coefficients lane + 64 rr + 512 hh of accumulator component m.
+    const int hh = wave >> 3, rr = wave & 7;
+    const int ecoef = lane + 64 * rr + kH * hh;               // this lane's coefficient, both components
+    // digits of (X^abar - 1) acc_m at ecoef for the CMux step `step`, w[m] = acc_m[ecoef]
+    // (include/gatebootstrapping_gpu.cuh:157-181); byte (row, hh, lane, rr) of the digit table
+    auto decompose = [&](int step, const uint32_t (&w)[2]) {
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[step]);
         const int alo = (int)(abar & (kN - 1));
-        const bool ahi = (abar >> kNbit) != 0;
-        const char* rbase = (const char*)(accL + out * 2 * kN) + opaque(4 * ((lane + h * kH - alo) & (kN - 1)));
-        uint32_t rot[kRegs8];
+        const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
+        const int ridx = (ecoef - alo) & (kN - 1);
+        uint32_t rot[2];
 #pragma unroll
-        for (int r = 0; r < kRegs8; r++) rot[r] = *(const uint32_t*)(rbase + 256 * r);
-        uint32_t lo[kL], hi[kL];
+        for (int m = 0; m < 2; m++) rot[m] = accL[m * 2 * kN + ridx];
+        uint8_t* dst = (uint8_t*)digL + (hh * 64 + lane) * 8 + rr;
 #pragma unroll
-        for (int dg = 0; dg < kL; dg++) { lo[dg] = 0; hi[dg] = 0; }
+        for (int m = 0; m < 2; m++) {
+            const uint32_t t = ((neg ? 0u - rot[m] : rot[m]) - w[m] + decomp_offset()) ^ decomp_signmask();
 #pragma unroll
-        for (int r = 0; r < kRegs8; r++) {
-            const bool neg = (lane + 64 * r + h * kH < alo) != ahi;
-            const uint32_t t = ((neg ? 0u - rot[r] : rot[r]) - w[r] + decomp_offset()) ^ decomp_signmask();
-#pragma unroll
-            for (int dg = 0; dg < kL; dg++) {
-                const uint32_t b = (uint32_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit) & 0xffu;
-                if (r < 4) lo[dg] |= b << (8 * r);
-                else hi[dg] |= b << (8 * (r - 4));
-            }
+            for (int dg = 0; dg < kL; dg++)
+                dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
         }
-#pragma unroll
-        for (int dg = 0; dg < kL; dg++) digL[((out * kL + dg) * 2 + h) * 64 + lane] = make_uint2(lo[dg], hi[dg]);
     };
-    if (!row_wave && steps > 0) {
-        uint32_t w[kRegs8];
+    if (steps > 0) {
+        uint32_t w[2];
 #pragma unroll
-        for (int r = 0; r < kRegs8; r++) w[r] = accL[out * 2 * kN + h * kH + lane + 64 * r];
+        for (int m = 0; m < 2; m++) w[m] = accL[m * 2 * kN + ecoef];
         decompose(0, w);
     }
     __syncthreads();
@@ -180,26 +176,31 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         CUFHE_AMD_PHASE(2)
         __syncthreads();
         CUFHE_AMD_PHASE(3)
-        uint32_t wnew[kRegs8];
-        if (!row_wave) {
-            // last inverse stage (u0, u1) -> (u0 + u1, (u0 - u1) I^-1), I^-1 = -I; wave h finishes
-            // coefficients e + 512 h
-            const double* other = handL + out * kN + (h ^ 1) * kH + lane;
-            char* acck = (char*)(accL + out * 2 * kN + h * kH) + opaque(4 * lane);
+        uint32_t wnew[2];
+        {
+            // last inverse stage (u0, u1) -> (u0 + u1, (u0 - u1) I^-1), I^-1 = -I, for coefficient lane + 64 rr of half hh
+            // of both components, then the centred lift into the accumulator (both copies)
+            const double* hd = handL + rr * 64 + lane;
+            double u0[2], u1[2];
+            uint32_t old[2];
 #pragma unroll
-            for (int r = 0; r < kRegs8; r++) {
-                const double v = other[r * 64];
-                const double y = h ? fpf::mulmod(v - u[r], -fpf::ROOT4) : u[r] + v;
-                const uint32_t w = *(const uint32_t*)(acck + 256 * r) + fpf::lift_u32_small(y);
-                *(uint32_t*)(acck + 256 * r) = w;
-                *(uint32_t*)(acck + 256 * r + 4096) = w;
-                wnew[r] = w;
+            for (int m = 0; m < 2; m++) {
+                u0[m] = hd[m * kN];
+                u1[m] = hd[m * kN + kH];
+                old[m] = accL[m * 2 * kN + ecoef];
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const double y = hh ? fpf::mulmod(u0[m] - u1[m], -fpf::ROOT4) : u0[m] + u1[m];
+                wnew[m] = old[m] + fpf::lift_u32_small(y);
+                accL[m * 2 * kN + ecoef] = wnew[m];
+                accL[m * 2 * kN + kN + ecoef] = wnew[m];
             }
         }
         CUFHE_AMD_PHASE(4)
         __syncthreads();
         CUFHE_AMD_PHASE(5)
-        if (!row_wave && i + 1 < steps) decompose(i + 1, wnew);     // reads the other half's new words: after the barrier
+        if (i + 1 < steps) decompose(i + 1, wnew);            // reads other waves' new words: after the barrier
         CUFHE_AMD_PHASE(6)
         __syncthreads();
         CUFHE_AMD_PHASE(7)

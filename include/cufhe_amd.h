@@ -180,8 +180,8 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * Launch shape of the blind rotation (all variants produce identical words).  A launch is cut into whole
  * rounds of the batch kernel's grid (2048 rotations: two per SIMD, highest throughput) plus a tail, and the
  * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: the 16-wave
- * workgroup-per-rotation kernel with split transforms (lowest latency: 3.3 ms for up to 64 rotations,
- * 3.9 / 7.0 / 10.4 ms for up to 256 / 512 / 768), the batch kernel with one rotation per SIMD (12.7 ms for
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 3.1 ms for up to 64 rotations,
+ * 3.6 / 6.7 / 10.0 ms for up to 256 / 512 / 768), the batch kernel with one rotation per SIMD (12.7 ms for
  * up to 1024), both for 1025..1280 (16.6 ms), or a full round (20.7 ms).  "ll_threshold" / "half_threshold" (default -1 = by cost) force
  * the first / second of these up to the given count, "wg_threshold" (default 0) the older 8-wave
  * workgroup-per-rotation kernel, "tail_split" 0 launches everything above 2048 as one grid.
