@@ -50,7 +50,7 @@ class PsParams(ctypes.Structure):
 class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
-                                               "cross_stream_waits", "record_ns", "retire_ns", "launch_ns")]
+                                               "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames")]
 
 
 # every symbol include/cufhe_amd.h declares, with its signature

@@ -1048,6 +1048,13 @@ int cufhe_amd_set_option(const char* key, long value)
             }
         return 0;
     }
+    if (!strcmp(key, "sched_rename")) {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        g_sched_rename = value != 0;
+        if (g_scheduler)
+            for (int d = 0; d < g_scheduler->gpu_num(); d++) g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
+        return 0;
+    }
     if (!strcmp(key, "share_devices")) { g_share_devices = value; g_phys_count = cufhe_amd_device_count(); return 0; }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }

@@ -136,6 +136,7 @@ struct Stats {
     uint64_t forced_syncs = 0;        // a stale `tlwehost` had to be waited for (see resolve_host)
     uint64_t max_level_gates = 0;
     uint64_t cross_stream_waits = 0;
+    uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
     std::atomic<uint64_t> launch_ns{0};
@@ -145,7 +146,7 @@ struct Stats {
     {
         gates = o.gates; groups = o.groups; levels = o.levels; launch_sequences = o.launch_sequences;
         uploads = o.uploads; uploads_shared = o.uploads_shared; downloads = o.downloads; forced_syncs = o.forced_syncs;
-        max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits;
+        max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits; renames = o.renames;
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
         return *this;
@@ -281,10 +282,27 @@ class DeviceSched {
 
     size_t level_flush_gates = 2048;   // a level this full is launched at once (one round of the blind-rotate grid)
     size_t total_flush_gates = 32768;  // bound on the recorded program
+    // Renaming: an output whose device buffer still has recorded users (an earlier write not yet superseded, readers of
+    // the old value) takes a FRESH buffer instead of waiting for them, so that only true data dependences order the
+    // program (a temporary re-used down a ripple-carry chain no longer serialises the adders' independent gates).  The
+    // old buffer is recycled once the last level naming it has retired.  The device pointer of a ciphertext
+    // (cufhe_amd_ctxt_device_ptr, Ctxt::tlwedevices) is then no longer constant: off unless asked for.
+    bool rename_outputs = false;
 
    private:
     struct StreamState { uint32_t max_depth = 0; std::vector<uint64_t> open; };
     struct Buf { void* p; size_t cap; };
+    struct RetiredBuf { uint32_t* p; int level; uint32_t last_use; };      // renamed-away buffers still named by recorded levels
+    std::vector<RetiredBuf> retired_;
+    void collect_retired()
+    {
+        size_t k = 0;
+        for (const RetiredBuf& r : retired_) {
+            if (done(r.last_use)) slot_free(r.level, r.p);
+            else retired_[k++] = r;
+        }
+        retired_.resize(k);
+    }
 
     int fail(int rc, const std::string& what)
     {
@@ -692,12 +710,18 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     for (int i = 0; i < 3; i++)
         if (need_up[i]) record_upload(ins[i], stream);
 
-    uint32_t D = base_depth_;
+    uint32_t Din = base_depth_;       // the true data dependences: every input has been produced
     for (int i = 0; i < 3; i++)
-        if (ins[i]) D = std::max(D, ins[i]->d[device_].ready);
+        if (ins[i]) Din = std::max(Din, ins[i]->d[device_].ready);
     cufhe_amd_ctxt::PerDev& po = out->d[device_];
-    D = std::max(D, po.ready);
+    uint32_t D = std::max(Din, po.ready);                             // write after write
     if (has_readers(po)) D = std::max(D, max_reader(po) + 1);         // write after read
+    // operand buffers as of now: an in-place gate reads the buffer its output may be about to leave
+    const uint32_t* const in_dev[3] = {ins[0]->d[device_].dev, ins[1] ? ins[1]->d[device_].dev : nullptr,
+                                       ins[2] ? ins[2]->d[device_].dev : nullptr};
+    uint32_t* fresh = nullptr;
+    if (rename_outputs && D > Din && slot_alloc(out->level, &fresh) == 0) D = Din;
+    else fresh = nullptr;
 
     Plan& p = plan_at(D);
     for (int i = 0; i < 3; i++) {
@@ -706,10 +730,19 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
         add_dep(p, pd.wdepth);
         use(pd, D);
     }
-    add_dep(p, po.wdepth);
-    for_readers(po, [&](uint32_t r) { add_dep(p, r); });
+    if (!fresh) {
+        add_dep(p, po.wdepth);
+        for_readers(po, [&](uint32_t r) { add_dep(p, r); });
+    }
     for (int i = 0; i < 3; i++)
         if (ins[i]) add_reader(ins[i]->d[device_], D);
+    if (fresh) {
+        // the old buffer keeps serving the levels that name it (this gate included, if it is in place)
+        retired_.push_back({po.dev, out->level, po.last_use});
+        po.dev = fresh;
+        po.last_use = 0;
+        stats_.renames++;
+    }
     // the write: in-place gates are safe, every kernel reads its operands before it writes
     po.version++;
     po.wdepth = D;
@@ -719,9 +752,7 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     po.snap_plan = nullptr;
     po.snap_owned = false;
     use(po, D);
-    p.gates[kind].push_back(GateRef{op, po.dev, ins[0]->d[device_].dev,
-                                          ins[1] ? ins[1]->d[device_].dev : nullptr,
-                                          ins[2] ? ins[2]->d[device_].dev : nullptr});
+    p.gates[kind].push_back(GateRef{op, po.dev, in_dev[0], in_dev[1], in_dev[2]});
     if (copying) {
         const size_t slot = p.out_words;
         p.out_words += (size_t)be_->words(out->level);
@@ -771,7 +802,18 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
 
 inline int DeviceSched::after_record()
 {
-    if (!levels_.empty() && levels_.front()->gate_count() >= level_flush_gates) return flush(1);
+    // A full front level is launched at once when the program behind it is flat or as wide as it is: the launch then
+    // overlaps the recording and the copies of the next one.  When the levels behind it are narrow (the carry chains of
+    // adders whose independent gates fill the front level) launching it would move the front, and the chains recorded
+    // afterwards would sit one level later than their siblings: every chain level would then be a mix of all bit
+    // positions and cost a started round more (measured: 310 ms against 251 for 256 sixteen-bit adders).  Such a front
+    // level waits for the caller's Synchronize, up to eight rounds.
+    if (!levels_.empty()) {
+        const size_t front = levels_.front()->gate_count();
+        if (front >= level_flush_gates &&
+            (levels_.size() == 1 || 2 * levels_[1]->gate_count() >= level_flush_gates || front >= 8 * level_flush_gates))
+            return flush(1);
+    }
     if (pending_gates_ >= total_flush_gates) return flush();
     return 0;
 }
@@ -976,6 +1018,7 @@ inline int DeviceSched::retire(Group* g)
         live_.pop_front();
     }
     owner_->collect_zombies();
+    collect_retired();
     return rc;
 }
 

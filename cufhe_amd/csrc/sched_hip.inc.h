@@ -14,6 +14,7 @@ long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
 long g_sched_level_gates = 2048; // a dependence level this full is launched at once
 long g_sched_total_gates = 32768;
+long g_sched_rename = 0;          // 1: outputs take fresh device buffers instead of waiting for the old one's users (sched_core.h)
 
 class HipBackend : public sched::Backend {
    public:
@@ -175,6 +176,7 @@ sched::Scheduler* scheduler()
         for (int d = 0; d < g_gpu_num; d++) {
             g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
             g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
+            g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
         }
     }
     return g_scheduler;
@@ -357,6 +359,7 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->uploads = s.uploads; out->uploads_shared = s.uploads_shared; out->downloads = s.downloads;
     out->forced_syncs = s.forced_syncs; out->max_level_gates = s.max_level_gates; out->cross_stream_waits = s.cross_stream_waits;
     out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
+    out->renames = s.renames;
     if (reset) s = sched::Stats();
     return 0;
 }

@@ -136,6 +136,7 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t cross_stream_waits; /* event dependences between flushes on different internal streams */
     uint64_t record_ns, retire_ns;  /* host time on the issuing thread: recording gates, delivering results */
     uint64_t launch_ns;             /* host time on the device's launch worker */
+    uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 
@@ -204,6 +205,12 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * "sched_streams" (default 4): internal HIP streams per device over which independent flushes of the
  * per-gate API overlap; "sched_threads" (default 1): one launch worker thread per device (0: launches
  * happen on the issuing thread).  Both before the first ciphertext is created.
+ * "sched_rename" (default 0): 1 = an output whose device buffer still has recorded users (an earlier write,
+ * readers of the old value) takes a fresh buffer instead of being ordered after them, so that only true data
+ * dependences order a recorded program: a temporary re-used down a ripple-carry chain no longer serialises the
+ * independent gates of the adders (16-bit adders: 64 dependence levels become 33).  The pointer returned by
+ * cufhe_amd_ctxt_device_ptr (Ctxt::tlwedevices in the C++ shim) is then only valid until the ciphertext is next
+ * written; results, tlwehost and every API call behave the same.
  * "sched_level_gates" (default 2048) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program. */
 int cufhe_amd_set_option(const char* key, long value);

@@ -163,7 +163,7 @@ struct Ctxt {
     Ctxt& operator=(const Ctxt&) = delete;
 
     alignas(64) TFHEpp::TLWE<P> tlwehost;
-    std::vector<typename P::T*> tlwedevices;
+    std::vector<typename P::T*> tlwedevices;   // as of construction; with "sched_rename" on ask cufhe_amd_ctxt_device_ptr(handle, i)
     cufhe_amd_ctxt* handle = nullptr;
 };
 

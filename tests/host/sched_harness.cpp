@@ -152,6 +152,8 @@ struct ModelCtxt {
     std::vector<bool> dev_defined;
 };
 
+static bool g_rename = false;      // argv[4]: outputs take fresh device buffers instead of waiting (DeviceSched::rename_outputs)
+
 struct Test {
     int G;
     Scheduler* S;
@@ -168,6 +170,7 @@ struct Test {
             be.push_back(b);
             return b;
         });
+        for (int d = 0; d < gpus; d++) S->dev(d).rename_outputs = g_rename;
     }
     ~Test()
     {
@@ -490,6 +493,7 @@ int main(int argc, char** argv)
     const int seeds = argc > 1 ? atoi(argv[1]) : 50;
     const int gpus = argc > 2 ? atoi(argv[2]) : 2;
     const bool threaded = argc > 3 ? atoi(argv[3]) != 0 : true;
+    g_rename = argc > 4 ? atoi(argv[4]) != 0 : false;
     int failures = 0;
     for (int s = 1; s <= seeds; s++) {
         const int f = random_program(1000 + s, 1 + (s % gpus), threaded);

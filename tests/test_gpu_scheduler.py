@@ -100,9 +100,21 @@ def test_chained_program_levels_and_words(engine, keys):
         s.Destroy()
 
 
-def test_ripple_adders_levels_and_words(engine, keys):
+@pytest.mark.parametrize("rename", [0, 1])
+def test_ripple_adders_levels_and_words(engine, keys, rename):
     """16 8-bit ripple-carry adders issued bit by bit, one stream each (640 dependent gates,
-    tests/cpp/test_gate_api.cpp RippleAdders): <= 40 launch sequences, sums == oracle words."""
+    tests/cpp/test_gate_api.cpp RippleAdders): <= 40 launch sequences, sums == oracle words.  With "sched_rename" the
+    re-used temporaries stop ordering the program (t1 is overwritten while its readers are still on record: it takes a
+    fresh device buffer) and only the carry chain is left: two levels per bit."""
+    api = engine.api
+    api.set_option("sched_rename", rename)
+    try:
+        _ripple_adders(engine, keys, rename)
+    finally:
+        api.set_option("sched_rename", 0)
+
+
+def _ripple_adders(engine, keys, rename):
     api = engine.api
     A, B = 16, 8
     rng = np.random.default_rng(72)
@@ -130,7 +142,8 @@ def test_ripple_adders_levels_and_words(engine, keys):
     api.Synchronize()
     stats = api.sched_stats()
     assert stats.gates == 5 * A * B
-    assert stats.launch_sequences <= 40, f"{stats.launch_sequences} launch sequences"
+    assert stats.launch_sequences <= (2 * B + 2 if rename else 40), f"{stats.launch_sequences} launch sequences"
+    assert (stats.renames > 0) == bool(rename)
     # the same program on the oracle, bit by bit (batched over the adders)
     ex, ey = ex.reshape(A, B, -1), ey.reshape(A, B, -1)
     wc = ecarry

@@ -27,8 +27,8 @@ def harness():
     return EXE
 
 
-def _run(exe, seeds, gpus, threaded):
-    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded)], capture_output=True, text=True, timeout=900)
+def _run(exe, seeds, gpus, threaded, rename=0):
+    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded), str(rename)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     return {s["name"]: s for s in (json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("SHAPE "))}
 
@@ -46,12 +46,22 @@ def test_random_programs_match_in_order_semantics(harness, threaded):
     assert shapes["multi_gpu"]["gates"] == 192
 
 
+def test_random_programs_with_output_renaming(harness):
+    """DeviceSched::rename_outputs ("sched_rename"): outputs take fresh device buffers instead of waiting for the users of
+    the old one.  Same in-order semantics on the random programs (1-3 devices, worker threads); the ripple-carry adders,
+    whose temporaries are re-used bit after bit, drop from 4 levels per bit to 2."""
+    shapes = _run(harness, 120, 3, 1, rename=1)
+    assert shapes["ripple_adders"]["gates"] == 640 and shapes["ripple_adders"]["launch_sequences"] <= 18
+    assert shapes["chained"]["launch_sequences"] <= 6 and shapes["intensive"]["launch_sequences"] <= 8
+
+
 def test_sanitizers(harness, tmp_path):
     """The same run under AddressSanitizer + UBSan (CPU build only), worker threads on."""
     exe = str(tmp_path / "sched_harness_asan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=all", "-o", exe, SRC])
     _run(exe, 25, 3, 1)
+    _run(exe, 25, 3, 1, rename=1)
 
 
 def test_thread_sanitizer(harness, tmp_path):

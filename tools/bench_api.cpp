@@ -75,8 +75,11 @@ int main(int argc, char** argv)
                 (unsigned long long)ss.launch_sequences);
     // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
     // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
-    // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders.
-    {
+    // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders; once as the reference's
+    // buffers dictate (the temporaries t1, t2 re-used bit after bit order the program) and once with "sched_rename"
+    // (outputs take fresh device buffers: only the carry chain is left).
+    for (int rename = 0; rename < 2; rename++) {
+        CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", rename));
         const int kAdders = 256, kBits = 16;
         std::vector<Ctxt<P>> x(kAdders * kBits), y(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);
         for (auto* v : {&x, &y})
@@ -104,11 +107,13 @@ int main(int argc, char** argv)
             best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             all_stats(ns, 0);
         }
-        std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"gates\": %llu, \"total_ms\": %.2f, "
-                    "\"gates_per_s\": %.0f, \"dependence_levels\": %llu, \"launch_sequences\": %llu, \"max_level_gates\": %llu}\n",
-                    (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
+        std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"sched_rename\": %d, \"gates\": %llu, "
+                    "\"total_ms\": %.2f, \"gates_per_s\": %.0f, \"dependence_levels\": %llu, \"launch_sequences\": %llu, "
+                    "\"max_level_gates\": %llu}\n",
+                    rename, (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
                     (unsigned long long)ns.launch_sequences, (unsigned long long)ns.max_level_gates);
     }
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 0));
     for (auto& s : st) s.Destroy();
     CleanUp();
     return 0;
