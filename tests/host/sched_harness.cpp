@@ -71,9 +71,12 @@ class FakeBackend : public Backend {
     }
     int run_gates(int s, int level, const GateRef* g, size_t n) override
     {
-        launches++;
         std::vector<GateRef> v(g, g + n);
-        std::shuffle(v.begin(), v.end(), rng_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);      // the launch worker and the issuing thread (event_query) share rng_
+            launches++;
+            std::shuffle(v.begin(), v.end(), rng_);
+        }
         push(s, [=] {
             for (const GateRef& r : v) toy_gate(r.op, level, r.out, r.in0, r.in1, r.in2);
         });

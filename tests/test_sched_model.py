@@ -68,6 +68,7 @@ def test_thread_sanitizer(harness, tmp_path):
     """The issuing thread against the per-device launch workers under ThreadSanitizer (CPU build only)."""
     exe = str(tmp_path / "sched_harness_tsan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe, SRC])
-    out = subprocess.run([exe, "12", "3", "1"], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "ThreadSanitizer" not in out.stderr, out.stderr[:4000]
+    for rename in ("0", "1"):
+        out = subprocess.run([exe, "12", "3", "1", rename], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        assert "ThreadSanitizer" not in out.stderr, out.stderr[:4000]
