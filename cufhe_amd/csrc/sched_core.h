@@ -273,6 +273,7 @@ class DeviceSched {
         for (void* s : slabs_) be_->free_device(s);
         slabs_.clear();
         for (auto& f : free_slots_) f.clear();
+        retired_.clear();
     }
 
     // one slot per ciphertext, carved from slabs (the reference pays a cudaMalloc per Ctxt per GPU,
