@@ -377,13 +377,16 @@ def test_per_gate_api_error_paths(engine, keys):
     st.Destroy()
 
 
-def test_random_program_matches_in_order_oracle(engine, keys, oracle):
-    """A seeded random program through the per-gate API on the real device -- copying gates and g-gates of both levels,
+@pytest.mark.parametrize("rename", [0, 1])
+def test_random_program_matches_in_order_oracle(engine, keys, oracle, rename):
+    """(rename: the same with "sched_rename", outputs taking fresh device buffers.)
+    A seeded random program through the per-gate API on the real device -- copying gates and g-gates of both levels,
     in-place outputs, shared inputs, explicit copies, Flush, StreamQuery polls -- against an in-order interpreter whose
     gates are the CPU oracle's: every tlwehost must hold the oracle's words at the end (the CPU twin of this test,
     with a stubbed device, is tests/test_sched_model.py)."""
     api = engine.api
-    rng = np.random.default_rng(2025)
+    api.set_option("sched_rename", rename)
+    rng = np.random.default_rng(2025 + rename)
     nct = 14
     cts = {0: [api.Ctxt(0) for _ in range(nct)], 1: [api.Ctxt(1) for _ in range(nct // 2)]}
     host = {}     # model: the eventual tlwehost of every ciphertext
@@ -459,6 +462,7 @@ def test_random_program_matches_in_order_oracle(engine, keys, oracle):
         else:
             api.Flush(0)
     api.Synchronize()
+    api.set_option("sched_rename", 0)
     for lvl, lst in cts.items():
         for i, c in enumerate(lst):
             assert np.array_equal(c.tlwehost, host[id(c)]), f"level {lvl} ciphertext {i}"
