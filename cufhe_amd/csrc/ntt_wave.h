@@ -63,6 +63,21 @@ constexpr double forward_digit_spectrum_bound(double digit_max)
     if (b >= fpf::LIM_WIDE) return -1.0;                      // stage 9: mulmod_wide
     return b + fpf::after_mulmod_wide(b);
 }
+// The same for ntt_forward<SMALL_IN = false> (any 32-bit words in: every stage reduces, stages 8 and 9 wide): 8.92
+constexpr double forward_words_spectrum_bound()
+{
+    double b = 4294967296.0 / fpf::P;
+    for (int s = 0; s <= 7; s++) {
+        if (b >= fpf::LIM_NARROW) return -1.0;
+        b = b + fpf::after_mulmod(b);
+    }
+    for (int s = 8; s <= 9; s++) {
+        if (b >= fpf::LIM_WIDE) return -1.0;
+        b = b + fpf::after_mulmod_wide(b);
+    }
+    return b;
+}
+static_assert(forward_words_spectrum_bound() > 0 && forward_words_spectrum_bound() < fpf::LIM_WIDE, "forward NTT schedule (32-bit words in)");
 // `rows` wide products of a spectrum bounded by s accumulate without reduction
 constexpr bool pointwise_sum_fits(double s, int rows)
 {

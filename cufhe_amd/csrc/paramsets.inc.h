@@ -10,10 +10,45 @@ long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-p
 constexpr long kPsAutoBatch = 600;
 
 struct PsState {
-    bool ready = false, lds_opt_in = false;
+    bool ready = false, lds_opt_in = false, ks_lds_opt_in = false;
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
+    uint32_t* ksk_padded = nullptr;   // sets whose key switch has the default shape: rows padded for keyswitch_kernel
 };
+
+// kN = 1024, n = 630, t = 8, basebit = 2: the hand-scheduled shared-table key switch of kernels.hip.h applies as it is
+template <class PS>
+constexpr bool ps_ks_is_default_shape = PS::k * PsDims<PS>::N == kN && PS::n == kLvl0N && PS::t == kKsT && PS::basebit == kKsBasebit;
+static_assert(PsKs<PsDefault>::row_pad == kKsRowPad, "one padded table serves both shared-table kernels");
+
+template <class PS>
+int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count)
+{
+    if (count == 0) return 0;
+    const long wg_max = g_ks_wg_threshold < 0 ? kKsAutoWg : g_ks_wg_threshold;
+    if ((long)count > wg_max && ps.ksk_padded) {
+        // 16 ciphertexts per workgroup, table rows through LDS
+        const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
+        if constexpr (ps_ks_is_default_shape<PS>) {
+            if (!s.ks_lds_opt_in) {
+                HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
+                s.ks_lds_opt_in = true;
+            }
+            hipLaunchKernelGGL(keyswitch_kernel, dim3(blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, ps.ksk_padded);
+        } else {
+            if (!ps.ks_lds_opt_in) {
+                HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_ps_shared_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsKs<PS>::lds_bytes));
+                ps.ks_lds_opt_in = true;
+            }
+            hipLaunchKernelGGL(keyswitch_ps_shared_kernel<PS>, dim3(blocks), dim3(kKsThreads), PsKs<PS>::lds_bytes, st, d, (int)count, ps.ksk_padded);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, ps.ksk);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 PsState g_ps[kParamSets][kMaxLogicalDevices];
 
 PsState& ps_state(int set, int device) { return g_ps[set][device]; }
@@ -113,10 +148,7 @@ int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
     if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
     if (int rc = upload_descs(s, sc, lin, &dlin)) return rc;
     if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, nullptr)) return rc;
-    if (!ks.empty()) {
-        hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)ks.size()), dim3(kKsThreads), 0, st, dks, (int)ks.size(), ps.ksk);
-        HIP_TRY(hipGetLastError());
-    }
+    if (int rc = ps_launch_keyswitch<PS>(s, ps, st, dks, ks.size())) return rc;
     return launch_lincomb(st, dlin, lin.size(), D::lvl0_words);
 }
 
@@ -133,6 +165,7 @@ void ps_release(int device)
         if (!ps.ready) continue;
         (void)hipFree(ps.bk_ntt);
         (void)hipFree(ps.ksk);
+        if (ps.ksk_padded) (void)hipFree(ps.ksk_padded);
         ps = PsState{};
     }
 }
@@ -179,11 +212,20 @@ int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const 
                 HIP_TRY(hipDeviceSynchronize());
                 HIP_TRY(hipFree(ps.bk_ntt));
                 HIP_TRY(hipFree(ps.ksk));
+                if (ps.ksk_padded) HIP_TRY(hipFree(ps.ksk_padded));
                 ps = PsState{};
             }
             HIP_TRY(hipMalloc((void**)&ps.bk_ntt, (size_t)PS::n * D::bk_ntt_step_doubles * sizeof(double)));
             HIP_TRY(hipMalloc((void**)&ps.ksk, D::ksk_words * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(ps.ksk, ksk, D::ksk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+            {      // the same table with rows padded to a multiple of 64 words, for the shared-table kernels
+                constexpr size_t w0 = D::lvl0_words, pad = PsKs<PS>::row_pad;
+                const size_t ksk_rows = D::ksk_words / w0;
+                HIP_TRY(hipMalloc((void**)&ps.ksk_padded, ksk_rows * pad * sizeof(uint32_t)));
+                HIP_TRY(hipMemset(ps.ksk_padded, 0, ksk_rows * pad * sizeof(uint32_t)));
+                HIP_TRY(hipMemcpy2D(ps.ksk_padded, pad * sizeof(uint32_t), ksk, w0 * sizeof(uint32_t), w0 * sizeof(uint32_t), ksk_rows,
+                                    hipMemcpyHostToDevice));
+            }
             uint32_t* d_bk = nullptr;
             HIP_TRY(hipMalloc((void**)&d_bk, D::bk_words * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(d_bk, bk, D::bk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -252,9 +294,7 @@ int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count
         if (int rc = open_scratch(s, st, count * sizeof(LinDesc) + 4096, &sc)) return rc;
         LinDesc* d;
         if (int rc = upload_descs(s, sc, ks, &d)) return rc;
-        hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, ps.ksk);
-        HIP_TRY(hipGetLastError());
-        return 0;
+        return ps_launch_keyswitch<PS>(s, ps, st, d, count);
     });
 }
 

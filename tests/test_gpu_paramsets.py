@@ -88,16 +88,22 @@ def test_extreme_key_words(engine, pset):
 
 def test_keyswitch_words(engine, pset):
     name, idx, L, K = pset
-    count = 7
+    count = 23
     rng = np.random.default_rng(6)
     t1 = rng.integers(0, 2**32, size=(count, K.words[1]), dtype=np.uint64).astype(np.uint32)
     t1[0] = 0
     t1[1] = 0xFFFFFFFF
     d0 = engine.api.DeviceBuffer(count * K.words[0])
-    engine.api.ps_keyswitch_batch(idx, _up(engine, t1), d0, count)
-    got = d0.download().reshape(count, -1)
-    for g in range(count):
-        assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g}"
+    for thr in (-1, 0):       # 0: sets with the default key-switch shape take the shared-table kernel of kernels.hip.h
+        engine.api.set_option("ks_wg_threshold", thr)
+        try:
+            d0.upload(np.zeros(count * K.words[0], np.uint32))
+            engine.api.ps_keyswitch_batch(idx, _up(engine, t1), d0, count)
+        finally:
+            engine.api.set_option("ks_wg_threshold", -1)
+        got = d0.download().reshape(count, -1)
+        for g in range(count):
+            assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g} (ks_wg_threshold {thr})"
 
 
 def test_every_gate_words_and_truth_table(engine, pset, keys):
