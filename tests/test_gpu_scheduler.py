@@ -6,6 +6,8 @@ Reference programs: test/test_api_gpu.cu:140-159 (chained in-place gates), test/
 and test/test_util.h:29-94 (every gate over many streams), test/test_intensive.cc:21-128 (polling),
 include/cufhe_gpu.cuh:282-313 (g-gates).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -377,16 +379,17 @@ def test_per_gate_api_error_paths(engine, keys):
     st.Destroy()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CUFHE_AMD_STRESS_SEEDS", "1"))))
 @pytest.mark.parametrize("rename", [0, 1])
-def test_random_program_matches_in_order_oracle(engine, keys, oracle, rename):
-    """(rename: the same with "sched_rename", outputs taking fresh device buffers.)
+def test_random_program_matches_in_order_oracle(engine, keys, oracle, rename, seed):
+    """(rename: the same with "sched_rename", outputs taking fresh device buffers; CUFHE_AMD_STRESS_SEEDS=n runs n programs.)
     A seeded random program through the per-gate API on the real device -- copying gates and g-gates of both levels,
     in-place outputs, shared inputs, explicit copies, Flush, StreamQuery polls -- against an in-order interpreter whose
     gates are the CPU oracle's: every tlwehost must hold the oracle's words at the end (the CPU twin of this test,
     with a stubbed device, is tests/test_sched_model.py)."""
     api = engine.api
     api.set_option("sched_rename", rename)
-    rng = np.random.default_rng(2025 + rename)
+    rng = np.random.default_rng(2025 + rename + 1000 * seed)
     nct = 14
     cts = {0: [api.Ctxt(0) for _ in range(nct)], 1: [api.Ctxt(1) for _ in range(nct // 2)]}
     host = {}     # model: the eventual tlwehost of every ciphertext
