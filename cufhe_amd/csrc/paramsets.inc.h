@@ -7,7 +7,9 @@
 namespace {
 
 long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-per-rotation kernel is used (-1: by cost)
-constexpr long kPsAutoBatch = 600;
+// By cost: a round of the wave-per-rotation kernel (up to 2048 rotations) takes about as long as two rounds of 256 of the
+// workgroup-per-rotation kernel for the N = 1024 sets (19.5 / 24 ms against 9.4 / 10.8 per round), three for N = 512 (17 against 5.5).
+template <class PS> constexpr long kPsAutoBatch = PS::Nbit == 9 ? 769 : 513;
 
 struct PsState {
     bool ready = false, lds_opt_in = false, ks_lds_opt_in = false;
@@ -80,7 +82,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_batch_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsbLds<PS>::bytes));
         ps.lds_opt_in = true;
     }
-    if ((long)count >= (g_ps_batch_threshold < 0 ? kPsAutoBatch : g_ps_batch_threshold)) {
+    if ((long)count >= (g_ps_batch_threshold < 0 ? kPsAutoBatch<PS> : g_ps_batch_threshold)) {
         // one wave per rotation, 8 rotations per workgroup share the key rows (throughput shape)
         const unsigned blocks = (unsigned)((count + PsbLds<PS>::waves - 1) / PsbLds<PS>::waves);
         hipLaunchKernelGGL(blind_rotate_ps_batch_kernel<PS>, dim3(blocks), dim3(PsbLds<PS>::threads), PsbLds<PS>::bytes, st, d, (int)count,
