@@ -89,6 +89,7 @@ long g_ks_split_threshold = -1; // key switches per launch up to which each ciph
 //   16 ciphertexts per workgroup, table through LDS: 1.5 - 1.6 whatever n <= 4096 (1024 dependent steps)
 // so: split up to 192, one workgroup per ciphertext up to 1900, the shared-table kernel above.
 constexpr long kKsAutoSplit = 192, kKsAutoWg = 1900;
+long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
@@ -310,6 +311,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLlLdsBytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLl2LdsBytes));
         s.br_lds_opt_in = true;
     }
     // One round of the batch kernel's grid is 256 workgroups x 8 rotations and takes ~19 ms however few of its
@@ -325,18 +327,37 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     };
     // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
     //   low-latency kernel  3.1 (n <= 64), 3.6 / 6.7 / 10.0 / 13.3 / 16.6 per started round of 256 (key switch included)
+    //   its paired form     5.3 - 5.8 per started round of 512 (11.5 for 1024, 17.1 for 1536, 22.9 for 2048)
     //   one rotation per SIMD 12.7 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
-    // so: low-latency up to 768, one-per-SIMD for 769..1024, both for 1025..1280, a full round above.
+    // so: low-latency up to 256, rounds of 512 on the paired kernel (+ a last round of up to 256 on the single one) up
+    // to 1536, a full round of the batch kernel above.  ("ll2_threshold" 0 gives the rules without the paired kernel:
+    // low-latency up to 768, one-per-SIMD for 769..1024, both for 1025..1280.)
     const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
     auto launch_ll = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
         // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
         hipLaunchKernelGGL(blind_rotate_ll_kernel, dim3((unsigned)n), dim3(kLlThreads), kLlLdsBytes, st, dd, (int)n,
                            s.bk_ntt, s.tables512, steps, dump);
     };
+    auto launch_ll2 = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
+        // two rotations per workgroup: the row phase of one beside the inverse transforms of the other (kernels_ll.hip.h)
+        hipLaunchKernelGGL(blind_rotate_ll2_kernel, dim3((unsigned)((n + 1) / 2)), dim3(kLlThreads), kLl2LdsBytes, st, dd, (int)n,
+                           s.bk_ntt, s.tables512, steps, dump);
+    };
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
+        if (g_ll2_threshold > 0 && (long)n <= g_ll2_threshold) {
+            launch_ll2(dd, n, dump);
+            return;
+        }
+        if (g_ll2_threshold < 0 && auto_ll && auto_half && (long)g_wg_threshold == 0 && n > 256 && n <= 1536) {
+            // rounds of 512 on the paired kernel (5.7 ms each) and a last started round of up to 256 on the single one (3.3)
+            const size_t rem = n % 512, paired = (rem == 0 || rem > 256) ? n : n - rem;
+            launch_ll2(dd, paired, dump);
+            if (paired < n) launch_ll(dd + paired, n - paired, dump ? dump + paired * 2 * kN : nullptr);
+            return;
+        }
         if (auto_ll && auto_half && n > 1024 && n <= 1280) {
-            // 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.2): 15.5 ms against
-            // 16.6 for five rounds of the low-latency kernel and 20 for a full round
+            // (without the paired kernel) 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.2):
+            // 15.5 ms against 16.6 for five rounds of the low-latency kernel and 20 for a full round
             launch_batch(dd, 1024, kBrWavesPerBlock / 2, dump);
             launch_ll(dd + 1024, n - 1024, dump ? dump + (size_t)1024 * 2 * kN : nullptr);
             return;
@@ -356,7 +377,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         }
     };
     const size_t tail = count % kRound;
-    const long tail_max = std::max(auto_half ? 1024L : g_half_threshold, std::max(auto_ll ? 1280L : g_ll_threshold, g_wg_threshold));
+    const long tail_max = std::max(auto_half ? 1024L : g_half_threshold, std::max(auto_ll ? (g_ll2_threshold < 0 ? 1536L : 1280L) : g_ll_threshold, g_wg_threshold));
     if (g_tail_split && count > kRound && tail != 0 && (long)tail <= tail_max) {
         const size_t full = count - tail;
         launch_batch(d, full, kBrWavesPerBlock, acc_dump);
@@ -1063,6 +1084,7 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
     if (!strcmp(key, "ps_batch_threshold")) { g_ps_batch_threshold = value; return 0; }
+    if (!strcmp(key, "ll2_threshold")) { g_ll2_threshold = value; return 0; }
     if (!strcmp(key, "lvl0_param_set")) {
         if (value >= 0) {
             cufhe_amd_ps_params p;

@@ -227,6 +227,233 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 }
 
 // ----------------------------------------------------------------------------------
+// Two rotations per workgroup (launches of 257 .. 1280 rotations and their tails): the same waves, the same
+// arithmetic, but while the twelve row waves work on one rotation the four inverse waves transform the sums of the
+// other, and the two rotations share every key row (loaded once into the row waves' registers).
+//   slot 1   row waves: row phase of A, step i          inverse waves: inverse transforms of B, step i-1
+//   tail     all waves: last stage + lift + accumulator of B (i-1), barrier, decomposition of B for step i
+//   slot 2   row waves: row phase of B, step i          inverse waves: inverse transforms of A, step i
+//   tail     all waves: the same for A
+// Six barriers per step for two rotations.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition now
+// computes its rotated index), sums 16 KiB (an inverse wave leaves its half transform where it read its sum), digits
+// 6 KiB, abar list.
+// ----------------------------------------------------------------------------------
+constexpr int kLl2RotBytes = 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8 + kAbarBytes + 16;    // 32032
+constexpr int kLl2LdsRot = kLlLdsTiles + 16 * kTile512Bytes;
+constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes;                                       // 152896
+static_assert(kLl2LdsBytes <= 160 * 1024, "paired low-latency kernel does not fit the CU's LDS");
+
+__global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    struct Rot { uint32_t* acc; double* sum; uint2* dig; uint16_t* abar; uint32_t* bbar; };
+    Rot rot[2];
+    int gidx[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        char* base = smem + kLl2LdsRot + x * kLl2RotBytes;
+        rot[x].acc = (uint32_t*)base;                                        // [j][N]
+        rot[x].sum = (double*)(base + 2 * kN * 4);                           // [out][h][c][lane], then [out][h][e]
+        rot[x].dig = (uint2*)(base + 2 * kN * 4 + 2 * kN * 8);               // [row][h][lane]
+        rot[x].abar = (uint16_t*)(base + 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8);
+        rot[x].bbar = (uint32_t*)((char*)rot[x].abar + kAbarBytes);
+        const int g = 2 * (int)blockIdx.x + x;
+        gidx[x] = g < count ? g : count - 1;             // an odd launch computes its last rotation twice (second copy: no output)
+    }
+    if (2 * (int)blockIdx.x >= count) return;
+    const bool live1 = 2 * (int)blockIdx.x + 1 < count;
+
+    for (int i = tid; i < 2 * kLds512TableDoubles; i += kLlThreads) {     // tb_fwd .. tc_inv are contiguous
+        const int hh = i / kLds512TableDoubles, k = i % kLds512TableDoubles;
+        ((double*)(smem + kLlLdsTables))[i] = gt2[hh].tb_fwd[k];
+    }
+    LinDesc dsc[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        dsc[x] = descs[gidx[x]];
+        for (int i = tid; i <= kLvl0N; i += kLlThreads) {
+            const uint32_t c = (uint32_t)dsc[x].ca * dsc[x].in0[i] + (uint32_t)dsc[x].cb * dsc[x].in1[i];
+            if (i < kLvl0N) rot[x].abar[i] = (uint16_t)((c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit));
+            else *rot[x].bbar = 2 * kN - ((c + dsc[x].off) >> (32 - 1 - kNbit));
+        }
+        for (int i = tid; i < 2 * kN; i += kLlThreads) rot[x].sum[i] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < 2; x++) {   // RotatedTestVector, include/gatebootstrapping_gpu.cuh:29-52
+        const uint32_t bbar = *rot[x].bbar;
+        for (int e = tid; e < kN; e += kLlThreads) {
+            const bool neg = (bbar != 2 * kN) && (((uint32_t)e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
+            rot[x].acc[e] = 0;
+            rot[x].acc[kN + e] = neg ? 0u - kMu : kMu;
+        }
+    }
+    __syncthreads();
+
+    const bool row_wave = wave < kLlRowWaves;
+    const int h = wave & 1;
+    const int row = wave >> 1;
+    const int out = (wave - kLlRowWaves) >> 1;
+    const Wave512Ctx ctx = make_wave512_ctx(smem, kLlLdsTiles + wave * kTile512Bytes,
+                                            kLlLdsTables + h * kLds512TableBytes, gt2 + h, lane);
+    const int key_idx = (4 * ((lane >> 3) & 1)) * 64 + (8 * h + (lane & 7) + 16 * (lane >> 4));
+    double2 b[8];
+    auto load_row = [&](int step) {
+        const double2* rowp = (const double2*)(bk_ntt + ((size_t)step * kBkRows + row) * (2 * kN));
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
+    };
+    if (row_wave && steps > 0) load_row(0);
+    const int hh = wave >> 3, rr = wave & 7;
+    const int ecoef = lane + 64 * rr + kH * hh;
+
+    // row waves: digits -> first stage -> forward half transform -> products into the sums of rotation r
+    auto row_phase = [&](const Rot& r) {
+        const uint2 q0 = r.dig[(row * 2 + 0) * 64 + lane], q1 = r.dig[(row * 2 + 1) * 64 + lane];
+        double x[kRegs8];
+#pragma unroll
+        for (int k = 0; k < kRegs8; k++) {
+            const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(k < 4 ? q0.x : q0.y, 8u * (k & 3), 8u);
+            const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(k < 4 ? q1.x : q1.y, 8u * (k & 3), 8u);
+            x[k] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);
+        }
+        ntt512_forward(x, ctx);
+        double* s0 = r.sum + h * kH + lane;
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                __hip_atomic_fetch_add(s0 + o * kN + (2 * cc) * 64, fpf::mulmod_wide(x[2 * cc], b[4 * o + cc].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(s0 + o * kN + (2 * cc + 1) * 64, fpf::mulmod_wide(x[2 * cc + 1], b[4 * o + cc].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+    };
+    // inverse waves: half h of sum `out` of rotation r, left in place of the sum in natural order
+    auto inverse_phase = [&](const Rot& r) {
+        double* s = r.sum + out * kN + h * kH + lane;
+        double u[kRegs8];
+#pragma unroll
+        for (int k = 0; k < kRegs8; k++) u[k] = fpf::reduce(s[k * 64]);
+        ntt512_inverse(u, ctx);
+#pragma unroll
+        for (int k = 0; k < kRegs8; k++) s[k * 64] = u[k];
+    };
+    // all waves: last inverse stage, lift, accumulator of rotation r at this lane's coefficient (both components)
+    auto tail_final = [&](const Rot& r, uint32_t (&wnew)[2]) {
+        const double* hd = r.sum + rr * 64 + lane;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const double u0 = hd[m * kN], u1 = hd[m * kN + kH];
+            const double y = hh ? fpf::mulmod(u0 - u1, -fpf::ROOT4) : u0 + u1;
+            wnew[m] = r.acc[m * kN + ecoef] + fpf::lift_u32_small(y);
+        }
+    };
+    // ... after a barrier: clear this lane's slot of the sums (both readers of a slot are done) and decompose for `step`
+    auto tail_decompose = [&](const Rot& r, const uint32_t (&wnew)[2], int step, bool more) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) r.sum[m * kN + hh * kH + rr * 64 + lane] = 0.0;      // each slot by exactly one lane of one wave
+        if (!more) return;
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)r.abar[step]);
+        const int alo = (int)(abar & (kN - 1));
+        const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
+        const int ridx = (ecoef - alo) & (kN - 1);
+        uint8_t* dst = (uint8_t*)r.dig + (hh * 64 + lane) * 8 + rr;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const uint32_t rv = r.acc[m * kN + ridx];
+            const uint32_t t = ((neg ? 0u - rv : rv) - wnew[m] + decomp_offset()) ^ decomp_signmask();
+#pragma unroll
+            for (int dg = 0; dg < kL; dg++)
+                dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
+        }
+    };
+    // The rotated operand of the decomposition is another wave's coefficient: the new words are all stored before any is read.
+    auto tail = [&](const Rot& r, int next_step, bool more) {
+        uint32_t wnew[2];
+        tail_final(r, wnew);
+#pragma unroll
+        for (int m = 0; m < 2; m++) r.acc[m * kN + ecoef] = wnew[m];
+        __syncthreads();
+        tail_decompose(r, wnew, next_step, more);
+    };
+
+    // digits of step 0, both rotations
+    if (steps > 0) {
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            uint32_t w[2];
+#pragma unroll
+            for (int m = 0; m < 2; m++) w[m] = rot[x].acc[m * kN + ecoef];
+            const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)rot[x].abar[0]);
+            const int alo = (int)(abar & (kN - 1));
+            const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
+            const int ridx = (ecoef - alo) & (kN - 1);
+            uint8_t* dst = (uint8_t*)rot[x].dig + (hh * 64 + lane) * 8 + rr;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const uint32_t rv = rot[x].acc[m * kN + ridx];
+                const uint32_t t = ((neg ? 0u - rv : rv) - w[m] + decomp_offset()) ^ decomp_signmask();
+#pragma unroll
+                for (int dg = 0; dg < kL; dg++)
+                    dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        // slot 1: rows of A (step i) beside the inverse transforms of B (step i - 1)
+        if (row_wave) row_phase(rot[0]);
+        else if (i > 0) inverse_phase(rot[1]);
+        __syncthreads();
+        if (i > 0) {
+            tail(rot[1], i, true);
+            __syncthreads();
+        }
+        // slot 2: rows of B (step i) beside the inverse transforms of A (step i)
+        if (row_wave) {
+            row_phase(rot[1]);
+            if (i + 1 < steps) load_row(i + 1);               // b is free: in flight during the tails
+        } else {
+            inverse_phase(rot[0]);
+        }
+        __syncthreads();
+        tail(rot[0], i + 1, i + 1 < steps);
+        __syncthreads();
+    }
+    if (steps > 0) {      // B's last step
+        if (!row_wave) inverse_phase(rot[1]);
+        __syncthreads();
+        tail(rot[1], steps, false);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        if (x == 1 && !live1) break;
+        const int g = 2 * (int)blockIdx.x + x;
+        if (acc_dump) {
+            uint32_t* o = acc_dump + (size_t)g * 2 * kN;
+            for (int e = tid; e < 2 * kN; e += kLlThreads) o[e] = rot[x].acc[e];
+        }
+        if (dsc[x].out) {
+            uint32_t* o = dsc[x].out;      // __SampleExtractIndex__<P,0>
+            for (int e = tid; e < kN; e += kLlThreads) {
+                if (e == 0) { o[0] = rot[x].acc[0]; o[kN] = rot[x].acc[kN]; }
+                else o[kN - e] = 0u - rot[x].acc[e];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // res = a (signed small) * b (torus) mod (X^512 + 1, 2^32), one wave per product: the
 // stand-alone 512-point negacyclic transform (the reference's SmallForwardNTT_512 /
 // SmallInverseNTT_512, include/ntt_gpu/ntt_gpuntt.cuh:283-329,394-440) -- the same wave code as

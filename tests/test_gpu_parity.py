@@ -13,18 +13,20 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["batch", "half", "wg", "ll"])
+@pytest.fixture(params=["batch", "half", "wg", "ll", "ll2"])
 def br_kernel(request, engine):
     """Run a test once per blind-rotate kernel: wave-per-rotation (batch: two rotations per SIMD; half: one
-    per SIMD, the tail shape), workgroup-per-rotation (wg) and the 16-wave split-transform kernel (ll,
-    lowest latency).  All must give the oracle's words."""
+    per SIMD, the tail shape), workgroup-per-rotation (wg), the 16-wave split-transform kernel (ll, lowest latency) and
+    its two-rotations-per-workgroup form (ll2).  All must give the oracle's words."""
     which = request.param
+    engine.api.set_option("ll2_threshold", 1 << 30 if which == "ll2" else 0)
     engine.api.set_option("ll_threshold", 1 << 30 if which == "ll" else 0)
     engine.api.set_option("wg_threshold", 1 << 30 if which in ("wg", "ll") else 0)
     engine.api.set_option("half_threshold", 1 << 30 if which == "half" else 0)   # "batch": two rotations per SIMD whatever the count
     engine.api.set_option("ks_wg_threshold", 0 if which in ("batch", "half") else 1 << 30)
     engine.api.set_option("ks_split_threshold", 1 << 30 if which == "ll" else 0)   # ll: 8 workgroups per key switch
     yield which
+    engine.api.set_option("ll2_threshold", -1)
     engine.api.set_option("ll_threshold", -1)
     engine.api.set_option("wg_threshold", 0)
     engine.api.set_option("ks_wg_threshold", -1)
@@ -440,7 +442,8 @@ def test_ragged_batch_sizes(engine, keys, count):
 
 
 @pytest.mark.parametrize("count,opts", [(700, dict(ll_threshold=0, wg_threshold=0)),        # one rotation per SIMD (4 of 8 waves)
-                                        (1100, {}), (3200, {}),                               # (rounds +) 1024 at one per SIMD + low-latency kernel
+                                        (1100, dict(ll2_threshold=0)), (3200, dict(ll2_threshold=0)),   # (rounds +) 1024 at one per SIMD + low-latency kernel
+                                        (300, {}), (600, {}), (1300, {}), (1536, {}), (3500, {}),       # paired low-latency kernel: all / 512 + single kernel / tail
                                         (2049, {}), (2700, {}), (4600, {})])                  # full rounds + a tail
 def test_launch_shapes_with_tails(engine, keys, count, opts):
     """Launches that do not fill whole rounds of the blind-rotate grid are cut into full rounds plus a
@@ -459,10 +462,11 @@ def test_launch_shapes_with_tails(engine, keys, count, opts):
     finally:
         engine.api.set_option("ll_threshold", -1)
         engine.api.set_option("wg_threshold", 0)
+        engine.api.set_option("ll2_threshold", -1)
     assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
     cut = count - count % 2048
-    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, cut + 1023, cut + 1024, cut + 1027,
-                                      count - 5, count - 1]), 0, count - 1))
+    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, cut + 511, cut + 512, cut + 513, cut + 1023, cut + 1024,
+                                      cut + 1027, count - 5, count - 2, count - 1]), 0, count - 1))
     want = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0][idx], ins[1][idx])
     assert np.array_equal(got[idx], want)
 

@@ -1,4 +1,4 @@
-"""Gate-batch time at the batch sizes between the launch shapes (defaults): python tools/tail_times.py [counts...]"""
+"""Gate-batch time at the batch sizes between the launch shapes: python tools/tail_times.py [option=value ...] [counts...]"""
 import os
 import sys
 import time
@@ -13,7 +13,9 @@ ksk = rng.integers(0, 2**32, size=int(P.ksk_words), dtype=np.uint64).astype(np.u
 eng.SetGPUNum(1)
 eng.Initialize(bk, ksk)
 n = int(P.n)
-counts = [int(a) for a in sys.argv[1:]] or [900, 1024, 1025, 1100, 1280, 1281, 1536, 2047, 2048, 3072, 3200, 3328, 3329, 4096]
+for kv in [a for a in sys.argv[1:] if "=" in a]:      # library options, e.g. ll2_threshold=2048
+    eng.api.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+counts = [int(a) for a in sys.argv[1:] if "=" not in a] or [900, 1024, 1025, 1100, 1280, 1281, 1536, 2047, 2048, 3072, 3200, 3328, 3329, 4096]
 mx = max(counts)
 a = rng.integers(0, 2**32, size=(mx, n + 1), dtype=np.uint64).astype(np.uint32)
 d0 = eng.api.DeviceBuffer(a.size).upload(a)
