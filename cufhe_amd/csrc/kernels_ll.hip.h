@@ -230,17 +230,16 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 // Two rotations per workgroup (launches of 257 .. 1280 rotations and their tails): the same waves, the same
 // arithmetic, but while the twelve row waves work on one rotation the four inverse waves transform the sums of the
 // other, and the two rotations share every key row (loaded once into the row waves' registers).
-//   slot 1   row waves: row phase of A, step i          inverse waves: inverse transforms of B, step i-1
-//   tail     all waves: last stage + lift + accumulator of B (i-1), barrier, decomposition of B for step i
-//   slot 2   row waves: row phase of B, step i          inverse waves: inverse transforms of A, step i
-//   tail     all waves: the same for A
-// Six barriers per step for two rotations.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition now
+//   slot 1   row waves: row phase of A, step i     inverse waves: tail of B's step i-1 (inverse transforms, last stage,
+//                                                   lift, accumulator, decomposition for step i)
+//   slot 2   row waves: row phase of B, step i     inverse waves: the same for A's step i
+// Two workgroup barriers per step for two rotations; inside a tail the four inverse waves meet twice at a counter in LDS.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition now
 // computes its rotated index), sums 16 KiB (an inverse wave leaves its half transform where it read its sum), digits
 // 6 KiB, abar list.
 // ----------------------------------------------------------------------------------
 constexpr int kLl2RotBytes = 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8 + kAbarBytes + 16;    // 32032
 constexpr int kLl2LdsRot = kLlLdsTiles + 16 * kTile512Bytes;
-constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes;                                       // 152896
+constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes + 16;                                  // 152912 (+ the inverse waves' counter)
 static_assert(kLl2LdsBytes <= 160 * 1024, "paired low-latency kernel does not fit the CU's LDS");
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
@@ -267,6 +266,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     }
     if (2 * (int)blockIdx.x >= count) return;
     const bool live1 = 2 * (int)blockIdx.x + 1 < count;
+    if (tid == 0) *(uint32_t*)(smem + kLl2LdsRot + 2 * kLl2RotBytes) = 0;      // the inverse waves' counter (inv_sync)
 
     for (int i = tid; i < 2 * kLds512TableDoubles; i += kLlThreads) {     // tb_fwd .. tc_inv are contiguous
         const int hh = i / kLds512TableDoubles, k = i % kLds512TableDoubles;
@@ -334,8 +334,26 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
                 __hip_atomic_fetch_add(s0 + o * kN + (2 * cc + 1) * 64, fpf::mulmod_wide(x[2 * cc + 1], b[4 * o + cc].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
     };
-    // inverse waves: half h of sum `out` of rotation r, left in place of the sum in natural order
-    auto inverse_phase = [&](const Rot& r) {
+    // The four inverse waves synchronise among themselves through a counter in LDS (the row waves are busy with the
+    // other rotation and must not be held up by a workgroup barrier -- measured: with the tail of a step spread over all
+    // sixteen waves behind two more barriers a round of 512 rotations takes 6 % longer): every wave adds 1, then waits
+    // for 4 more than last time.  DS operations of a wave execute in order, so what it wrote before the add is in LDS
+    // when the count shows.  The wait is bounded so that a logic error shows up as wrong words in the tests, not as a
+    // hung device; a correct run waits a few hundred cycles.
+    uint32_t* sync_cnt = (uint32_t*)(smem + kLl2LdsRot + 2 * kLl2RotBytes);
+    uint32_t sync_target = 0;
+    auto inv_sync = [&]() {
+        sync_target += 4;
+        if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int spins = 0; spins < (1 << 16); spins++) {
+            if (__hip_atomic_load(sync_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= sync_target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    // inverse waves: the whole tail of rotation r's step -- half h of sum `out` (left in place of the sum for the
+    // sibling half), last stage + lift + accumulator at coefficients lane + 64 k + 512 h, and, once all four have stored
+    // their words, the decomposition of those coefficients for step `next_step` (all l digits, eight signed bytes to a word)
+    auto inverse_chain = [&](const Rot& r, int next_step, bool more) {
         double* s = r.sum + out * kN + h * kH + lane;
         double u[kRegs8];
 #pragma unroll
@@ -343,45 +361,48 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         ntt512_inverse(u, ctx);
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) s[k * 64] = u[k];
-    };
-    // all waves: last inverse stage, lift, accumulator of rotation r at this lane's coefficient (both components)
-    auto tail_final = [&](const Rot& r, uint32_t (&wnew)[2]) {
-        const double* hd = r.sum + rr * 64 + lane;
+        inv_sync();
+        const double* other = r.sum + out * kN + (h ^ 1) * kH + lane;
+        uint32_t* acck = r.acc + out * kN + h * kH + lane;
+        uint32_t wnew[kRegs8];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const double u0 = hd[m * kN], u1 = hd[m * kN + kH];
-            const double y = hh ? fpf::mulmod(u0 - u1, -fpf::ROOT4) : u0 + u1;
-            wnew[m] = r.acc[m * kN + ecoef] + fpf::lift_u32_small(y);
+        for (int k = 0; k < kRegs8; k++) {
+            const double v = other[k * 64];
+            const double y = h ? fpf::mulmod(v - u[k], -fpf::ROOT4) : u[k] + v;
+            wnew[k] = acck[k * 64] + fpf::lift_u32_small(y);
+            acck[k * 64] = wnew[k];
         }
-    };
-    // ... after a barrier: clear this lane's slot of the sums (both readers of a slot are done) and decompose for `step`
-    auto tail_decompose = [&](const Rot& r, const uint32_t (&wnew)[2], int step, bool more) {
+        inv_sync();
 #pragma unroll
-        for (int m = 0; m < 2; m++) r.sum[m * kN + hh * kH + rr * 64 + lane] = 0.0;      // each slot by exactly one lane of one wave
+        for (int k = 0; k < kRegs8; k++) s[k * 64] = 0.0;       // the sibling has read it
         if (!more) return;
-        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)r.abar[step]);
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)r.abar[next_step]);
         const int alo = (int)(abar & (kN - 1));
-        const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
-        const int ridx = (ecoef - alo) & (kN - 1);
-        uint8_t* dst = (uint8_t*)r.dig + (hh * 64 + lane) * 8 + rr;
+        const bool ahi = (abar >> kNbit) != 0;
+        const uint32_t* accj = r.acc + out * kN;
+        uint32_t rv[kRegs8];
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const uint32_t rv = r.acc[m * kN + ridx];
-            const uint32_t t = ((neg ? 0u - rv : rv) - wnew[m] + decomp_offset()) ^ decomp_signmask();
+        for (int k = 0; k < kRegs8; k++) rv[k] = accj[(lane + 64 * k + h * kH - alo) & (kN - 1)];
+        uint32_t lo[kL], hi[kL];
 #pragma unroll
-            for (int dg = 0; dg < kL; dg++)
-                dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
+        for (int dg = 0; dg < kL; dg++) { lo[dg] = 0; hi[dg] = 0; }
+#pragma unroll
+        for (int k = 0; k < kRegs8; k++) {
+            const bool neg = (lane + 64 * k + h * kH < alo) != ahi;
+            const uint32_t t = ((neg ? 0u - rv[k] : rv[k]) - wnew[k] + decomp_offset()) ^ decomp_signmask();
+#pragma unroll
+            for (int dg = 0; dg < kL; dg++) {
+                const uint32_t bb = (uint32_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit) & 0xffu;
+                if (k < 4) lo[dg] |= bb << (8 * k);
+                else hi[dg] |= bb << (8 * (k - 4));
+            }
         }
-    };
-    // The rotated operand of the decomposition is another wave's coefficient: the new words are all stored before any is read.
-    auto tail = [&](const Rot& r, int next_step, bool more) {
-        uint32_t wnew[2];
-        tail_final(r, wnew);
 #pragma unroll
-        for (int m = 0; m < 2; m++) r.acc[m * kN + ecoef] = wnew[m];
-        __syncthreads();
-        tail_decompose(r, wnew, next_step, more);
+        for (int dg = 0; dg < kL; dg++) r.dig[((out * kL + dg) * 2 + h) * 64 + lane] = make_uint2(lo[dg], hi[dg]);
     };
+    // one serial chain per slot: the inverse waves go first whenever they can issue (without it the chain, behind
+    // three row waves per SIMD, sets the length of the slot: 5.9 ms per 2 rotations against 4.8)
+    if (!row_wave) __builtin_amdgcn_s_setprio(3);
 
     // digits of step 0, both rotations
     if (steps > 0) {
@@ -409,29 +430,21 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
 
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
-        // slot 1: rows of A (step i) beside the inverse transforms of B (step i - 1)
+        // slot 1: rows of A (step i) beside the tail of B's step i - 1 (inverse transforms, accumulator, digits of step i)
         if (row_wave) row_phase(rot[0]);
-        else if (i > 0) inverse_phase(rot[1]);
+        else if (i > 0) inverse_chain(rot[1], i, true);
         __syncthreads();
-        if (i > 0) {
-            tail(rot[1], i, true);
-            __syncthreads();
-        }
-        // slot 2: rows of B (step i) beside the inverse transforms of A (step i)
+        // slot 2: rows of B (step i) beside the tail of A's step i
         if (row_wave) {
             row_phase(rot[1]);
-            if (i + 1 < steps) load_row(i + 1);               // b is free: in flight during the tails
+            if (i + 1 < steps) load_row(i + 1);               // b is free
         } else {
-            inverse_phase(rot[0]);
+            inverse_chain(rot[0], i + 1, i + 1 < steps);
         }
-        __syncthreads();
-        tail(rot[0], i + 1, i + 1 < steps);
         __syncthreads();
     }
     if (steps > 0) {      // B's last step
-        if (!row_wave) inverse_phase(rot[1]);
-        __syncthreads();
-        tail(rot[1], steps, false);
+        if (!row_wave) inverse_chain(rot[1], steps, false);
         __syncthreads();
     }
 
