@@ -338,14 +338,15 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     // other rotation and must not be held up by a workgroup barrier -- measured: with the tail of a step spread over all
     // sixteen waves behind two more barriers a round of 512 rotations takes 6 % longer): every wave adds 1, then waits
     // for 4 more than last time.  DS operations of a wave execute in order, so what it wrote before the add is in LDS
-    // when the count shows.  The wait is bounded so that a logic error shows up as wrong words in the tests, not as a
-    // hung device; a correct run waits a few hundred cycles.
+    // when the count shows.  The wait is bounded (about 0.1 s; a correct run waits a few hundred cycles, and the waves
+    // of a workgroup are resident, and preempted, together) so that a logic error shows up as wrong words in the tests,
+    // not as a hung device.
     uint32_t* sync_cnt = (uint32_t*)(smem + kLl2LdsRot + 2 * kLl2RotBytes);
     uint32_t sync_target = 0;
     auto inv_sync = [&]() {
         sync_target += 4;
         if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int spins = 0; spins < (1 << 16); spins++) {
+        for (int spins = 0; spins < (1 << 20); spins++) {
             if (__hip_atomic_load(sync_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= sync_target) break;
             __builtin_amdgcn_s_sleep(1);
         }
