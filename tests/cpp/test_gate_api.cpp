@@ -370,6 +370,8 @@ int main(int argc, char** argv)
     // more logical GPUs than the box has (test/test_gate_gpu_multi.cc hard-codes gpuNum = 2): every logical device
     // keeps its own keys, scheduler, launch thread and streams, several of them on one physical GPU
     if (getenv("CUFHE_AMD_SHARE_DEVICES")) CUFHE_AMD_CHECK(cufhe_amd_set_option("share_devices", 1));
+    // the whole program again with outputs taking fresh device buffers (include/cufhe_amd.h, "sched_rename")
+    if (getenv("CUFHE_AMD_SCHED_RENAME")) CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 1));
     SetGPUNum(gpus);
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc

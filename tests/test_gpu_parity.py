@@ -320,6 +320,27 @@ def test_cpp_gate_api_three_logical_gpus(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+def test_cpp_gate_api_with_output_renaming(engine):
+    """The same program, two logical devices, with "sched_rename": every check of the reference's test programs (truth
+    tables, chained in-place gates, polling, device-resident g-gates, TRLWE-level primitives, launch-count bounds) holds
+    when outputs take fresh device buffers."""
+    import os
+    import subprocess
+    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api")
+    assert os.path.exists(exe), "built by test_cpp_gate_api_mirror"
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1", CUFHE_AMD_SCHED_RENAME="1"))
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
+
+
 def test_plain_bootstrap(engine, keys, oracle, br_kernel):
     """Bootstrap (src/bootstrap_gpu.cu:290-301): blind rotate -> extract -> key switch of one TLWE."""
     rng = np.random.default_rng(31)
