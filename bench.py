@@ -64,7 +64,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cufhe_amd", "csrc")
     # the device code of the two profiled kernels and what they include (host-side files do not change what a launch executes)
-    for f in ("fpfield.h", "ntt_wave.h", "kernels.hip.h", "kernels_lvl2.hip.h"):
+    for f in ("fpfield.h", "ntt_wave.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_lvl2.hip.h"):
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()

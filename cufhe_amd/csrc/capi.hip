@@ -19,6 +19,7 @@
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
 #include "kernels_ks2.hip.h"
+#define CUFHE_AMD_LL_DECLARATIONS_ONLY      // defined in kernels_ll.hip
 #include "kernels_ll.hip.h"
 #include "kernels_ps.hip.h"
 

@@ -18,8 +18,11 @@
 //                used to recompute the decomposed word of its coefficients: six times the same arithmetic,
 //                on the waves that set the length of the step)
 // Four workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
+// The kernels of this file are compiled in their own translation unit (kernels_ll.hip, with
+// -mllvm -amdgpu-sched-strategy=max-ilp: 3.5 % faster here, while the same strategy costs the N = 512 parameter-set
+// kernel 4 %); capi.hip includes it with CUFHE_AMD_LL_DECLARATIONS_ONLY for the constants and the prototypes.
 #pragma once
-#include "kernels.hip.h"
+#include "kernels_common.hip.h"
 #include "ntt_wave512.h"
 
 namespace cufhe_amd {
@@ -36,6 +39,10 @@ constexpr int kLlLdsAbar = kLlLdsDig + kBkRows * 2 * 64 * 8;                  //
 constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 145424
 static_assert(kBgbit <= 8, "digits are packed as signed bytes");
 
+__global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
+#ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         }
     }
 }
+#endif
 
 // ----------------------------------------------------------------------------------
 // Two rotations per workgroup (launches of 257 .. 1280 rotations and their tails): the same waves, the same
@@ -242,6 +250,10 @@ constexpr int kLl2LdsRot = kLlLdsTiles + 16 * kTile512Bytes;
 constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes + 16;                                  // 152912 (+ the inverse waves' counter)
 static_assert(kLl2LdsBytes <= 160 * 1024, "paired low-latency kernel does not fit the CU's LDS");
 
+__global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
+    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
+#ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
@@ -466,6 +478,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         }
     }
 }
+#endif
 
 // ----------------------------------------------------------------------------------
 // res = a (signed small) * b (torus) mod (X^512 + 1, 2^32), one wave per product: the
@@ -475,6 +488,10 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
 // ----------------------------------------------------------------------------------
 constexpr int kPoly512LdsBytes = kLds512TableBytes + kNttWavesPerBlock * kTile512Bytes;
 
+__global__ __launch_bounds__(kNttThreads) void polymul512_kernel(
+    uint32_t* __restrict__ res, const int32_t* __restrict__ a, const uint32_t* __restrict__ b,
+    int count, const Ntt512Tables* __restrict__ gt, double n_inverse);
+#ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
 __global__ __launch_bounds__(kNttThreads) void polymul512_kernel(
     uint32_t* __restrict__ res, const int32_t* __restrict__ a, const uint32_t* __restrict__ b,
     int count, const Ntt512Tables* __restrict__ gt, double n_inverse)
@@ -503,5 +520,6 @@ __global__ __launch_bounds__(kNttThreads) void polymul512_kernel(
 #pragma unroll
     for (int r = 0; r < kRegs8; r++) res[(size_t)g * kH + lane + 64 * r] = fpf::lift_u32(x[r]);
 }
+#endif
 
 }  // namespace cufhe_amd
