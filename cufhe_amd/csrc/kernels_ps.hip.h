@@ -125,8 +125,9 @@ template <> struct Poly<9> {
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt512_inverse(x, c); }
 };
 
-constexpr int kPsWaves = 8;
-constexpr int kPsThreads = 64 * kPsWaves;
+// waves of the workgroup-per-rotation kernel: one per TRGSW row where that takes more than 8 (k2n512: 9 rows would
+// otherwise be walked in two passes, the second with one busy wave)
+template <class PS> constexpr int kPsWavesOf = ((PS::k + 1) * PS::l > 8) ? 12 : 8;
 
 template <class PS>
 struct PsLds {
@@ -134,7 +135,9 @@ struct PsLds {
     using PO = Poly<PS::Nbit>;
     static constexpr int tables = 0;
     static constexpr int tiles = tables + PO::table_bytes;
-    static constexpr int acc = tiles + kPsWaves * PO::tile_bytes;              // [K1][N] u32
+    static constexpr int waves = kPsWavesOf<PS>;
+    static constexpr int threads = 64 * waves;
+    static constexpr int acc = tiles + waves * PO::tile_bytes;                 // [K1][N] u32
     static constexpr int sums = (acc + D::K1 * D::N * 4 + 15) & ~15;           // [SUMS][R][64] f64
     static constexpr int abar = sums + D::SUMS * D::N * 8;
     static constexpr int bytes = abar + kAbarBytes + 16;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
 // src/bootstrap_gpu.cu:366-381.
 // ----------------------------------------------------------------------------------------------
 template <class PS>
-__global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
+__global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const typename Poly<PS::Nbit>::Tables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {
@@ -217,16 +220,16 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
     uint32_t* bbar_slot = (uint32_t*)(smem + L::abar + kAbarBytes);
 
     const LinDesc d = descs[g];
-    for (int i = tid; i <= PS::n; i += kPsThreads) {      // pre-add and modulus switch, :316-345
+    for (int i = tid; i <= PS::n; i += L::threads) {      // pre-add and modulus switch, :316-345
         const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
         if (i < PS::n) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - PS::Nbit))) >> (32 - 1 - PS::Nbit));
         else *bbar_slot = 2 * N - ((c + d.off) >> (32 - 1 - PS::Nbit));
     }
-    for (int i = tid; i < D::SUMS * N; i += kPsThreads) sumL[i] = 0.0;
+    for (int i = tid; i < D::SUMS * N; i += L::threads) sumL[i] = 0.0;
     __syncthreads();
     {   // RotatedTestVector, :29-52: mask components zero, body +-mu
         const uint32_t bbar = *bbar_slot;
-        for (int e = tid; e < N; e += kPsThreads) {
+        for (int e = tid; e < N; e += L::threads) {
             const bool neg = (bbar != 2 * N) && (((uint32_t)e < (bbar & (N - 1))) != ((bbar >> PS::Nbit) != 0));
             for (int j = 0; j < PS::k; j++) accL[j * N + e] = 0;
             accL[PS::k * N + e] = neg ? 0u - kMu : kMu;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
         const int alo = (int)(abar & (N - 1));
         const bool ahi = (abar >> PS::Nbit) != 0;
 #pragma unroll 1
-        for (int row = wave; row < D::ROWS; row += kPsWaves) {
+        for (int row = wave; row < D::ROWS; row += L::waves) {
             const int j = row / PS::l, dg = row % PS::l;
             const uint32_t* accj = accL + j * N;
             const uint32_t pos = 32 - (dg + 1) * PS::Bgbit;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
         }
         __syncthreads();
 #pragma unroll 1
-        for (int s = wave; s < D::SUMS; s += kPsWaves) {      // :227-284
+        for (int s = wave; s < D::SUMS; s += L::waves) {      // :227-284
             double* sp = sumL + s * N + lane;
             double A[R];
 #pragma unroll
@@ -294,11 +297,11 @@ __global__ __launch_bounds__(kPsThreads) void blind_rotate_ps_kernel(
 
     if (acc_dump) {
         uint32_t* o = acc_dump + (size_t)g * K1 * N;
-        for (int e = tid; e < K1 * N; e += kPsThreads) o[e] = accL[e];
+        for (int e = tid; e < K1 * N; e += L::threads) o[e] = accL[e];
     }
     if (d.out) {   // __SampleExtractIndex__<P,0>: per mask component a'[0] = a[0], a'[m] = -a[N-m]; b' = b[0]
         uint32_t* o = d.out;
-        for (int e = tid; e < PS::k * N; e += kPsThreads) {
+        for (int e = tid; e < PS::k * N; e += L::threads) {
             const int j = e / N, m = e % N;
             o[e] = m == 0 ? accL[j * N] : 0u - accL[j * N + N - m];
         }

@@ -7,9 +7,10 @@
 namespace {
 
 long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-per-rotation kernel is used (-1: by cost)
-// By cost: a round of the wave-per-rotation kernel (up to 2048 rotations) takes about as long as two rounds of 256 of the
-// workgroup-per-rotation kernel for the N = 1024 sets (19.5 / 24 ms against 9.4 / 10.8 per round), three for N = 512 (17 against 5.5).
-template <class PS> constexpr long kPsAutoBatch = PS::Nbit == 9 ? 769 : 513;
+// By cost (tools/ps_latency.py, tools/ps_times.py; blind rotation + key switch): the workgroup-per-rotation kernel takes
+// 5.0 / 3.5 / 4.0 ms per started round of 256 (default / k2n512 / cggi16), a round of the wave-per-rotation kernel (up to
+// 2048 rotations) 21 / 18.5 / 26 ms: the second wins from the fifth / sixth / seventh started round on.
+template <class PS> constexpr long kPsAutoBatch = PS::limbs > 1 ? 1537 : PS::Nbit == 9 ? 1281 : 1025;
 
 struct PsState {
     bool ready = false, lds_opt_in = false, ks_lds_opt_in = false;
@@ -89,7 +90,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
                            ps.bk_ntt, ps_tables<PS>(s), steps, dump);
     } else {
         // one workgroup per rotation (latency shape)
-        hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(kPsThreads), PsLds<PS>::bytes, st, d, (int)count,
+        hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(PsLds<PS>::threads), PsLds<PS>::bytes, st, d, (int)count,
                            ps.bk_ntt, ps_tables<PS>(s), steps, dump);
     }
     HIP_TRY(hipGetLastError());

@@ -192,7 +192,7 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * up to 32, 0.19 ms at 192), up to ks_wg_threshold one workgroup per ciphertext (0.22 ms up to 256,
  * 0.8 ms at 1024), above that 16 ciphertexts share each step of the key in LDS (1.5 ms whatever the
  * count up to 4096).  All variants produce identical words.
- * "ps_batch_threshold" (default -1 = by cost: 513, or 769 for N = 512): rotations per launch from which the parameter-set path
+ * "ps_batch_threshold" (default -1 = by cost: 1025, 1281 for N = 512, 1537 for sets with key limbs): rotations per launch from which the parameter-set path
  * (cufhe_amd_ps_*) uses the wave-per-rotation kernel instead of a workgroup per rotation.
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048

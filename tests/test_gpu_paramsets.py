@@ -32,7 +32,7 @@ def pset(request, engine):
 @pytest.fixture(autouse=True, params=["wg", "batch"])
 def ps_kernel(request, engine):
     """Both launch shapes of the blind rotation: a workgroup per rotation (small launches) and a wave per rotation with
-    eight rotations per workgroup sharing the key rows (above 512 or 768 rotations); forced here for every count."""
+    eight rotations per workgroup sharing the key rows (above 1024 to 1536 rotations, by set); forced here for every count."""
     engine.api.set_option("ps_batch_threshold", 1 << 30 if request.param == "wg" else 1)
     yield request.param
     engine.api.set_option("ps_batch_threshold", -1)
