@@ -235,14 +235,14 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 #endif
 
 // ----------------------------------------------------------------------------------
-// Two rotations per workgroup (launches of 257 .. 1280 rotations and their tails): the same waves, the same
+// Two rotations per workgroup (launches of 257 .. 1536 rotations and their tails): the same waves, the same
 // arithmetic, but while the twelve row waves work on one rotation the four inverse waves transform the sums of the
 // other, and the two rotations share every key row (loaded once into the row waves' registers).
 //   slot 1   row waves: row phase of A, step i     inverse waves: tail of B's step i-1 (inverse transforms, last stage,
 //                                                   lift, accumulator, decomposition for step i)
 //   slot 2   row waves: row phase of B, step i     inverse waves: the same for A's step i
-// Two workgroup barriers per step for two rotations; inside a tail the four inverse waves meet twice at a counter in LDS.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition now
-// computes its rotated index), sums 16 KiB (an inverse wave leaves its half transform where it read its sum), digits
+// Two workgroup barriers per step for two rotations; inside a tail the four inverse waves meet twice at a counter in
+// LDS.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition computes its rotated index), sums 16 KiB (an inverse wave leaves its half transform where it read its sum), digits
 // 6 KiB, abar list.
 // ----------------------------------------------------------------------------------
 constexpr int kLl2RotBytes = 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8 + kAbarBytes + 16;    // 32032
