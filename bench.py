@@ -49,6 +49,44 @@ _spec.loader.exec_module(distutil)
 RANK, LOCAL_RANK, WORLD = distutil.rank_env()
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
+    ap.add_argument("--total-gates", type=int, default=0,
+                    help="strong scaling: this many gates per step split contiguously over the ranks (configs[2]: 32768)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads / api_pcie_inclusive / latency")
+    ap.add_argument("--workload", choices=["nand", "mux", "mixed", "nand_lvl2"], default="nand",
+                    help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix; "
+                         "nand_lvl2 = configs[4] (N = 2048 ring, 64-bit torus)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` run plainly (N > 1, no WORLD_SIZE in the environment): this process
+    becomes the launcher -- it has not imported torch or the HIP library and never touches the GPU --
+    starts N fresh rank processes of this same command, relays rank 0's JSON line and exits with
+    the first failing rank's code (cufhe_amd/dist.py: spawn_ranks)."""
+    timeout = float(os.environ.get("CUFHE_AMD_BENCH_LAUNCH_TIMEOUT", "1500"))
+    rc, out = distutil.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=timeout)
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in out.splitlines()):
+        sys.stderr.write("bench.py launcher: rank 0 printed no JSON line\n")
+        rc = 1
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    ARGS = parse_args()
+    if "WORLD_SIZE" not in os.environ and ARGS.gpus > 1:
+        self_launch(ARGS)            # does not return
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: its bundled HIP runtime is the one the process uses)
 import torch.distributed as dist  # noqa: E402
@@ -151,22 +189,10 @@ def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
-    ap.add_argument("--total-gates", type=int, default=0,
-                    help="strong scaling: this many gates per step split contiguously over the ranks (configs[2]: 32768)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads / api_pcie_inclusive / latency")
-    ap.add_argument("--workload", choices=["nand", "mux", "mixed", "nand_lvl2"], default="nand",
-                    help="nand = BASELINE configs[1] (the metric's config); mux = configs[3]; mixed = configs[2] op mix; "
-                         "nand_lvl2 = configs[4] (N = 2048 ring, 64-bit torus)")
-    args = ap.parse_args()
+    args = ARGS
     if args.gpus != WORLD:
-        if WORLD == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={WORLD}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                 "or plainly (no WORLD_SIZE in the environment) and bench.py starts the ranks itself")
 
     if WORLD > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -52,3 +52,69 @@ def max_over_ranks(value, dist=None):
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
+    """Self-launcher for `bench.py --gpus N` run plainly (no torch.distributed.run around it): start
+    `world` child processes of `child_cmd`, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), wait for all of them, and return
+    (exit_code, stdout_of_rank_0).  The caller must not have touched the GPU: children are fresh
+    processes, nothing is exec'd over a process that initialised HIP.  A rank that fails (or the
+    timeout) ends the others -- they would wait for it in the barrier forever -- by their exact
+    PIDs, and the launcher reports a non-zero exit code.  Ranks other than 0 inherit stderr, their
+    stdout is dropped (rank 0 prints the one JSON line)."""
+    import subprocess
+    import time
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["MASTER_ADDR"] = "127.0.0.1"
+    base["MASTER_PORT"] = str(free_port())
+    base["WORLD_SIZE"] = str(world)
+    base["LOCAL_WORLD_SIZE"] = str(world)
+    procs = []
+    for r in range(world):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(child_cmd), env=e, stdin=subprocess.DEVNULL,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained by a thread so that a long line can never block the child
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0 = time.monotonic()
+    rc = 0
+    pending = set(range(world))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+            if rc == 0:
+                rc = 124
+            for r in pending:
+                procs[r].terminate()
+            deadline = time.monotonic() + 10
+            for r in pending:
+                try:
+                    procs[r].wait(max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            pending = set()
+        if pending:
+            time.sleep(poll)
+    reader.join(10)
+    out = chunks[0].decode(errors="replace") if chunks else ""
+    return rc, out

@@ -78,3 +78,136 @@ def test_two_ranks_gloo(tmp_path, keys):
         lo, hi = np.load(tmp_path / f"range{rank}.npy")
         got[lo:hi] = np.load(tmp_path / f"shard{rank}.npy")
     assert np.array_equal(got, want)
+
+
+def _dist():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
+    d = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(d)
+    return d
+
+
+STUB_CHILD = r'''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail" or (mode == "hang" and rank == 0):
+    time.sleep(600)                       # a rank waiting in a barrier for the one that died / a hung rank
+print("noise on stdout of rank %d" % rank)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "port": os.environ["MASTER_PORT"]}))
+'''
+
+
+def test_self_launcher_with_stub_children():
+    """bench.py --gpus N run plainly: spawn_ranks starts N fresh rank processes, relays rank 0's
+    stdout, and a failing (or hung) rank ends the job with a non-zero exit code, not a hang."""
+    import json
+    import time
+    d = _dist()
+    rc, out = d.spawn_ranks([sys.executable, "-c", STUB_CHILD, "ok"], 3)
+    assert rc == 0
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 3        # rank 0's line only
+    assert out.count("noise") == 1
+    t0 = time.monotonic()
+    rc, out = d.spawn_ranks([sys.executable, "-c", STUB_CHILD, "fail"], 3)
+    assert rc == 7 and time.monotonic() - t0 < 60                          # rank 1's code; ranks 0 and 2 were ended
+    t0 = time.monotonic()
+    rc, out = d.spawn_ranks([sys.executable, "-c", STUB_CHILD, "hang"], 2, timeout=2.0)
+    assert rc == 124 and time.monotonic() - t0 < 60
+
+
+def test_bench_refuses_world_mismatch_and_self_launches_before_torch():
+    """The launcher branch of bench.py runs before torch / the HIP library are imported (a process
+    that touched the GPU must not start ranks), and a WORLD_SIZE that contradicts --gpus is an error."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("self_launch(ARGS)") < src.index("import torch")
+    assert src.index("self_launch(ARGS)") < src.index("import numpy")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+GPU_WORKER = r'''
+import os, sys, importlib.util
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
+d = importlib.util.module_from_spec(spec); spec.loader.exec_module(d)
+rank, local_rank, world = d.rank_env()
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=rank, world_size=world)
+dev = d.device_for_rank(local_rank, torch.cuda.device_count())      # wraps on a 1-GPU box
+torch.cuda.set_device(dev)
+import oracle_lib as ol
+import cufhe_amd as eng
+eng.api.set_option("device_base", dev)
+L = ol.load(); keys = ol.Keys(L, seed=1)
+eng.SetGPUNum(1); eng.Initialize(keys.bk, keys.ksk)
+count = 24
+bits = np.random.default_rng(5).integers(0, 2, size=(2, count)).astype(np.uint8)
+ins = [keys.encrypt(bits[i], 0, seed=300 + i) for i in range(2)]
+ops = np.array([[3, 4, 5, 0][g % 4] for g in range(count)], np.int32)
+lo, hi = d.shard(count, rank, world)
+n = hi - lo
+d0 = eng.api.DeviceBuffer(n * (ol.n + 1)).upload(np.ascontiguousarray(ins[0][lo:hi]))
+d1 = eng.api.DeviceBuffer(n * (ol.n + 1)).upload(np.ascontiguousarray(ins[1][lo:hi]))
+dout = eng.api.DeviceBuffer(n * (ol.n + 1))
+dist.barrier()
+eng.api.gate_batch(np.ascontiguousarray(ops[lo:hi]), 0, dout, d0, d1, None, count=n, device=0)
+eng.Synchronize()
+dist.barrier()
+np.save(os.path.join(OUT, f"shard{rank}.npy"), dout.download().reshape(n, -1))
+np.save(os.path.join(OUT, f"range{rank}.npy"), np.array([lo, hi]))
+mapped = [l.split()[-1] for l in open("/proc/self/maps") if "libcufhe_amd.so" in l]
+assert mapped, "HIP library not mapped in the rank"
+eng.CleanUp()
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_library_words(tmp_path, keys):
+    """Two ranks, each loading libcufhe_amd.so with its own `device_base` (wrapping onto the one GPU of
+    a 1-GPU box), each running its contiguous shard of a mixed gate list through the C ABI: the
+    union of the shards == the oracle's words (test/test_gate_gpu_multi.cc:36-93 shards by stream
+    device; include/cufhe_gpu.cuh:154-159; per-GPU key replicas src/bootstrap_gpu.cu:115-137)."""
+    d = _dist()
+    code = f"ROOT={ROOT!r}\nOUT={str(tmp_path)!r}\n" + GPU_WORKER
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "HIP_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    rc, out = d.spawn_ranks([sys.executable, "-c", code], 2, env=env, timeout=900)
+    assert rc == 0, out
+    count = 24
+    bits = np.random.default_rng(5).integers(0, 2, size=(2, count)).astype(np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=300 + i) for i in range(2)]
+    ops = np.array([[3, 4, 5, 0][g % 4] for g in range(count)], np.int32)
+    want = keys.gate_batch(ops, 0, ins[0], ins[1])
+    got = np.zeros_like(want)
+    for rank in range(2):
+        lo, hi = np.load(tmp_path / f"range{rank}.npy")
+        got[lo:hi] = np.load(tmp_path / f"shard{rank}.npy")
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_this_box():
+    """`python bench.py --gpus 2` run plainly prints one line with n_gpus 2 (ranks wrap onto the GPUs present)."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gates", "512"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
