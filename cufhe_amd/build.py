@@ -32,16 +32,26 @@ def _compile_and_link(out, defines=(), extra=(), verbose=False):
 
 
 DIAG_OUT = os.path.join(HERE, "libcufhe_amd_diag.so")
+# fault injection for tests/test_gpu_fault.py: one inverse wave of the paired low-latency kernel misses a rendezvous
+FAULT_OUT = os.path.join(HERE, "libcufhe_amd_diag_ll2_timeout.so")
 
 
-def build(force=False, verbose=False, diagnostic=None, extra=()):
-    """diagnostic: list of ablation switch names (NO_TW, NO_XPOSE, NO_BK, BK0): a timing-only build whose
-    results are WRONG; it goes to libcufhe_amd_diag.so and is never loaded by the package."""
+def build(force=False, verbose=False, diagnostic=None, extra=(), out=None):
+    """diagnostic: list of ablation switch names (NO_TW, NO_XPOSE, NO_BK, BK0, PHASES, LL2_TIMEOUT): a build whose
+    results are WRONG by design (timing experiments, fault injection); it goes to libcufhe_amd_diag.so (or `out`)
+    and is never loaded by the package."""
     if diagnostic:
-        return _compile_and_link(DIAG_OUT, ["-DCUFHE_AMD_DIAGNOSTIC_BUILD"] + [f"-DCUFHE_AMD_ABL_{d}" for d in diagnostic], extra)
+        return _compile_and_link(out or DIAG_OUT, ["-DCUFHE_AMD_DIAGNOSTIC_BUILD"] + [f"-DCUFHE_AMD_ABL_{d}" for d in diagnostic], extra)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     return _compile_and_link(OUT, (), extra, verbose)
+
+
+def build_fault_injection(force=False):
+    """libcufhe_amd_diag_ll2_timeout.so, rebuilt when any source is newer."""
+    if not force and os.path.exists(FAULT_OUT) and all(os.path.getmtime(FAULT_OUT) >= os.path.getmtime(d) for d in DEPS):
+        return FAULT_OUT
+    return build(diagnostic=["LL2_TIMEOUT"], out=FAULT_OUT)
 
 
 if __name__ == "__main__":

@@ -59,6 +59,9 @@ struct DeviceState {
     Ntt512Tables* tables512 = nullptr;   // [3]: the two 512-point halves (low-latency kernel), stand-alone N = 512
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
+    // device fault word: pinned, host-coherent, mapped into the device (kernels_common.hip.h: kFault*); sticky until CleanUp
+    uint32_t* fault_host = nullptr;
+    uint32_t* fault = nullptr;
     bool profiling = false;
     bool br_lds_opt_in = false, ks_lds_opt_in = false;
     // N = 2048 / 64-bit torus (lvl2.inc.h)
@@ -230,8 +233,31 @@ int ensure_ntt(int device)
     build_tables_512(host512);
     HIP_TRY(hipMalloc((void**)&s.tables512, sizeof(host512)));
     HIP_TRY(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
+    HIP_TRY(hipHostMalloc((void**)&s.fault_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *s.fault_host = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&s.fault, s.fault_host, 0));
     s.ntt_ready = true;
     return 0;
+}
+
+// A kernel that found its own result untrustworthy has set a bit in the device's fault word (today: the bounded LDS
+// rendezvous of blind_rotate_ll2_kernel).  Called wherever the host observes completion (Synchronize, StreamQuery,
+// StreamSynchronize, the scheduler's event polls): status -5 with text, where the reference would have printed
+// "CuCheckError() failed" and exited (include/details/error_gpu.cuh:40-60; the C++ shim aborts on any negative status).
+// Sticky, like a CUDA context error, until CleanUp().
+int device_fault(int device)
+{
+    DeviceState& s = g_dev[device];
+    if (!s.fault_host) return 0;
+    const uint32_t bits = __atomic_load_n(s.fault_host, __ATOMIC_ACQUIRE);
+    if (bits == 0) return 0;
+    std::string what;
+    if (bits & kFaultLl2SyncTimeout) what += " blind_rotate_ll2_kernel: the inverse waves' LDS rendezvous timed out;";
+    if (bits & ~kFaultLl2SyncTimeout) what += " unknown bits;";
+    char hex[16];
+    snprintf(hex, sizeof hex, "0x%x", bits);
+    return fail(-5, std::string("device ") + std::to_string(device) + " fault word " + hex + ":" + what +
+                        " ciphertexts produced since Initialize() are not trustworthy -- CleanUp() and Initialize() again");
 }
 
 
@@ -342,7 +368,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     auto launch_ll2 = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
         // two rotations per workgroup: the row phase of one beside the inverse transforms of the other (kernels_ll.hip.h)
         hipLaunchKernelGGL(blind_rotate_ll2_kernel, dim3((unsigned)((n + 1) / 2)), dim3(kLlThreads), kLl2LdsBytes, st, dd, (int)n,
-                           s.bk_ntt, s.tables512, steps, dump);
+                           s.bk_ntt, s.tables512, steps, dump, s.fault);
     };
     auto launch_small = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
         if (g_ll2_threshold > 0 && (long)n <= g_ll2_threshold) {
@@ -731,6 +757,7 @@ int cufhe_amd_cleanup(void)
         s.keys2_ready = s.br2_lds_opt_in = s.ks2_lds_opt_in = false;
         s.tables2 = nullptr; s.bk2_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables512)); }
+        if (s.fault_host) { (void)hipHostFree(s.fault_host); s.fault_host = nullptr; s.fault = nullptr; }   // the fault, if any, ends with the keys
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
         s.staging.clear();
         for (auto& kv : s.workspaces) (void)hipFree(kv.second.base);
@@ -752,6 +779,7 @@ int cufhe_amd_synchronize(void)
     for (int i = 0; i < g_gpu_num; i++) {
         HIP_TRY(hipSetDevice(phys_device(i)));
         HIP_TRY(hipDeviceSynchronize());
+        if (int rc = device_fault(i)) return rc;
     }
     return 0;
 }
@@ -792,7 +820,10 @@ int cufhe_amd_stream_query(int device, void* stream)
         if (q <= 0) return q;
     }
     hipError_t e = hipStreamQuery((hipStream_t)stream);
-    if (e == hipSuccess) return 1;
+    if (e == hipSuccess) {
+        if (int rc = device_fault(device)) return rc;
+        return 1;
+    }
     if (e == hipErrorNotReady) return 0;
     return fail(-2, std::string("hipStreamQuery: ") + hipGetErrorString(e));
 }
@@ -800,7 +831,7 @@ int cufhe_amd_stream_synchronize(int device, void* stream)
 {
     if (int rc = use_device(device)) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    return 0;
+    return device_fault(device);
 }
 
 int cufhe_amd_malloc(int device, size_t bytes, void** dptr)

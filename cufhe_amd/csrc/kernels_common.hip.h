@@ -48,6 +48,10 @@ struct LinDesc {
     uint32_t pad;
 };
 
+// Device fault word (one uint32 per device in host-visible memory, DeviceState::fault): bits a kernel sets when it
+// detects that its own result cannot be trusted.  The host turns any set bit into status -5 (capi.hip: device_fault).
+constexpr uint32_t kFaultLl2SyncTimeout = 1u;      // blind_rotate_ll2_kernel: the inverse waves' LDS rendezvous timed out
+
 // NTT-only kernels (key conversion, product check): 4 waves per workgroup
 constexpr int kNttWavesPerBlock = 4;
 constexpr int kNttThreads = 64 * kNttWavesPerBlock;

@@ -252,11 +252,11 @@ static_assert(kLl2LdsBytes <= 160 * 1024, "paired low-latency kernel does not fi
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump, uint32_t* fault);
 #ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
+    const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump, uint32_t* fault)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -350,17 +350,38 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     // other rotation and must not be held up by a workgroup barrier -- measured: with the tail of a step spread over all
     // sixteen waves behind two more barriers a round of 512 rotations takes 6 % longer): every wave adds 1, then waits
     // for 4 more than last time.  DS operations of a wave execute in order, so what it wrote before the add is in LDS
-    // when the count shows.  The wait is bounded (about 0.1 s; a correct run waits a few hundred cycles, and the waves
-    // of a workgroup are resident, and preempted, together) so that a logic error shows up as wrong words in the tests,
-    // not as a hung device.
+    // when the count shows.  A correct run waits a few hundred cycles (the waves of a workgroup are resident, and
+    // preempted, together).  The wait is bounded (2^20 polls with s_sleep, about 0.1 s) so that a logic error cannot hang
+    // the device -- and a wave whose wait expires REPORTS it: it sets kFaultLl2SyncTimeout in the device's fault word
+    // (host-visible memory; Synchronize / StreamQuery / every completion the scheduler observes return status -5 from
+    // then on, the C++ shim aborts) and poisons the counter, so that the workgroup drains at once instead of timing out
+    // 2 x 630 more times.  The words such a launch produced are wrong; nothing downstream may trust them, and with the
+    // status nothing has to find that out from a failed decryption.
     uint32_t* sync_cnt = (uint32_t*)(smem + kLl2LdsRot + 2 * kLl2RotBytes);
     uint32_t sync_target = 0;
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_LL2_TIMEOUT)
+    constexpr int kSyncSpins = 1 << 12;      // fault injection (tests/test_gpu_fault.py): wave 15 of workgroup 0 skips one arrival
+    int sync_calls = 0;
+#else
+    constexpr int kSyncSpins = 1 << 20;
+#endif
     auto inv_sync = [&]() {
         sync_target += 4;
-        if (lane == 0) __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (int spins = 0; spins < (1 << 20); spins++) {
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_LL2_TIMEOUT)
+        const bool skip = blockIdx.x == 0 && wave == 15 && ++sync_calls == 5;
+        if (lane == 0 && !skip)
+#else
+        if (lane == 0)
+#endif
+            __hip_atomic_fetch_add(sync_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int spins = 0;
+        for (; spins < kSyncSpins; spins++) {
             if (__hip_atomic_load(sync_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= sync_target) break;
             __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins == kSyncSpins && lane == 0) {
+            __hip_atomic_fetch_or(sync_cnt, 0x80000000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // every later wait passes
+            if (fault) __hip_atomic_fetch_or(fault, kFaultLl2SyncTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
     // inverse waves: the whole tail of rotation r's step -- half h of sum `out` (left in place of the sum for the

@@ -86,11 +86,15 @@ class HipBackend : public sched::Backend {
     int event_query(void* ev) override
     {
         const hipError_t e = hipEventQuery((hipEvent_t)ev);
-        if (e == hipSuccess) return 1;
+        if (e == hipSuccess) return fault_or(1);
         if (e == hipErrorNotReady) return 0;
         return chk(e, "hipEventQuery");
     }
-    int event_sync(void* ev) override { return chk(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"); }
+    int event_sync(void* ev) override
+    {
+        if (int rc = chk(hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize")) return rc;
+        return fault_or(0);
+    }
     int stream_wait(int s, void* ev) override
     {
         hipStream_t st;
@@ -122,6 +126,12 @@ class HipBackend : public sched::Backend {
     }
 
    private:
+    // completion observed: a kernel may have reported through the device's fault word (capi.hip: device_fault)
+    int fault_or(int ok)
+    {
+        if (int rc = device_fault(device_)) return keep(rc);
+        return ok;
+    }
     int chk(hipError_t e, const char* what)
     {
         if (e == hipSuccess) return 0;
