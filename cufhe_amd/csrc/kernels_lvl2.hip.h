@@ -184,6 +184,11 @@ constexpr int k2LdsBytes = k2LdsTb + 2 * k2TbBytes;              // 158480
 
 __device__ __forceinline__ void load_key_poly(double2 (&b)[8], const double* poly, int lane)
 {
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_BK)       // timing-only: no key loads
+#pragma unroll
+    for (int q = 0; q < 8; q++) b[q] = make_double2(1234567.0 + q + (double)(uintptr_t)poly * 1e-30, 7654321.0 + lane);
+    return;
+#endif
     const double2* p = (const double2*)poly;
 #pragma unroll
     for (int q = 0; q < 8; q++) b[q] = p[q * 64 + lane];
@@ -193,6 +198,14 @@ __device__ __forceinline__ void load_key_poly(double2 (&b)[8], const double* pol
 __device__ __forceinline__ void accumulate_poly(double* sums, const double (&x)[kRegs], const double2 (&b)[8], int lane)
 {
     double* s0 = sums + lane;
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_L2_NOATOM)       // timing-only: plain stores instead of LDS atomics
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        s0[(2 * q) * 64] = fpf::mulmod(x[2 * q], b[q].x);
+        s0[(2 * q + 1) * 64] = fpf::mulmod(x[2 * q + 1], b[q].y);
+    }
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         __hip_atomic_fetch_add(s0 + (2 * q) * 64, fpf::mulmod(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -200,7 +213,7 @@ __device__ __forceinline__ void accumulate_poly(double* sums, const double (&x)[
     }
 }
 
-__global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
+__global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_v2_kernel(
     const RotDesc2* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const NttTables* __restrict__ gt2, int steps, uint64_t* __restrict__ acc_dump)
 {
@@ -434,6 +447,348 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         for (int e = tid; e < k2N; e += k2Threads) {
             if (e == 0) { o[0] = accL[0]; o[k2N] = accL[k2N]; }
             else o[k2N - e] = 0ull - accL[e];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Blind rotate lvl02 + sample extract, round-3 schedule (same arithmetic, same words as the kernel above).
+//
+// What the per-phase cycle counters of the kernel above showed (tools/lvl2_phases.py, profiles/r03_lvl2_phases_before.txt):
+// the two waves of a SIMD run the same phase, the older one is served first, finishes its forward transform and products
+// while the younger one transforms, and then waits at the barrier while the younger one runs its products ALONE -- a phase
+// bound by the CU's vector-memory path (768 KiB of key per step at 64 B/clk = 12.3 k of the step's 56.8 k cycles; without key
+// loads the step takes 48.0 k, without LDS atomics as long as with them).  The barrier between the halves (the six sums were
+// one region, reused) re-aligned the waves twice per step, and the twelve inverse jobs left SIMDs half empty.  Here:
+//   * the accumulator lives in REGISTERS (wave (j, c) owns the pairs (e, e + 1024), e = 256 c + lane + 64 m, of acc_j: the
+//     pairs it decomposes) and the transposes go through half-size tiles (ntt_wave.h: xpose_half_tile), which frees 65 KiB
+//     of LDS: the sums of the two halves get a region each, so a wave runs forward-products-forward-products without a
+//     barrier and the two waves of a SIMD fall into anti-phase by themselves (one transforms while the other streams key);
+//   * inverse jobs: phase A = the six of output 1 and two of output 0, phase B = the other four of output 0 on waves 0-3
+//     while waves 4-7 -- the owners of acc_1 -- recombine output 1 (last stage, lift, the three limbs shifted and summed in
+//     registers: no 64-bit LDS atomics), phase C = waves 0-3 recombine output 0; the results stay where the sums were;
+//   * the first key polynomials of the next step are requested at the start of phase B, when nothing else uses the
+//     vector-memory path;
+//   * the rotated read of the decomposition needs the accumulator in LDS: the owners leave a copy in two sum regions
+//     that are idle at that point (output 1's, consumed in phase B), zeroed again after the reads.
+// Six workgroup barriers per step as before.
+// LDS: 8 half tiles 33 KiB, sums 2 x 48 KiB, abar list, stage 4-7 twiddles 7.5 KiB, stage 8-9 forward twiddles 12 KiB
+// (the inverse ones, 12 KiB more, do not fit and stay in global memory: no key load is in flight when they are read) = 153 360 B.
+// ----------------------------------------------------------------------------------
+constexpr int k3LdsTiles = 0;
+constexpr int k3LdsSum = k3LdsTiles + 8 * kHalfTileBytes;        // 33792: [half][out * 3 + limb][1024] f64
+constexpr int k3SumDoubles = k2Prods * k2Half;                   // 6144 per half
+constexpr int k3LdsAbar = k3LdsSum + 2 * k3SumDoubles * 8;       // + 98304
+constexpr int k3LdsTb = k3LdsAbar + kAbarBytes + 16;
+constexpr int k3LdsTc = k3LdsTb + 2 * k2TbBytes;                 // stage 8-9 forward twiddles of both halves: [h][12][64]
+constexpr int k3TcBytes = kTcCount * 64 * 8;                     // 6144 per half
+constexpr int k3LdsTu = k3LdsTc + 2 * k3TcBytes;                 // stage 0-3 twiddles: [h][tu_fwd[16] | tu_inv[16]]
+constexpr int k3LdsBytes = k3LdsTu + 2 * 256;                    // 153872
+static_assert(k3LdsBytes <= 160 * 1024, "lvl2 blind rotate does not fit the CU's LDS");
+static_assert(2 * k2Half * 8 <= 2 * k2Half * 8 && 2 * k2N * 8 <= 2 * 2 * k2Half * 8, "accumulator copy fits two sum polynomials per component");
+
+__global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
+    const RotDesc2* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
+    const NttTables* __restrict__ gt2, int steps, uint64_t* __restrict__ acc_dump)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double* sumL = (double*)(smem + k3LdsSum);                // [h][out * 3 + limb][reg][lane]
+    uint16_t* abar_lds = (uint16_t*)(smem + k3LdsAbar);
+    uint32_t* bbar_slot = (uint32_t*)(smem + k3LdsAbar + kAbarBytes);
+
+    const RotDesc2 d = descs[g];
+    for (int i = tid; i <= kLvl0N; i += k2Threads) {
+        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
+        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - k2Nbit))) >> (32 - 1 - k2Nbit));
+        else *bbar_slot = 2 * k2N - ((c + d.off) >> (32 - 1 - k2Nbit));
+    }
+    for (int i = tid; i < 2 * k3SumDoubles; i += k2Threads) sumL[i] = 0.0;
+    for (int i = tid; i < 2 * 2 * kTbCount * 16; i += k2Threads) {     // tb_fwd and tb_inv are contiguous in NttTables
+        const int h = i / (2 * kTbCount * 16), k = i % (2 * kTbCount * 16);
+        ((double*)(smem + k3LdsTb))[i] = gt2[h].tb_fwd[k];
+    }
+    for (int i = tid; i < 2 * kTcCount * 64; i += k2Threads) {
+        const int h = i / (kTcCount * 64), k = i % (kTcCount * 64);
+        ((double*)(smem + k3LdsTc))[i] = gt2[h].tc_fwd[k];
+    }
+    if (tid < 64) ((double*)(smem + k3LdsTu))[tid] = gt2[tid >> 5].tu_fwd[tid & 31];     // tu_fwd[16], tu_inv[16] are contiguous
+    __syncthreads();
+
+    const int wj = wave / k2L, wd = wave % k2L;               // TRGSW row (wj, wd); owner of acc_wj at e = 256 wd + lane + 64 m (+ 1024)
+    const int e_first = 256 * wd + lane;
+    // accumulator: RotatedTestVector<lvl2param>, include/gatebootstrapping_gpu.cuh:29-52
+    uint64_t acc_lo[4], acc_hi[4];
+    {
+        const uint32_t bbar = *bbar_slot;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint32_t e0 = (uint32_t)(e_first + 64 * m), e1 = e0 + k2Half;
+            const bool n0 = (bbar != 2 * k2N) && ((e0 < (bbar & (k2N - 1))) != ((bbar >> k2Nbit) != 0));
+            const bool n1 = (bbar != 2 * k2N) && ((e1 < (bbar & (k2N - 1))) != ((bbar >> k2Nbit) != 0));
+            acc_lo[m] = wj ? (n0 ? 0ull - k2Mu : k2Mu) : 0ull;
+            acc_hi[m] = wj ? (n1 ? 0ull - k2Mu : k2Mu) : 0ull;
+        }
+    }
+    // the LDS copy of acc_j for the rotated reads: the first two sum polynomials of output 1, half j
+    char* stage = smem + k3LdsSum + (wj * k3SumDoubles + 3 * k2Half) * 8;
+    auto publish_acc = [&]() {
+        char* o = stage + opaque(8 * e_first);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            *(uint64_t*)(o + 512 * m) = acc_lo[m];
+            *(uint64_t*)(o + 512 * m + 8 * k2Half) = acc_hi[m];
+        }
+    };
+    WaveCtx ctx_tile;
+    {
+        const int lam8 = lane & 7, hi = lane >> 4;
+        const int tile_off = k3LdsTiles + wave * kHalfTileBytes;
+        ctx_tile.a65 = smem + opaque(tile_off + 8 * lane);
+        ctx_tile.a66 = ctx_tile.a65;
+        ctx_tile.b65 = smem + opaque(tile_off + 8 * (65 * lam8 + hi));
+        ctx_tile.b66 = smem + opaque(tile_off + 8 * (66 * lam8 + hi));
+        ctx_tile.tb_fwd = ctx_tile.tb_inv = ctx_tile.tc_fwd = ctx_tile.tc_inv = nullptr;
+        ctx_tile.gt = gt2;
+    }
+    // table addresses of half hh, rebuilt where needed (a few address adds) instead of being carried through the step
+    auto half_ctx = [&](int hh) {
+        WaveCtx c = ctx_tile;
+        int o16 = 8 * (lane & 15), o64 = 8 * lane;
+        asm volatile("" : "+v"(o16), "+v"(o64));
+        const NttTables* gth = gt2 + hh;
+        c.tb_fwd = smem + (k3LdsTb + hh * k2TbBytes) + o16;
+        c.tb_inv = c.tb_fwd + 8 * kTbCount * 16;
+        c.tc_fwd = smem + (k3LdsTc + hh * k3TcBytes) + o64;
+        c.tc_inv = (const char*)gth->tc_inv + o64;
+        c.gt = gth;
+        c.tu_l = smem + (k3LdsTu + hh * 256);
+        return c;
+    };
+    // inverse half-transform of sum (o, hh), left in place in natural order.  The stage 9-8 twiddles come from global
+    // memory (no room in LDS): they are requested ahead of the barrier in front of the job (load_twc).
+    double twc[kTcCount];
+    auto load_twc = [&](int hh) {
+        int o64 = 8 * lane;
+        asm volatile("" : "+v"(o64));
+        const char* t = (const char*)gt2[hh].tc_inv + o64;
+#pragma unroll
+        for (int k = 0; k < kTcCount; k++) twc[k] = *(const double*)(t + 512 * k);
+    };
+    auto inverse_job = [&](int o, int hh) {
+        const WaveCtx ctx = half_ctx(hh);
+        double* s = sumL + hh * k3SumDoubles + o * k2Half + lane;
+        double A[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) A[r] = fpf::reduce(s[r * 64]);
+        ntt_inverse_twc<true, true>(A, ctx, twc);           // |A| <= 2 p, natural order
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) s[r * 64] = A[r];
+    };
+    // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, of the three limbs of output wj at this wave's pairs,
+    // centred lift, limbs shifted and summed into the accumulator registers; the sums are left zero for the next step
+    auto recombine = [&]() {
+        double* s0 = sumL + wj * k2Limbs * k2Half + e_first;
+        double u0[k2Limbs][4], u1[k2Limbs][4];
+#pragma unroll
+        for (int l = 0; l < k2Limbs; l++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                u0[l][m] = s0[l * k2Half + 64 * m];
+                u1[l][m] = s0[k3SumDoubles + l * k2Half + 64 * m];
+            }
+#pragma unroll
+        for (int l = 0; l < k2Limbs; l++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                s0[l * k2Half + 64 * m] = 0.0;
+                s0[k3SumDoubles + l * k2Half + 64 * m] = 0.0;
+                const double lo = fpf::reduce(u0[l][m] + u1[l][m]);
+                const double hi = fpf::reduce(fpf::mulmod(u0[l][m] - u1[l][m], -fpf::ROOT4));
+                acc_lo[m] += to_u64(lo) << (k2LimbBits * l);
+                acc_hi[m] += to_u64(hi) << (k2LimbBits * l);
+            }
+    };
+
+    double2 kb[3][8];
+    uint32_t warm = 0;
+#define CUFHE_AMD_KEYPOLY3(key, k) ((key) + (size_t)((k) / k2Prods) * (k2BkRows * k2Prods * k2Half) + ((k) % k2Prods) * k2Half)
+    auto prefetch_key = [&](int step) {
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)
+        const double* key = bk_ntt + (size_t)(step & 1) * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#else
+        const double* key = bk_ntt + (size_t)step * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#endif
+        load_key_poly(kb[0], CUFHE_AMD_KEYPOLY3(key, 0), lane);
+        load_key_poly(kb[1], CUFHE_AMD_KEYPOLY3(key, 1), lane);
+    };
+    if (steps > 0) prefetch_key(0);
+    publish_acc();
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    // timing-only: cycles of this wave per phase: [0] copy visible (barrier), [1] rotated reads + barrier, [2] digits + barrier,
+    // [3] fwd h0, [4] prod h0, [5] fwd h1, [6] prod h1, [7] barrier, [8] inverse A, [9] barrier, [10] phase B, [11] barrier, [12] phase C
+    unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define CUFHE_AMD_PHASE3(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
+#else
+#define CUFHE_AMD_PHASE3(k)
+#endif
+#pragma unroll 1
+    for (int i = 0; i < steps; i++) {
+        __syncthreads();                                      // every owner's copy of the accumulator is in LDS
+        CUFHE_AMD_PHASE3(0)
+        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
+        const int alo = (int)(abar & (k2N - 1));
+        const bool ahi = (abar >> k2Nbit) != 0;
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)
+        const double* key = bk_ntt + (size_t)(i & 1) * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#else
+        const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
+#endif
+        // Decomposition of (X^abar - 1) acc_wj at this wave's pairs, all four digits; digit d, packed per pair, goes to the
+        // (idle) transpose tile of wave (wj, d).
+        uint32_t ab[kRegs];
+        {
+            uint64_t rot0[4], rot1[4];
+            const int rb = (e_first - alo) & (k2N - 1);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int i0 = (rb + 64 * m) & (k2N - 1);
+                rot0[m] = *(const uint64_t*)(stage + 8 * i0);
+                rot1[m] = *(const uint64_t*)(stage + 8 * (i0 ^ k2Half));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                  // all rotated reads done: the copy is dead
+            CUFHE_AMD_PHASE3(1)
+            {   // the two sum polynomials the copy occupied are zero again before any product is added (barrier below)
+                char* z = smem + k3LdsSum + ((wave >> 2) * k3SumDoubles + 3 * k2Half) * 8 + opaque((wave & 3) * 4096 + 16 * lane);
+#pragma unroll
+                for (int t = 0; t < 4; t++) *(double2*)(z + 1024 * t) = make_double2(0.0, 0.0);
+            }
+            char* dig_out = smem + opaque(k3LdsTiles + (wj * k2L) * kHalfTileBytes + 4 * e_first);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int e0 = e_first + 64 * m;
+                const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
+                const uint64_t t0 = ((neg0 ? 0ull - rot0[m] : rot0[m]) - acc_lo[m] + decomp_offset2()) ^ decomp_signmask2();
+                const uint64_t t1 = ((neg1 ? 0ull - rot1[m] : rot1[m]) - acc_hi[m] + decomp_offset2()) ^ decomp_signmask2();
+#pragma unroll
+                for (int dd = 0; dd < k2L; dd++) {
+                    constexpr int kTop = 64 - k2Bgbit;
+                    const int pos = kTop - k2Bgbit * dd;
+                    uint32_t a, b;
+                    if (pos >= 32) {
+                        a = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t0 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
+                        b = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t1 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
+                    } else {
+                        a = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t0 >> 32), (uint32_t)t0, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
+                        b = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), (uint32_t)t1, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
+                    }
+                    *(uint32_t*)(dig_out + dd * kHalfTileBytes + 256 * m) = __builtin_amdgcn_perm(b, a, 0x05040100u);   // (a & 0xffff) | (b << 16)
+                }
+            }
+            __syncthreads();
+            const char* dig_in = smem + opaque(k3LdsTiles + wave * kHalfTileBytes + 4 * lane);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) ab[r] = *(const uint32_t*)(dig_in + 256 * r);
+        }
+        CUFHE_AMD_PHASE3(2)
+        // forward transform and products of both halves, no barrier in between: sums[h] has its own region
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const WaveCtx ctx = half_ctx(h);
+            double tu[15];
+            load_tu(tu, ctx.tu_l);               // in flight while the digits are unpacked
+            double x[kRegs];
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) {
+                uint32_t w = ab[r];
+                asm volatile("" : "+v"(w));      // re-derive per half: keeps 16 registers live, not 64
+                const double a = (double)(int)(int16_t)(w & 0xffffu), b = (double)((int)w >> 16);
+                x[r] = __builtin_fma(h ? -b : b, fpf::ROOT4, a);      // first forward stage, exact: |I b| < 2^33
+            }
+            ntt_forward_a_tu<false>(x, tu);
+            ntt_forward_bc<true, true>(x, ctx);
+#pragma unroll
+            for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
+            CUFHE_AMD_PHASE3(3 + 2 * h)
+#pragma unroll
+            for (int pp = 0; pp < k2Prods; pp++) {
+                const int k = k2Prods * h + pp;            // compile-time: both loops are unrolled
+                if (k + 2 < 2 * k2Prods) load_key_poly(kb[(k + 2) % 3], CUFHE_AMD_KEYPOLY3(key, k + 2), lane);
+                accumulate_poly(sumL + h * k3SumDoubles + pp * k2Half, x, kb[k % 3], lane);
+            }
+            CUFHE_AMD_PHASE3(4 + 2 * h)
+        }
+        load_twc(wave >= 5 ? 1 : 0);
+        __syncthreads();                                      // the twelve sums are complete
+        CUFHE_AMD_PHASE3(7)
+        // inverse jobs, phase A: all of output 1 and two of output 0
+        {
+            const int o = wave == 0 ? 0 : wave == 1 ? 1 : 3 + (wave - 2) % 3;
+            const int hh = wave >= 5 ? 1 : 0;
+            if (hh) inverse_job(o, 1);
+            else inverse_job(o, 0);
+        }
+        if (wave < 4) load_twc(wave == 0 ? 0 : 1);
+        CUFHE_AMD_PHASE3(8)
+        __syncthreads();
+        CUFHE_AMD_PHASE3(9)
+        // phase B: waves 0-3 finish output 0, waves 4-7 recombine output 1 into their accumulator registers; then the key of
+        // the next step is requested (idle vector-memory path; behind the jobs, whose loads would queue behind the key's)
+        if (wave < 4) {
+            if (wave == 0) inverse_job(2, 0);
+            else inverse_job(wave - 1, 1);
+        } else {
+            recombine();
+        }
+        if (i + 1 < steps) prefetch_key(i + 1);
+        // L2 warming: the 32 workgroups that share an XCD (blocks b, b + 8, ...: round-robin dispatch, for speed only) walk
+        // the key together, and whoever touches a line first waits for the fabric.  Each workgroup touches 1/32 of the key of
+        // step i + 2 (one 4-byte load per 128-byte line: 768 KiB / 32 = 192 lines = 3 wave-loads on wave 7), so that the
+        // XCD's L2 holds the whole step before anyone needs it (measured: 1 % of the launch).
+        if (wave == 7 && i + 2 < steps) {
+            const char* nk = (const char*)(bk_ntt + (size_t)(i + 2) * k2BkStepDoubles) + (size_t)((blockIdx.x >> 3) & 31) * 24576 + lane * 128;
+            warm = *(const volatile uint32_t*)nk + *(const volatile uint32_t*)(nk + 8192) + *(const volatile uint32_t*)(nk + 16384);
+        }
+        CUFHE_AMD_PHASE3(10)
+        __syncthreads();
+        CUFHE_AMD_PHASE3(11)
+        // phase C: waves 0-3 recombine output 0; everyone leaves a copy of its accumulator for the next rotated read
+        if (wave < 4) recombine();
+        publish_acc();
+        CUFHE_AMD_PHASE3(12)
+    }
+#undef CUFHE_AMD_KEYPOLY3
+
+    asm volatile("" :: "v"(warm));      // keeps the warming loads alive
+    if (acc_dump) {
+        uint64_t* o = acc_dump + (size_t)g * 2 * k2N + wj * k2N + e_first;
+#pragma unroll
+        for (int m = 0; m < 4; m++) { o[64 * m] = acc_lo[m]; o[64 * m + k2Half] = acc_hi[m]; }
+    }
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    if (acc_dump && lane == 0 && g == 0) {
+        __syncthreads();
+        unsigned long long* o = (unsigned long long*)acc_dump + 2048 + wave * 16;     // overwrites part of the dump: timing only
+        for (int k = 0; k < 16; k++) o[k] = ph[k];
+    }
+#endif
+    if (d.out) {   // __SampleExtractIndex__<lvl2param,0>, src/bootstrap_gpu.cu:366-381
+        uint64_t* o = d.out;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int e0 = e_first + 64 * m, e1 = e0 + k2Half;
+            if (wj) {
+                if (e0 == 0) o[k2N] = acc_lo[m];
+            } else {
+                if (e0 == 0) o[0] = acc_lo[m];
+                else o[k2N - e0] = 0ull - acc_lo[m];
+                o[k2N - e1] = 0ull - acc_hi[m];
+            }
         }
     }
 }

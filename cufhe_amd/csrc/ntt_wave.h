@@ -139,6 +139,11 @@ struct WaveCtx {
     const char* tc_fwd;   // LDS tables + 8*lane    (+ 512*k)
     const char* tc_inv;
     const NttTables* gt;  // global tables (uniform scalars)
+    // optional: [tu_fwd[16] | tu_inv[16]] in LDS (256 bytes).  Read through the scalar cache at their use (TwUniform) the
+    // stage 0-3 twiddles cost an s_load followed at once by s_waitcnt lgkmcnt(0) -- the scalar-load latency exposed AND the
+    // wave's LDS reads drained -- in every transform; as broadcast LDS reads issued ahead of the transpose in front of
+    // their phase (TU_LDS variants below) they cost nothing.
+    const char* tu_l;
 };
 
 // A byte offset the compiler cannot see through: `lds + opaque(off)` keeps the full per-lane
@@ -166,6 +171,7 @@ __device__ __forceinline__ WaveCtx make_wave_ctx(char* lds, int tile_off, int ta
     c.tc_fwd = lds + opaque(tables_off + 8 * (2 * kTbCount * 16) + 8 * lane);
     c.tc_inv = c.tc_fwd + 8 * (kTcCount * 64);
     c.gt = gt;
+    c.tu_l = nullptr;
     return c;
 }
 
@@ -292,6 +298,44 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
     }
 #endif
 
+// The same two layout changes through a HALF-SIZE tile (8 rows of pitch 66: 4224 bytes) in two passes of eight
+// registers: pass p moves the elements with e[9] = p.  A -> B: all lanes store registers 8p .. 8p + 7 as rows 0 .. 7, then
+// the lanes whose layout-B row e[9:6] has e[9] = p (lane bit 3) read their sixteen registers; B -> A: those lanes store
+// their sixteen registers, then all lanes read registers 8p .. 8p + 7.  Twice the DS instructions on one side (half of
+// them with half the lanes), no VALU instruction more; for kernels whose LDS is the scarce resource (kernels_lvl2.hip.h).
+// WaveCtx for it: make_wave_ctx_half (b65 / b66 built from e[8:6]).
+constexpr int kHalfTileBytes = 66 * 8 * 8;   // 4224
+template <bool A_TO_B>
+__device__ __forceinline__ void xpose_half_tile(double (&x)[kRegs], char* abase, char* bbase)
+{
+    const bool upper = (threadIdx.x & 8) != 0;      // e[9] of this lane's layout-B row
+    double y[kRegs];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        asm volatile("" ::: "memory");
+        if (A_TO_B) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) lds_st(abase, 8 * 66 * r, x[8 * p + r]);
+            asm volatile("" ::: "memory");
+            if (upper == (p == 1)) {
+#pragma unroll
+                for (int k = 0; k < kRegs; k++) y[k] = lds_ld(bbase, 32 * k);
+            }
+        } else {
+            if (upper == (p == 1)) {
+#pragma unroll
+                for (int k = 0; k < kRegs; k++) lds_st(bbase, 32 * k, x[k]);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 8; r++) y[8 * p + r] = lds_ld(abase, 8 * 65 * r);
+        }
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < kRegs; r++) x[r] = y[r];
+}
+
 // ---- layout change B <-> C without LDS -------------------------------------------------
 // B: lane = lambda | g << 4, reg = 4 h + m      C: lane = lambda | h << 4, reg = 4 m + g
 // (g = e[1:0], h = e[5:4], m = e[3:2]).  For every m this is a 4 x 4 transpose between the
@@ -375,15 +419,28 @@ __device__ __forceinline__ void ntt_forward_a(double (&x)[kRegs], const WaveCtx&
 {
     ct_four_stages<SMALL_IN>(x, TwUniform{c.gt->tu_fwd});
 }
+// the same with the fifteen stage 0-3 twiddles in registers: load_tu(tu, c.tu_l) / load_tu(tu, c.tu_l + 128) for the
+// inverse, placed by the caller far enough ahead of the transform
+__device__ __forceinline__ void load_tu(double (&tu)[15], const char* tu_lds)
+{
+#pragma unroll
+    for (int k = 0; k < 15; k++) tu[k] = lds_ld(tu_lds, 8 * k);
+}
+template <bool SMALL_IN>
+__device__ __forceinline__ void ntt_forward_a_tu(double (&x)[kRegs], const double (&tu)[15])
+{
+    ct_four_stages<SMALL_IN>(x, TwArr{tu});
+}
 // forward, phases B and C: out in layout C (spectrum order).  WIDE8: stage 8 inputs may
 // exceed 5.142 p (true for 32-bit inputs, not for gadget digits).
-template <bool WIDE8>
+template <bool WIDE8, bool HALF_TILE = false>
 __device__ __forceinline__ void ntt_forward_bc(double (&x)[kRegs], const WaveCtx& c)
 {
     double twb[kTbCount];
 #pragma unroll
     for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_fwd, 128 * k);
-    CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
+    if (HALF_TILE) xpose_half_tile<true>(x, c.a66, c.b66);
+    else CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
     ct_four_stages<false>(x, TwArr{twb});
     double twc[kTcCount];
 #pragma unroll
@@ -398,36 +455,45 @@ __device__ __forceinline__ void ntt_forward_bc(double (&x)[kRegs], const WaveCtx
     for (int g = 0; g < 8; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], twc[4 + g]);
 }
 // SMALL_IN: the input is a gadget-digit polynomial (|x| <= 32); otherwise 32-bit words
-template <bool SMALL_IN>
+template <bool SMALL_IN, bool HALF_TILE = false>
 __device__ __forceinline__ void ntt_forward(double (&x)[kRegs], const WaveCtx& c)
 {
     ntt_forward_a<SMALL_IN>(x, c);
-    ntt_forward_bc<!SMALL_IN>(x, c);
+    ntt_forward_bc<!SMALL_IN, HALF_TILE>(x, c);
 }
 
 // inverse: x in layout C with |x| <= p/2, out in layout A with |x| <= 2p, NOT scaled by
 // 1/N (N^-1 is folded into the NTT-domain bootstrapping key)
-__device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c)
+// twc: the twelve stage 9-8 twiddles of this lane (c.tc_inv + 512 k), fetched by the caller -- ahead of a barrier, say
+template <bool HALF_TILE = false, bool TU_LDS = false>
+__device__ __forceinline__ void ntt_inverse_twc(double (&x)[kRegs], const WaveCtx& c, const double (&twc)[kTcCount])
 {
-    {
-        double twc[kTcCount];
 #pragma unroll
-        for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
+    for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], twc[4 + g]);
 #pragma unroll
-        for (int g = 0; g < 8; g++) gs_bfly<false>(x[2 * g], x[2 * g + 1], twc[4 + g]);
+    for (int g = 0; g < 4; g++) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-#pragma unroll
-            for (int r = 0; r < 2; r++) gs_bfly<false>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
-        }
+        for (int r = 0; r < 2; r++) gs_bfly<false>(x[4 * g + r], x[4 * g + r + 2], twc[g]);
     }
     double twb[kTbCount];
 #pragma unroll
     for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_inv, 128 * k);
     xpose_cb_permlane(x);                            // C -> B in registers
     gs_four_stages(x, TwArr{twb});
-    CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
-    gs_four_stages(x, TwUniform{c.gt->tu_inv});
+    double tu[15];
+    if (TU_LDS) load_tu(tu, c.tu_l + 128);           // in flight during the transpose
+    if (HALF_TILE) xpose_half_tile<false>(x, c.a65, c.b65);
+    else CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
+    if (TU_LDS) gs_four_stages(x, TwArr{tu});
+    else gs_four_stages(x, TwUniform{c.gt->tu_inv});
+}
+template <bool HALF_TILE = false, bool TU_LDS = false>
+__device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c)
+{
+    double twc[kTcCount];
+#pragma unroll
+    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
+    ntt_inverse_twc<HALF_TILE, TU_LDS>(x, c, twc);
 }
 
 }  // namespace cufhe_amd

@@ -13,7 +13,12 @@ ksk = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.
 eng.SetGPUNum(1)
 eng.api.lvl2_initialize(bk, ksk)
 n, N = int(p2.n), int(p2.N)
-names = ["decompose", "fwd h0", "prod h0", "barrier", "sums h0 -> regs", "fwd h1", "prod h1", "barrier", "inverse A", "barrier", "inverse B + recombine", "barrier"]
+kernel = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+eng.api.set_option("lvl2_kernel", kernel)
+if kernel == 2:
+    names = ["decompose", "fwd h0", "prod h0", "barrier", "sums h0 -> regs", "fwd h1", "prod h1", "barrier", "inverse A", "barrier", "inverse B + recombine", "barrier"]
+else:
+    names = ["barrier", "rot reads+barrier", "digits+barrier", "fwd h0", "prod h0", "fwd h1", "prod h1", "barrier", "inverse A", "barrier", "phase B", "barrier", "phase C"]
 for count in (1, 4096):
     tl = rng.integers(0, 2**32, size=(count, n + 1), dtype=np.uint64).astype(np.uint32)
     d = eng.api.DeviceBuffer(tl.size).upload(tl)
@@ -24,6 +29,6 @@ for count in (1, 4096):
     w = acc.download()[: 2 * N * 2].view(np.uint64)
     print(f"--- {count} rotation(s): cycles per step (630 steps), workgroup 0, by wave")
     for wave in range(8):
-        c = w[2048 + wave * 16: 2048 + wave * 16 + 12] / 630.0
+        c = w[2048 + wave * 16: 2048 + wave * 16 + len(names)] / 630.0
         print(f"wave {wave}: " + "  ".join(f"{nm} {v:6.0f}" for nm, v in zip(names, c)) + f"   total {c.sum():7.0f}")
 eng.CleanUp()
