@@ -97,31 +97,64 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS = 1024                              # 256 CUs x 4
 
 
+FP64_ISSUE_CYCLES_SPEC = 4.0              # data sheet: 64 lanes over a 16-lane FP64 pipe (78.6 TFLOP/s)
+FP64_ISSUE_CYCLES_MEASURED = 4.34         # tools/ubench/ubench_ilp.hip on MI355X: two waves per SIMD, v_fma_f64 back to back
+DEVICE_SOURCES = ("fpfield.h", "ntt_wave.h", "ntt_wave512.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_ll.hip.h",
+                  "kernels_lvl2.hip.h", "kernels_ks2.hip.h", "kernels_ps.hip.h")
+
+
 def source_hash():
-    """sha256 over the kernel / host sources: recorded PMC facts are only valid for the exact code."""
+    """sha256 over every file with device code: recorded PMC facts are only valid for the exact kernels."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cufhe_amd", "csrc")
-    # the device code of the two profiled kernels and what they include (host-side files do not change what a launch executes)
-    for f in ("fpfield.h", "ntt_wave.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_lvl2.hip.h"):
+    for f in DEVICE_SOURCES:
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
 
 
-def kernel_facts(kernel, rotations):
-    """HBM traffic and VALU counters per launch from the committed rocprofv3 PMC passes
-    (profiles/kernel_facts.json, written by tools/kernel_facts.py from separate --pmc runs of this
-    command).  None when the sources changed since, or for another launch shape."""
-    try:
-        facts = json.load(open(os.path.join(ROOT, "profiles", "kernel_facts.json")))
-    except Exception:
+_FACTS = None
+
+
+def kernel_facts(kernel):
+    """Counters of one kernel from the committed rocprofv3 PMC passes (profiles/kernel_facts.json, written by
+    tools/kernel_facts.py from separate --pmc runs of this command): instruction counts and HBM bytes per rotation, which
+    do not depend on the run; clocks and times always come from THIS run.  None when the device code changed since."""
+    global _FACTS
+    if _FACTS is None:
+        try:
+            _FACTS = json.load(open(os.path.join(ROOT, "profiles", "kernel_facts.json")))
+        except Exception:
+            _FACTS = {}
+    if not _FACTS:
         return None, "no recorded PMC passes"
-    if facts.get("source_sha256") != source_hash():
-        return None, "stale: cufhe_amd/csrc changed since the PMC passes were recorded (%s)" % facts.get("recorded", "?")
-    k = facts.get("kernels", {}).get(kernel)
-    if not k or k.get("rotations_per_launch") != rotations:
-        return None, "no PMC pass for this kernel / launch shape"
-    return k, facts.get("recorded", "")
+    if _FACTS.get("source_sha256") != source_hash():
+        return None, "stale: cufhe_amd/csrc changed since the PMC passes were recorded (%s)" % _FACTS.get("recorded", "?")
+    k = _FACTS.get("kernels", {}).get(kernel)
+    if not k:
+        return None, "no PMC pass for this kernel"
+    return k, _FACTS.get("recorded", "")
+
+
+def valu_block(kernel, rotations, launch_ms, clock_hz):
+    """What actually bounds these kernels: FP64 VALU issue.  Instruction count per rotation from the PMC pass (a property
+    of the code), launch time and shader clock from this run."""
+    facts, note = kernel_facts(kernel)
+    if not facts or launch_ms <= 0 or not clock_hz:
+        return {"pmc_source": note}
+    insts = facts["valu_insts_per_rotation"] * rotations
+    slots = SIMDS * clock_hz * launch_ms * 1e-3          # SIMD-cycles available in the launch
+    return {
+        "insts_per_rotation": facts["valu_insts_per_rotation"],
+        "insts_per_step_per_wave": facts.get("valu_insts_per_step_per_wave"),
+        "frac_of_fp64_issue": FP64_ISSUE_CYCLES_SPEC * insts / slots,
+        "frac_of_measured_issue_floor": FP64_ISSUE_CYCLES_MEASURED * insts / slots,
+        "clock_hz_this_run": clock_hz,
+        "pipe_busy_under_profiler": facts.get("valu_pipe_busy"),
+        "lds_bank_conflict_frac": facts.get("lds_bank_conflict_frac"),
+        "waves_per_simd": facts.get("waves_per_simd"),
+        "pmc_source": note,
+    }
 
 
 def oracle_check(ol, L, ek, ops, in0, in1, in2, gpu_out, idx):
@@ -289,31 +322,27 @@ def main():
         bk_bytes = BK2_BYTES_PER_ROTATION if l2 else BK_BYTES_PER_ROTATION
         kernel = "blind_rotate_lvl2_kernel" if l2 else "blind_rotate_kernel"
         achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
-        facts, note = kernel_facts(kernel, rotations)
+        facts, note = kernel_facts(kernel)
         r = {
-            "bound": "hbm", "kernel": kernel,
+            "bound": "valu_fp64", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "accounting": "BK sweep (SURVEY.md 8d): the bytes a cache-less sweep of the bootstrapping key would read; "
-                          "the measured HBM traffic is `traffic`, the actual limiter is FP64 VALU issue (`valu`)",
+            "accounting": "achieved/peak/frac price the launch with the BK sweep SURVEY.md 8(d) prescribes (the bytes a cache-less "
+                          "sweep of the bootstrapping key would read) against the HBM peak; the sweep is served by the XCD L2s "
+                          "(`traffic` = measured fabric/HBM bytes), so `bound` names what the kernel actually runs into: FP64 "
+                          "vector issue, priced in `valu`",
             "traffic": None, "traffic_unit": "bytes per launch",
             "launch_ms": br_ms, "rotations_per_launch": rotations, "algorithmic_bytes_per_rotation": bk_bytes,
             "keyswitch_launch_ms": ks_ms, "pmc_source": note,
         }
         if facts:
-            r["traffic"] = facts["hbm_bytes_per_launch"]
-            insts, clk = facts["valu_insts_per_launch"], facts["clock_hz"]
-            r["valu"] = {
-                "insts_per_step_per_wave": facts["valu_insts_per_step_per_wave"],
-                "pipe_busy": facts["valu_pipe_busy"],                      # under the profiler, from the PMC pass
-                "frac_of_fp64_issue": 4.0 * insts / (SIMDS * clk * br_ms * 1e-3),   # this run's launch time
-                "waves_per_simd": facts.get("waves_per_simd"),
-                "recorded_launch_ms": facts.get("launch_ms"),
-            }
+            r["traffic"] = facts["hbm_bytes_per_rotation"] * rotations
+        r["valu"] = valu_block(kernel, rotations, br_ms, clock_hz)
         return r
 
     wl = args.workload
     elapsed = distutil.max_over_ranks(timed(wl, args.steps, args.warmup), dist)
     br_ms, ks_ms = kernel_times(wl)
+    clock_hz = api.probe_clock()          # shader clock under an FP64 load, this box, this run (prices `valu`)
 
     extras_on = RANK == 0 and WORLD == 1 and not args.no_extra and not strong
     latency_ms = None
@@ -368,6 +397,9 @@ def main():
                                      env=dict(os.environ, HIP_VISIBLE_DEVICES=str(DEV)) if WORLD > 1 else None)
                 lines = [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
                 res["api_pcie_inclusive"] = lines[0]
+                # enqueue -> Synchronize with H2D/D2H of the ciphertexts inside the timed region
+                # (the reference's own way of timing, test/test_util.h:29-72); `value` above is the inputs-resident rate
+                res["value_pcie_inclusive"] = lines[0].get("gates_per_s")
                 if len(lines) > 1:
                     res["api_pcie_inclusive"]["depth_first_netlist"] = lines[1]
                 if len(lines) > 2:
@@ -399,6 +431,7 @@ def main():
                     rf = roofline(w2, b2, k2)
                     extra[w2] = {"value": count * 2 / dt, "unit": "gates/s", "ms_per_step": 1e3 * dt / 2,
                                  "blind_rotate_launch_ms": b2, "keyswitch_launch_ms": k2, "roofline_frac": rf["frac"],
+                                 "bound": rf["bound"], "valu": rf["valu"],
                                  "baseline_config": {"mux": "configs[3]", "mixed": "configs[2] op mix on one GPU"}[w2],
                                  "gpu_words_match_oracle": oracle_check(ol, L, oek, ops, in0, in1, in2, out2, idx)}
                 try:
@@ -416,10 +449,35 @@ def main():
                     rf = roofline("nand_lvl2", b2, k2)
                     extra["nand_lvl2"] = {"value": count * 2 / dt, "unit": "gate-bootstraps/s", "ms_per_step": 1e3 * dt / 2,
                                           "blind_rotate_launch_ms": b2, "keyswitch_launch_ms": k2, "roofline_frac": rf["frac"],
+                                          "bound": rf["bound"], "valu": rf["valu"],
                                           "roofline_traffic": rf["traffic"], "baseline_config": "configs[4]",
                                           "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, -1), out2[idx]))}
                 except Exception as e:
                     extra["nand_lvl2"] = {"error": repr(e)}
+                # a mid-sized launch (512 gates: one round of the paired low-latency kernel) and the key switch of the main batch
+                try:
+                    run_step("nand", 512)
+                    eng.Synchronize()
+                    api.profile_get(reset=True)
+                    api.profile_enable(True)
+                    for _ in range(3):
+                        run_step("nand", 512)
+                    eng.Synchronize()
+                    mp = api.profile_get(reset=True)
+                    api.profile_enable(False)
+                    mbr = mp.blind_rotate_ms / max(mp.blind_rotate_launches, 1)
+                    extra["nand_512"] = {"ms_per_step": mbr + mp.keyswitch_ms / max(mp.keyswitch_launches, 1),
+                                         "blind_rotate_launch_ms": mbr, "kernel": "blind_rotate_ll2_kernel", "bound": "valu_fp64",
+                                         "valu": valu_block("blind_rotate_ll2_kernel", 512, mbr, clock_hz)}
+                    kfacts, knote = kernel_facts("keyswitch_kernel")
+                    extra["keyswitch_4096"] = {"launch_ms": ks_ms, "kernel": "keyswitch_kernel", "bound": "lds",
+                                               "algorithmic_bytes": 4096 * 15507456,
+                                               "lds_pipe_busy_under_profiler": kfacts.get("lds_pipe_busy") if kfacts else None,
+                                               "valu_pipe_busy_under_profiler": kfacts.get("valu_pipe_busy") if kfacts else None,
+                                               "lds_bank_conflict_frac": kfacts.get("lds_bank_conflict_frac") if kfacts else None,
+                                               "pmc_source": knote}
+                except Exception as e:
+                    extra["nand_512"] = {"error": repr(e)}
                 # the other compiled parameter sets through the generic kernels (kernels_ps.hip.h),
                 # 4096 NAND on random keys, sampled words against the oracle compiled for the set
                 psets = {}
@@ -445,6 +503,14 @@ def main():
                             ps_step()
                         eng.Synchronize()
                         dt = (time.perf_counter() - t0) / 2
+                        # the blind-rotate launch alone, HIP events on the launch stream
+                        api.profile_get(reset=True)
+                        api.profile_enable(True)
+                        ps_step()
+                        eng.Synchronize()
+                        pprof = api.profile_get(reset=True)
+                        api.profile_enable(False)
+                        pbr_ms = pprof.blind_rotate_ms / max(pprof.blind_rotate_launches, 1)
                         got = pout.download().reshape(count, w)
                         Ls = oracle_lib.load_set(name)
                         eks = Ls.orc_evalkey_create(pbk, pksk)
@@ -458,7 +524,12 @@ def main():
                         psets[name] = {"params": f"n={pp.n} N={pp.N} k={pp.k} l={pp.l} Bgbit={pp.Bgbit} key_limbs={pp.key_limbs}",
                                        "value": count / dt, "unit": "gate-bootstraps/s", "ms_per_step": 1e3 * dt,
                                        "kernel": "blind_rotate_ps_batch_kernel<PS> (wave per rotation, written once over the set; not hand-scheduled)",
+                                       "blind_rotate_launch_ms": pbr_ms,
                                        "bk_sweep_frac_of_hbm_peak": count * bk_bytes / dt / 8e12,
+                                       "bound": "valu_fp64",
+                                       "note": "the sweep fraction is an accounting figure (SURVEY.md 8d), not a physical bound: the key is served by "
+                                               "the XCD L2s, so it may exceed 1; what the kernel runs into is FP64 issue, `valu`",
+                                       "valu": valu_block("blind_rotate_ps_batch_kernel<%s>" % name, count, pbr_ms, clock_hz),
                                        "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, w), got[idx]))}
                     except Exception as e:
                         psets[name] = {"error": repr(e)}

@@ -98,6 +98,7 @@ SIGNATURES = {
     "cufhe_amd_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_long]),
     "cufhe_amd_profile_enable": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cufhe_amd_profile_get": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(Profile), ctypes.c_int]),
+    "cufhe_amd_probe_clock": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "cufhe_amd_polymul512_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
     "cufhe_amd_bootstrap_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_ps_count": (ctypes.c_int, []),

@@ -360,6 +360,13 @@ def profile_enable(on=True, device=0):
     check(lib.cufhe_amd_profile_enable(device, 1 if on else 0))
 
 
+def probe_clock(device=0):
+    """Shader clock in Hz under an FP64 load, measured now (cufhe_amd_probe_clock)."""
+    hz = ctypes.c_double(0.0)
+    check(lib.cufhe_amd_probe_clock(device, ctypes.byref(hz)))
+    return hz.value
+
+
 def profile_get(device=0, reset=True):
     p = Profile()
     check(lib.cufhe_amd_profile_get(device, ctypes.byref(p), 1 if reset else 0))

@@ -326,6 +326,25 @@ int upload_descs(DeviceState& s, Scratch& sc, const std::vector<Desc>& h, Desc**
     return 0;
 }
 
+// HIP events around a launch sequence on its own stream (cufhe_amd_profile_enable): begin before, end after
+int prof_begin(DeviceState& s, hipStream_t st, EventPair& ev)
+{
+    if (!s.profiling) return 0;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, st));
+    return 0;
+}
+int prof_end(DeviceState& s, hipStream_t st, EventPair& ev, size_t units, bool keyswitch)
+{
+    if (!s.profiling || !ev.a) return 0;
+    HIP_TRY(hipEventRecord(ev.b, st));
+    ev.units = units;
+    std::lock_guard<std::mutex> lk(s.staging_mu);
+    (keyswitch ? s.ks_events : s.br_events).push_back(ev);
+    return 0;
+}
+
 int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count, int steps, uint32_t* acc_dump)
 {
     if (count == 0) return 0;
@@ -1144,6 +1163,24 @@ int cufhe_amd_profile_enable(int device, int on)
 {
     if (int rc = check_device(device)) return rc;
     g_dev[device].profiling = on != 0;
+    return 0;
+}
+
+int cufhe_amd_probe_clock(int device, double* hz)
+{
+    if (int rc = use_device(device)) return rc;
+    if (!hz) return fail(-1, "null");
+    constexpr int kBlocks = 256, kWaves = 8;
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (kBlocks * kWaves + 1) * sizeof(double)));
+    std::vector<double> h(kBlocks * kWaves);
+    for (int rep = 0; rep < 2; rep++)        // the second launch runs on a chip that is already under load
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(kBlocks), dim3(64 * kWaves), 0, 0, d, d + kBlocks * kWaves, 3000);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    std::sort(h.begin(), h.end());
+    *hz = h[h.size() / 2];
     return 0;
 }
 

@@ -58,6 +58,26 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_kernel(
 }
 
 // ----------------------------------------------------------------------------------
+// Shader clock under an FP64 load: every wave runs a dependent FMA chain for about a millisecond between two pairs of
+// stamps, shader cycles (s_memtime) over the constant 100 MHz counter (s_memrealtime).  A measurement aid for
+// cufhe_amd_probe_clock (bench.py prices its instruction counts with THIS run's clock, not a recorded one).
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void clock_probe_kernel(double* __restrict__ hz_out, double* __restrict__ sink, int iters)
+{
+    double x = 1.0 + threadIdx.x * 1e-9, y = 0.5;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x = __builtin_fma(x, 0.999999, y); y = __builtin_fma(y, 0.999999, x); }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (x + y == 12345.678) sink[0] = x;       // keeps the chain
+    if ((threadIdx.x & 63) == 0)
+        hz_out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (double)(c1 - c0) / (double)(r1 - r0) * 1.0e8;
+}
+
+// ----------------------------------------------------------------------------------
 // Blind rotate + sample extract, one wave per rotation.
 // ----------------------------------------------------------------------------------
 // acc_j -> (X^abar - 1) acc_j + gadget offset, include/gatebootstrapping_gpu.cuh:157-181.

@@ -28,6 +28,8 @@ template <class PS>
 int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count)
 {
     if (count == 0) return 0;
+    EventPair ev{};
+    if (int rc = prof_begin(s, st, ev)) return rc;
     const long wg_max = g_ks_wg_threshold < 0 ? kKsAutoWg : g_ks_wg_threshold;
     if ((long)count > wg_max && ps.ksk_padded) {
         // 16 ciphertexts per workgroup, table rows through LDS
@@ -46,11 +48,11 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
             hipLaunchKernelGGL(keyswitch_ps_shared_kernel<PS>, dim3(blocks), dim3(kKsThreads), PsKs<PS>::lds_bytes, st, d, (int)count, ps.ksk_padded);
         }
         HIP_TRY(hipGetLastError());
-        return 0;
+        return prof_end(s, st, ev, count, true);
     }
     hipLaunchKernelGGL(keyswitch_ps_kernel<PS>, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, ps.ksk);
     HIP_TRY(hipGetLastError());
-    return 0;
+    return prof_end(s, st, ev, count, true);
 }
 PsState g_ps[kParamSets][kMaxLogicalDevices];
 
@@ -78,6 +80,8 @@ template <class PS>
 int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count, int steps, uint32_t* dump)
 {
     if (count == 0) return 0;
+    EventPair ev{};
+    if (int rc = prof_begin(s, st, ev)) return rc;
     if (!ps.lds_opt_in) {
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsLds<PS>::bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_batch_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsbLds<PS>::bytes));
@@ -94,7 +98,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
                            ps.bk_ntt, ps_tables<PS>(s), steps, dump);
     }
     HIP_TRY(hipGetLastError());
-    return 0;
+    return prof_end(s, st, ev, count, false);
 }
 
 template <class PS, class GetGate>

@@ -283,6 +283,9 @@ typedef struct cufhe_amd_profile {
 } cufhe_amd_profile;
 int cufhe_amd_profile_enable(int device, int on);
 int cufhe_amd_profile_get(int device, cufhe_amd_profile* out, int reset);
+/* Shader clock (Hz) the device holds under an FP64 load, measured now by a short calibration kernel (shader cycles over
+ * the constant 100 MHz counter, median over all waves).  Measurement aid: no counterpart in the reference. */
+int cufhe_amd_probe_clock(int device, double* hz);
 
 #ifdef __cplusplus
 }

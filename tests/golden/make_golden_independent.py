@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""make_golden_independent.py -- a SECOND, independent generator of full-size gate fixtures.
+
+Every other fixture under tests/golden/ is written by oracle/ (the C restatement the GPU words are compared with), so a
+misreading of the reference shared by the oracle and the kernels would pass unnoticed.  This script shares no code with
+oracle/ or cufhe_amd/: numpy and Python integers only, the external product as an exact SCHOOLBOOK negacyclic
+convolution in 64-bit integers (no transform, no prime, no floating point), written from the reference's text:
+
+  gate constants, pre-add            src/bootstrap_gpu.cu:402-421 (__HomGate__), :515-550 (__MuxBootstrap__)
+  modulus switch, test vector         include/gatebootstrapping_gpu.cuh:10-52, :287-345 (__BlindRotatePreAdd__)
+  (X^abar - 1) acc, gadget digits     include/gatebootstrapping_gpu.cuh:140-181
+  key indexing [step][row][out][N]    include/gatebootstrapping_gpu.cuh:207-217, src/bootstrap_gpu.cu:43-49
+  sample extract at index 0           src/bootstrap_gpu.cu:366-381
+  key switch                          include/keyswitch_gpu.cuh:13-23 (iksoffsetgen), :83-134 (KeySwitchFromTLWE)
+
+It writes tests/golden/golden_independent_v1.json: one NAND and one MUX on the BASELINE set (n = 630, N = 1024) and
+one NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
+defines that path).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
+key words define a word-level check); the fixture stores the seeds, a sha256 of each generated key, the inputs and the
+expected output words.  Takes a few minutes; run in the build container only:  python tests/golden/make_golden_independent.py
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+LVL0_N = 630
+MU0 = 1 << 29            # lvl0 / lvl1 message scale
+
+
+class Ring:
+    """the target ring of a blind rotation and the key switch back to lvl0"""
+
+    def __init__(self, N, nbit, l, Bgbit, bits, mu, t, basebit):
+        self.N, self.nbit, self.l, self.Bgbit, self.bits, self.mu, self.t, self.basebit = N, nbit, l, Bgbit, bits, mu, t, basebit
+        self.mask = (1 << bits) - 1
+        i = np.arange(N)[:, None]
+        m = np.arange(N)[None, :]
+        self.conv_idx = (i - m) % N                      # (d * k)[i] = sum_m d[(i - m) mod N] k[m] * (-1 if i < m)
+        self.conv_sign = np.where(i >= m, 1, -1).astype(np.int64)
+
+
+LVL1 = Ring(N=1024, nbit=10, l=3, Bgbit=6, bits=32, mu=1 << 29, t=8, basebit=2)
+LVL2 = Ring(N=2048, nbit=11, l=4, Bgbit=9, bits=64, mu=1 << 61, t=7, basebit=2)
+
+
+def modswitch(phase32, R):
+    """modSwitchFromTorus: the top nbit + 1 bits of a 32-bit phase"""
+    return (phase32 & 0xFFFFFFFF) >> (32 - 1 - R.nbit)
+
+
+def rotated_test_vector(bar, R):
+    """RotatedTestVector: a = 0, b = X^bar * (mu + mu X + ...), python ints mod 2^bits"""
+    b = []
+    for i in range(R.N):
+        if bar == 2 * R.N:
+            b.append(R.mu)
+        else:
+            neg = (i < (bar & (R.N - 1))) ^ ((bar >> R.nbit) & 1)
+            b.append((-R.mu) & R.mask if neg else R.mu)
+    return [[0] * R.N, b]
+
+
+def gadget_digits(acc_j, abar, R):
+    """digits of (X^abar - 1) acc_j: list over d of int64 arrays of N signed digits"""
+    N = R.N
+    offset = sum((1 << (R.Bgbit - 1)) << (R.bits - i * R.Bgbit) for i in range(1, R.l + 1))
+    roundoffset = 1 << (R.bits - R.l * R.Bgbit - 1)
+    digs = [np.zeros(N, np.int64) for _ in range(R.l)]
+    for i in range(N):
+        temp = acc_j[(i - abar) & (N - 1)]
+        if (i < (abar & (N - 1))) ^ ((abar >> R.nbit) & 1):
+            temp = -temp
+        temp = (temp - acc_j[i] + offset + roundoffset) & R.mask
+        for d in range(R.l):
+            digs[d][i] = ((temp >> (R.bits - (d + 1) * R.Bgbit)) & ((1 << R.Bgbit) - 1)) - (1 << (R.Bgbit - 1))
+    return digs
+
+
+def blind_rotate(c, bk, R):
+    """__BlindRotatePreAdd__ after the pre-add: c = 631 words of the linear combination (32-bit python ints).
+    bk: uint32 (lvl1) or uint64 (lvl2) array [n][(k+1) l][k+1][N].  Returns the accumulator [2][N] (python ints)."""
+    N = R.N
+    acc = rotated_test_vector(2 * N - modswitch(c[LVL0_N], R), R)
+    roundoffset = 1 << (32 - 2 - R.nbit)
+    rows = 2 * R.l
+    for i in range(LVL0_N):
+        abar = modswitch(c[i] + roundoffset, R)
+        # negacyclic matrices of the (k+1) l digit polynomials, side by side: [N][rows * N]
+        T = np.empty((N, rows * N), np.int64)
+        for j in range(2):
+            for d, dig in enumerate(gadget_digits(acc[j], abar, R)):
+                r = j * R.l + d
+                T[:, r * N:(r + 1) * N] = dig[R.conv_idx] * R.conv_sign
+        key = bk[i]                                          # [rows][2][N]
+        for o in range(2):
+            if R.bits == 32:
+                col = key[:, o, :].reshape(rows * N).astype(np.int64)     # < 2^32: exact in int64, |sum| < 2^50
+                s = T @ col
+                add = [int(v) & R.mask for v in s]
+            else:
+                kv = key[:, o, :].reshape(rows * N)
+                lo = (kv & np.uint64(0xFFFFFFFF)).astype(np.int64)
+                hi = (kv >> np.uint64(32)).astype(np.int64)                # two 32-bit halves: each |sum| < 2^54
+                slo, shi = T @ lo, T @ hi
+                add = [(int(a) + (int(b) << 32)) & R.mask for a, b in zip(slo, shi)]
+            acc[o] = [(x + y) & R.mask for x, y in zip(acc[o], add)]
+        if i % 90 == 0:
+            print(f"    step {i}/{LVL0_N}", flush=True)
+    return acc
+
+
+def sample_extract0(acc, R):
+    """__SampleExtractIndex__<P, 0>: N + 1 words"""
+    N = R.N
+    out = [acc[0][0]] + [(-acc[0][N - m]) & R.mask for m in range(1, N)]
+    return out + [acc[1][0]]
+
+
+def keyswitch(tlwe, ksk, R):
+    """KeySwitchFromTLWE: tlwe N + 1 words of R.bits bits -> 631 32-bit words.  ksk: uint32 [N][t][2][631]"""
+    roundoffset = 1 << (R.bits - (1 + R.basebit * R.t))
+    decompoffset = sum((1 << (R.basebit - 1)) << (R.bits - i * R.basebit) for i in range(1, R.t + 1))
+    res = np.zeros(LVL0_N + 1, np.int64)
+    b = tlwe[R.N]
+    res[LVL0_N] = b if R.bits == 32 else ((b + (1 << 31)) & R.mask) >> 32
+    for j in range(R.N):
+        tmp = (tlwe[j] + decompoffset + roundoffset) & R.mask
+        for k in range(R.t):
+            val = ((tmp >> (R.bits - (k + 1) * R.basebit)) & ((1 << R.basebit) - 1)) - (1 << (R.basebit - 1))
+            if val > 0:
+                res -= ksk[j, k, val - 1].astype(np.int64)
+            elif val < 0:
+                res += ksk[j, k, -val - 1].astype(np.int64)
+        res &= 0xFFFFFFFF
+    return [int(v) for v in res]
+
+
+def lincomb(ca, in0, cb, in1, off):
+    c = [(ca * int(a) + cb * int(b)) & 0xFFFFFFFF for a, b in zip(in0, in1)]
+    c[LVL0_N] = (c[LVL0_N] + off) & 0xFFFFFFFF
+    return c
+
+
+def gate_nand(in0, in1, bk, ksk, R):
+    """__HomGate__<casign -1, cbsign -1, offset +mu0>"""
+    acc = blind_rotate(lincomb(-1, in0, -1, in1, MU0), bk, R)
+    return keyswitch(sample_extract0(acc, R), ksk, R)
+
+
+def gate_mux(inc, in1, in0, bk, ksk, R):
+    """__MuxBootstrap__: BR(inc + in1 - mu0) + BR(-inc + in0 - mu0) + (0, mu), sample extract, key switch"""
+    a1 = blind_rotate(lincomb(1, inc, 1, in1, -MU0), bk, R)
+    a0 = blind_rotate(lincomb(-1, inc, 1, in0, -MU0), bk, R)
+    acc = [[(x + y) & R.mask for x, y in zip(a1[j], a0[j])] for j in range(2)]
+    acc[1][0] = (acc[1][0] + R.mu) & R.mask
+    return keyswitch(sample_extract0(acc, R), ksk, R)
+
+
+def random_words(rng, count, bits=32):
+    if bits == 32:
+        return rng.integers(0, 2**32, size=count, dtype=np.uint64).astype(np.uint32)
+    return rng.integers(0, 2**64, size=count, dtype=np.uint64)
+
+
+def main():
+    out = {"format": 1, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
+    t0 = time.time()
+    # --- BASELINE set: n = 630, N = 1024
+    krng = np.random.default_rng(20261004)
+    bk = random_words(krng, LVL0_N * 6 * 2 * 1024).reshape(LVL0_N, 6, 2, 1024)
+    ksk = random_words(krng, 1024 * 8 * 2 * 631).reshape(1024, 8, 2, 631)
+    irng = np.random.default_rng(777)
+    ins = [random_words(irng, 631) for _ in range(3)]
+    key1 = {"seed": 20261004, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
+    print("NAND, N = 1024", flush=True)
+    out["cases"].append({"ring": 1024, "op": "NAND", "key": key1, "inputs": [x.tolist() for x in ins[:2]],
+                         "expected": gate_nand(ins[0], ins[1], bk, ksk, LVL1)})
+    print("MUX, N = 1024", flush=True)
+    out["cases"].append({"ring": 1024, "op": "MUX", "key": key1, "inputs": [x.tolist() for x in ins],
+                         "expected": gate_mux(ins[0], ins[1], ins[2], bk, ksk, LVL1)})
+    # --- N = 2048 ring, 64-bit torus
+    krng = np.random.default_rng(20261005)
+    bk2 = random_words(krng, LVL0_N * 8 * 2 * 2048, 64).reshape(LVL0_N, 8, 2, 2048)
+    ksk2 = random_words(krng, 2048 * 7 * 2 * 631).reshape(2048, 7, 2, 631)
+    key2 = {"seed": 20261005, "bk_sha256": hashlib.sha256(bk2.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk2.tobytes()).hexdigest()}
+    print("NAND, N = 2048", flush=True)
+    out["cases"].append({"ring": 2048, "op": "NAND", "key": key2, "inputs": [x.tolist() for x in ins[:2]],
+                         "expected": gate_nand(ins[0], ins[1], bk2, ksk2, LVL2)})
+    out["seconds"] = round(time.time() - t0, 1)
+    dst = os.path.join(HERE, "golden_independent_v1.json")
+    json.dump(out, open(dst, "w"))
+    print("wrote", dst, out["seconds"], "s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,21 +1,25 @@
 #!/bin/bash
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* and profiles/kernel_facts.json.
-# Run on the GPU box from the repo root (gpurun -- 'bash tools/profile_round.sh r02').  One --stats pass and three
-# --pmc passes per workload, each pass its own process, --pmc never combined with --stats / sys traces
-# (MI355X_MICROARCH.md, rocprofv3 PMC slots: 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# Run on the GPU box from the repo root (gpurun -- 'bash tools/profile_round.sh r03').  The profiled command is the default
+# bench run (every workload of the driver line: the headline batch, mux, mixed, the N = 2048 ring, a 512-gate launch on the
+# paired low-latency kernel, the three parameter sets, the key switches): one --stats pass and four --pmc passes, each its own
+# process with python3 directly behind `--`, --pmc never combined with --stats / sys traces (MI355X_MICROARCH.md, rocprofv3
+# PMC slots: 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}_prof
 mkdir -p $OUT
-BENCH="python3 bench.py --no-extra --no-cpu-baseline"
-for WL in ${WORKLOADS:-nand nand_lvl2}; do
-  STEPS=5; [ $WL = nand_lvl2 ] && STEPS=2
-  rocprofv3 --kernel-trace --stats -d $OUT/${WL}_stats -o st --output-format csv -- $BENCH --workload $WL --steps $STEPS > $OUT/${WL}_bench_under_rocprof.json
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
-      --kernel-trace -d $OUT/${WL}_pmc_sq -o pmc --output-format csv -- $BENCH --workload $WL --steps 2 > /dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${WL}_pmc_fetch -o pmc --output-format csv -- $BENCH --workload $WL --steps 2 > /dev/null
-  rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/${WL}_pmc_tcc -o pmc --output-format csv -- $BENCH --workload $WL --steps 2 > /dev/null
-  echo "$WL passes done"
-done
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.json
+echo "stats pass done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
+    --kernel-trace -d $OUT/pmc_sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+echo "sq pass done"
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES \
+    --kernel-trace -d $OUT/pmc_lds -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+echo "lds pass done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+echo "fetch pass done"
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+echo "tcc pass done"
 find $OUT -name "*.csv" | head -40
