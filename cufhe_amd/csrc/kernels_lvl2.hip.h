@@ -464,14 +464,15 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_v2_kernel(
 //     pairs it decomposes) and the transposes go through half-size tiles (ntt_wave.h: xpose_half_tile), which frees 65 KiB
 //     of LDS: the sums of the two halves get a region each, so a wave runs forward-products-forward-products without a
 //     barrier and the two waves of a SIMD fall into anti-phase by themselves (one transforms while the other streams key);
-//   * inverse jobs: phase A = the six of output 1 and two of output 0, phase B = the other four of output 0 on waves 0-3
-//     while waves 4-7 -- the owners of acc_1 -- recombine output 1 (last stage, lift, the three limbs shifted and summed in
-//     registers: no 64-bit LDS atomics), phase C = waves 0-3 recombine output 0; the results stay where the sums were;
-//   * the first key polynomials of the next step are requested at the start of phase B, when nothing else uses the
+//   * the twelve inverse jobs run in ONE phase, three per SIMD: waves 0-3 (served first by their SIMDs) take two sums of
+//     one half each, stage by stage in one instruction stream with the twiddles loaded once, waves 4-7 one sum each; the
+//     results stay where the sums were, and after one barrier every wave recombines its pairs of its output (last stage,
+//     lift, the three limbs shifted and summed in registers: no 64-bit LDS atomics);
+//   * the first key polynomials of the next step are requested behind the inverse jobs, when nothing else uses the
 //     vector-memory path;
-//   * the rotated read of the decomposition needs the accumulator in LDS: the owners leave a copy in two sum regions
-//     that are idle at that point (output 1's, consumed in phase B), zeroed again after the reads.
-// Six workgroup barriers per step as before.
+//   * the rotated read of the decomposition needs the accumulator in LDS: the owners leave a copy in sum regions whose
+//     slice only they read, zeroed again after the rotated reads.
+// Five workgroup barriers per step (six before).
 // LDS: 8 half tiles 33 KiB, sums 2 x 48 KiB, abar list, stage 4-7 twiddles 7.5 KiB, stage 8-9 forward twiddles 12 KiB
 // (the inverse ones, 12 KiB more, do not fit and stay in global memory: no key load is in flight when they are read) = 153 360 B.
 // ----------------------------------------------------------------------------------
@@ -534,8 +535,9 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
             acc_hi[m] = wj ? (n1 ? 0ull - k2Mu : k2Mu) : 0ull;
         }
     }
-    // the LDS copy of acc_j for the rotated reads: the first two sum polynomials of output 1, half j
-    char* stage = smem + k3LdsSum + (wj * k3SumDoubles + 3 * k2Half) * 8;
+    // the LDS copy of acc_j for the rotated reads: sum polynomials (h, o) = (j, 3 j) and (j, 3 j + 1) -- of those the slice
+    // a wave writes is read, in the recombination, by that wave only
+    char* stage = smem + k3LdsSum + (wj * k3SumDoubles + 3 * wj * k2Half) * 8;
     auto publish_acc = [&]() {
         char* o = stage + opaque(8 * e_first);
 #pragma unroll
@@ -589,6 +591,18 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
 #pragma unroll
         for (int r = 0; r < kRegs; r++) s[r * 64] = A[r];
     };
+    // two sums of one half in one wave
+    auto inverse_job2 = [&](int o1, int o2, int hh) {
+        const WaveCtx ctx = half_ctx(hh);
+        double* s1 = sumL + hh * k3SumDoubles + o1 * k2Half + lane;
+        double* s2 = sumL + hh * k3SumDoubles + o2 * k2Half + lane;
+        double A[kRegs], B[kRegs];
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s1[r * 64]); B[r] = fpf::reduce(s2[r * 64]); }
+        ntt_inverse2_twc<true, true>(A, B, ctx, twc);
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) { s1[r * 64] = A[r]; s2[r * 64] = B[r]; }
+    };
     // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, of the three limbs of output wj at this wave's pairs,
     // centred lift, limbs shifted and summed into the accumulator registers; the sums are left zero for the next step
     auto recombine = [&]() {
@@ -615,7 +629,6 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     };
 
     double2 kb[3][8];
-    uint32_t warm = 0;
 #define CUFHE_AMD_KEYPOLY3(key, k) ((key) + (size_t)((k) / k2Prods) * (k2BkRows * k2Prods * k2Half) + ((k) % k2Prods) * k2Half)
     auto prefetch_key = [&](int step) {
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     publish_acc();
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     // timing-only: cycles of this wave per phase: [0] copy visible (barrier), [1] rotated reads + barrier, [2] digits + barrier,
-    // [3] fwd h0, [4] prod h0, [5] fwd h1, [6] prod h1, [7] barrier, [8] inverse A, [9] barrier, [10] phase B, [11] barrier, [12] phase C
+    // [3] fwd h0, [4] prod h0, [5] fwd h1, [6] prod h1, [7] barrier, [8] inverse jobs, [9] barrier, [12] recombination
     unsigned long long ph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
 #define CUFHE_AMD_PHASE3(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
 #else
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
             __syncthreads();                                  // all rotated reads done: the copy is dead
             CUFHE_AMD_PHASE3(1)
             {   // the two sum polynomials the copy occupied are zero again before any product is added (barrier below)
-                char* z = smem + k3LdsSum + ((wave >> 2) * k3SumDoubles + 3 * k2Half) * 8 + opaque((wave & 3) * 4096 + 16 * lane);
+                char* z = smem + k3LdsSum + ((wave >> 2) * k3SumDoubles + 3 * (wave >> 2) * k2Half) * 8 + opaque((wave & 3) * 4096 + 16 * lane);
 #pragma unroll
                 for (int t = 0; t < 4; t++) *(double2*)(z + 1024 * t) = make_double2(0.0, 0.0);
             }
@@ -723,48 +736,42 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
             }
             CUFHE_AMD_PHASE3(4 + 2 * h)
         }
-        load_twc(wave >= 5 ? 1 : 0);
+        // the twelve inverse jobs in one phase: waves 0-3 -- served first by their SIMDs -- take two sums of one half each,
+        // stage by stage in one instruction stream, waves 4-7 one sum each: three jobs per SIMD
+        //   wave 0: (3, 4 | h0)   wave 1: (5, 0 | h0)   wave 2: (3, 4 | h1)   wave 3: (5, 0 | h1)
+        //   wave 4: (1 | h0)      wave 5: (2 | h0)      wave 6: (1 | h1)      wave 7: (2 | h1)
+        const int jh = (wave >> 1) & 1;
+        load_twc(jh);
         __syncthreads();                                      // the twelve sums are complete
         CUFHE_AMD_PHASE3(7)
-        // inverse jobs, phase A: all of output 1 and two of output 0
-        {
-            const int o = wave == 0 ? 0 : wave == 1 ? 1 : 3 + (wave - 2) % 3;
-            const int hh = wave >= 5 ? 1 : 0;
-            if (hh) inverse_job(o, 1);
-            else inverse_job(o, 0);
-        }
-        if (wave < 4) load_twc(wave == 0 ? 0 : 1);
-        CUFHE_AMD_PHASE3(8)
-        __syncthreads();
-        CUFHE_AMD_PHASE3(9)
-        // phase B: waves 0-3 finish output 0, waves 4-7 recombine output 1 into their accumulator registers; then the key of
-        // the next step is requested (idle vector-memory path; behind the jobs, whose loads would queue behind the key's)
-        if (wave < 4) {
-            if (wave == 0) inverse_job(2, 0);
-            else inverse_job(wave - 1, 1);
-        } else {
-            recombine();
-        }
-        if (i + 1 < steps) prefetch_key(i + 1);
         // L2 warming: the 32 workgroups that share an XCD (blocks b, b + 8, ...: round-robin dispatch, for speed only) walk
         // the key together, and whoever touches a line first waits for the fabric.  Each workgroup touches 1/32 of the key of
         // step i + 2 (one 4-byte load per 128-byte line: 768 KiB / 32 = 192 lines = 3 wave-loads on wave 7), so that the
-        // XCD's L2 holds the whole step before anyone needs it (measured: 1 % of the launch).
+        // XCD's L2 holds the whole step before anyone needs it.  The loads are issued ahead of the inverse jobs and end
+        // behind them: nothing waits for them.
+        uint32_t warm0 = 0, warm1 = 0, warm2 = 0;
         if (wave == 7 && i + 2 < steps) {
             const char* nk = (const char*)(bk_ntt + (size_t)(i + 2) * k2BkStepDoubles) + (size_t)((blockIdx.x >> 3) & 31) * 24576 + lane * 128;
-            warm = *(const volatile uint32_t*)nk + *(const volatile uint32_t*)(nk + 8192) + *(const volatile uint32_t*)(nk + 16384);
+            warm0 = *(const uint32_t*)nk;
+            warm1 = *(const uint32_t*)(nk + 8192);
+            warm2 = *(const uint32_t*)(nk + 16384);
         }
-        CUFHE_AMD_PHASE3(10)
+        if (wave < 4) inverse_job2((wave & 1) ? 5 : 3, (wave & 1) ? 0 : 4, jh);      // one copy of the code: o, h are run-time values
+        else inverse_job(1 + (wave & 1), jh);
+        // the key of the next step is requested now (idle vector-memory path; behind the jobs, whose loads would queue behind it)
+        asm volatile("" :: "v"(warm0), "v"(warm1), "v"(warm2));      // the warming loads end here, long after their issue
+        if (i + 1 < steps) prefetch_key(i + 1);
+        CUFHE_AMD_PHASE3(8)
         __syncthreads();
-        CUFHE_AMD_PHASE3(11)
-        // phase C: waves 0-3 recombine output 0; everyone leaves a copy of its accumulator for the next rotated read
-        if (wave < 4) recombine();
+        CUFHE_AMD_PHASE3(9)
+        // every wave recombines its pairs of its output into its accumulator registers and leaves a copy for the next rotated read
+        recombine();
         publish_acc();
         CUFHE_AMD_PHASE3(12)
     }
 #undef CUFHE_AMD_KEYPOLY3
 
-    asm volatile("" :: "v"(warm));      // keeps the warming loads alive
+
     if (acc_dump) {
         uint64_t* o = acc_dump + (size_t)g * 2 * k2N + wj * k2N + e_first;
 #pragma unroll

@@ -142,7 +142,8 @@ struct WaveCtx {
     // optional: [tu_fwd[16] | tu_inv[16]] in LDS (256 bytes).  Read through the scalar cache at their use (TwUniform) the
     // stage 0-3 twiddles cost an s_load followed at once by s_waitcnt lgkmcnt(0) -- the scalar-load latency exposed AND the
     // wave's LDS reads drained -- in every transform; as broadcast LDS reads issued ahead of the transpose in front of
-    // their phase (TU_LDS variants below) they cost nothing.
+    // their phase (TU_LDS variants below) they cost nothing.  Used where waves run in lock-step (kernels_lvl2.hip.h); in
+    // the wave-per-rotation kernel the partner wave covers the stall (measured: 38.63 ms either way).
     const char* tu_l;
 };
 
@@ -277,6 +278,36 @@ __device__ __forceinline__ void gs_four_stages(double (&x)[kRegs], const TW& tw)
     }
 }
 
+// One Gentleman-Sande stage with register stride S (1, 2, 4, 8) and twiddles tw(first + g), and the four stages of
+// gs_four_stages applied to TWO polynomials stage by stage (two inverse transforms in one wave: their dependent chains
+// and LDS round trips cover each other when the partner wave on the SIMD is parked)
+template <int S, bool WIDE, class TW>
+__device__ __forceinline__ void gs_stage(double (&x)[kRegs], const TW& tw, int first)
+{
+#pragma unroll
+    for (int g = 0; g < 8 / S; g++) {
+        const double w = tw(first + g);
+#pragma unroll
+        for (int r = 0; r < S; r++) gs_bfly<WIDE>(x[2 * S * g + r], x[2 * S * g + r + S], w);
+    }
+}
+template <class TW>
+__device__ __forceinline__ void gs_four_stages2(double (&x)[kRegs], double (&y)[kRegs], const TW& tw)
+{
+    gs_stage<1, false>(x, tw, 7);
+    gs_stage<1, false>(y, tw, 7);
+    gs_stage<2, true>(x, tw, 3);
+    gs_stage<2, true>(y, tw, 3);
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = fpf::reduce(x[r]);
+#pragma unroll
+    for (int r = 0; r < 16; r++) y[r] = fpf::reduce(y[r]);
+    gs_stage<4, false>(x, tw, 1);
+    gs_stage<4, false>(y, tw, 1);
+    gs_stage<8, false>(x, tw, 0);
+    gs_stage<8, false>(y, tw, 0);
+}
+
 // ---- layout changes through the wave-private LDS tile -----------------------------
 // DS operations of one wave execute in issue order, so a wave may reuse its own tile
 // without any barrier.
@@ -309,31 +340,45 @@ template <bool A_TO_B>
 __device__ __forceinline__ void xpose_half_tile(double (&x)[kRegs], char* abase, char* bbase)
 {
     const bool upper = (threadIdx.x & 8) != 0;      // e[9] of this lane's layout-B row
-    double y[kRegs];
+    double t[8];                                     // eight registers beside x, not sixteen
+    if (A_TO_B) {
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-        asm volatile("" ::: "memory");
-        if (A_TO_B) {
+        for (int p = 0; p < 2; p++) {
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int r = 0; r < 8; r++) lds_st(abase, 8 * 66 * r, x[8 * p + r]);
             asm volatile("" ::: "memory");
-            if (upper == (p == 1)) {
+            if (upper == (p == 1)) {                 // registers 0-7 of x have been stored by now (pass 0), t is free
 #pragma unroll
-                for (int k = 0; k < kRegs; k++) y[k] = lds_ld(bbase, 32 * k);
-            }
-        } else {
-            if (upper == (p == 1)) {
+                for (int k = 0; k < 8; k++) x[k] = lds_ld(bbase, 32 * k);
 #pragma unroll
-                for (int k = 0; k < kRegs; k++) lds_st(bbase, 32 * k, x[k]);
+                for (int k = 0; k < 8; k++) t[k] = lds_ld(bbase, 32 * (k + 8));
             }
             asm volatile("" ::: "memory");
+        }
 #pragma unroll
-            for (int r = 0; r < 8; r++) y[8 * p + r] = lds_ld(abase, 8 * 65 * r);
+        for (int k = 0; k < 8; k++) x[8 + k] = t[k];
+    } else {
+        asm volatile("" ::: "memory");
+        if (!upper) {
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) lds_st(bbase, 32 * k, x[k]);
         }
         asm volatile("" ::: "memory");
-    }
 #pragma unroll
-    for (int r = 0; r < kRegs; r++) x[r] = y[r];
+        for (int r = 0; r < 8; r++) t[r] = lds_ld(abase, 8 * 65 * r);
+        asm volatile("" ::: "memory");
+        if (upper) {
+#pragma unroll
+            for (int k = 0; k < kRegs; k++) lds_st(bbase, 32 * k, x[k]);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[8 + r] = lds_ld(abase, 8 * 65 * r);      // x is dead in every lane by now
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = t[r];
+    }
 }
 
 // ---- layout change B <-> C without LDS -------------------------------------------------
@@ -486,6 +531,28 @@ __device__ __forceinline__ void ntt_inverse_twc(double (&x)[kRegs], const WaveCt
     else CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
     if (TU_LDS) gs_four_stages(x, TwArr{tu});
     else gs_four_stages(x, TwUniform{c.gt->tu_inv});
+}
+// Two inverse transforms with the SAME tables (two sums of one half) in one wave, stage by stage; the twiddles are loaded
+// once.  The tile is used by x's transpose, then by y's.
+template <bool HALF_TILE = false, bool TU_LDS = false>
+__device__ __forceinline__ void ntt_inverse2_twc(double (&x)[kRegs], double (&y)[kRegs], const WaveCtx& c, const double (&twc)[kTcCount])
+{
+    gs_stage<1, false>(x, TwArr{twc}, 4);
+    gs_stage<1, false>(y, TwArr{twc}, 4);
+    gs_stage<2, false>(x, TwArr{twc}, 0);
+    gs_stage<2, false>(y, TwArr{twc}, 0);
+    double twb[kTbCount];
+#pragma unroll
+    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_inv, 128 * k);
+    xpose_cb_permlane(x);                            // C -> B in registers
+    xpose_cb_permlane(y);
+    gs_four_stages2(x, y, TwArr{twb});
+    double tu[15];
+    if (TU_LDS) load_tu(tu, c.tu_l + 128);
+    if (HALF_TILE) { xpose_half_tile<false>(x, c.a65, c.b65); xpose_half_tile<false>(y, c.a65, c.b65); }
+    else { CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65) { double (&x)[kRegs] = y; CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65) } }
+    if (TU_LDS) gs_four_stages2(x, y, TwArr{tu});
+    else gs_four_stages2(x, y, TwUniform{c.gt->tu_inv});
 }
 template <bool HALF_TILE = false, bool TU_LDS = false>
 __device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c)
