@@ -98,7 +98,6 @@ long g_ks_wg_threshold = -1;    // key switches per launch up to which the workg
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
-long g_lvl2_kernel = 3;        // 3: round-3 schedule of the N = 2048 blind rotation; 2: the round-2 kernel (kept for A/B timing and as a cross-check)
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 constexpr int kMaxLogicalDevices = 64;    // SetGPUNum bound (per-device tables of fixed size: paramsets.inc.h)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
@@ -1144,11 +1143,6 @@ int cufhe_amd_set_option(const char* key, long value)
             if ((int)p.lvl0_words != kLvl0Words) return fail(-1, "lvl0_param_set: the set's lvl0 ciphertexts differ in size from the per-gate API's (n must be 630)");
         }
         g_lvl0_param_set = value;
-        return 0;
-    }
-    if (!strcmp(key, "lvl2_kernel")) {
-        if (value != 2 && value != 3) return fail(-1, "lvl2_kernel must be 2 or 3");
-        g_lvl2_kernel = value;
         return 0;
     }
     if (!strcmp(key, "lvl0_ring")) {

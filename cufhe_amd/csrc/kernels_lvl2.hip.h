@@ -20,15 +20,13 @@
 // root[2m + h m + g]).  One wave therefore runs a half with the lvl1 code and 16 registers
 // per lane; the two halves of a row are processed one after the other.
 //
-// Work split.  One 8-wave workgroup per blind rotation.  Wave w owns TRGSW row w = (j, d):
-// it decomposes digit d of (X^abar - 1) acc_j, transforms it, multiplies by its 6 key
-// polynomials (2 outputs x 3 limbs) and adds the products into six LDS sums with ds_add_f64, per half;
-// the twelve inverse half-transforms of the step then run three per SIMD in two phases, and waves 0-5 add
-// their limb of the result into the 64-bit accumulator in LDS with ds_add_u64.  Six workgroup barriers per CMux step.
-// LDS: 8 transpose tiles (66 KiB), accumulator 2 x 2048 x u64 (32 KiB), sums 6 x 1024 x f64
-// (48 KiB), abar list, the per-lane twiddles of stages 4-7 (7.5 KiB).  The stage 8-9 twiddle
-// tables of the two halves (24 KiB) do not fit beside that and are read from global memory
-// (L1/L2 resident, fetched ahead of the register transposes as in lvl1).
+// Work split.  One 8-wave workgroup per blind rotation.  Wave w owns TRGSW row w = (j, d) and the pairs (e, e + 1024),
+// e = 256 d + lane + 64 m, of accumulator component j -- in registers.  Per CMux step: the owners decompose their pairs
+// (rotated operand from an LDS copy of the accumulator) and hand digit d to wave (j, d) through its transpose tile; every
+// wave transforms its row and adds the products with its 6 key polynomials (2 outputs x 3 limbs) into the sums of that
+// half with ds_add_f64, both halves back to back; the twelve inverse half-transforms run three per SIMD in one phase;
+// every wave recombines the halves and the three limbs of its pairs into its accumulator registers.  Five workgroup
+// barriers per step.  LDS map and schedule: at the kernel.
 #pragma once
 #include "kernels.hip.h"
 
@@ -171,16 +169,10 @@ __global__ __launch_bounds__(kNttThreads) void bk2_to_ntt_kernel(
 }
 
 // ----------------------------------------------------------------------------------
-// Blind rotate lvl02 + sample extract, one workgroup per rotation.
+// Blind rotate lvl02 + sample extract, one 8-wave workgroup per rotation.
 // ----------------------------------------------------------------------------------
 constexpr int k2Threads = 512;
-constexpr int k2LdsTiles = 0;
-constexpr int k2LdsAcc = k2LdsTiles + 8 * kTileBytes;            // 67584
-constexpr int k2LdsSum = k2LdsAcc + 2 * k2N * 8;                 // + 32768
-constexpr int k2LdsAbar = k2LdsSum + k2Prods * k2Half * 8;       // + 49152
-constexpr int k2LdsTb = k2LdsAbar + kAbarBytes + 16;             // stage 4-7 twiddles of both halves: [h][fwd|inv][15][16]
-constexpr int k2TbBytes = 2 * kTbCount * 16 * 8;                 // 3840 per half
-constexpr int k2LdsBytes = k2LdsTb + 2 * k2TbBytes;              // 158480
+constexpr int k2TbBytes = 2 * kTbCount * 16 * 8;                 // stage 4-7 twiddles of one half, forward and inverse: 3840
 
 __device__ __forceinline__ void load_key_poly(double2 (&b)[8], const double* poly, int lane)
 {
@@ -213,248 +205,12 @@ __device__ __forceinline__ void accumulate_poly(double* sums, const double (&x)[
     }
 }
 
-__global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_v2_kernel(
-    const RotDesc2* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const NttTables* __restrict__ gt2, int steps, uint64_t* __restrict__ acc_dump)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int g = blockIdx.x;
-    if (g >= count) return;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    uint64_t* accL = (uint64_t*)(smem + k2LdsAcc);            // [j][2048]
-    double* sumL = (double*)(smem + k2LdsSum);                // [out * 3 + limb][reg][lane]
-    uint16_t* abar_lds = (uint16_t*)(smem + k2LdsAbar);
-    uint32_t* bbar_slot = (uint32_t*)(smem + k2LdsAbar + kAbarBytes);
-
-    const RotDesc2 d = descs[g];
-    for (int i = tid; i <= kLvl0N; i += k2Threads) {
-        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
-        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - k2Nbit))) >> (32 - 1 - k2Nbit));
-        else *bbar_slot = 2 * k2N - ((c + d.off) >> (32 - 1 - k2Nbit));
-    }
-    for (int i = tid; i < k2Prods * k2Half; i += k2Threads) sumL[i] = 0.0;
-    for (int i = tid; i < 2 * 2 * kTbCount * 16; i += k2Threads) {     // tb_fwd and tb_inv are contiguous in NttTables
-        const int h = i / (2 * kTbCount * 16), k = i % (2 * kTbCount * 16);
-        ((double*)(smem + k2LdsTb))[i] = gt2[h].tb_fwd[k];
-    }
-    __syncthreads();
-    {   // RotatedTestVector<lvl2param>, include/gatebootstrapping_gpu.cuh:29-52
-        const uint32_t bbar = *bbar_slot;
-        for (int e = tid; e < k2N; e += k2Threads) {
-            const bool neg = (bbar != 2 * k2N) && (((uint32_t)e < (bbar & (k2N - 1))) != ((bbar >> k2Nbit) != 0));
-            accL[e] = 0;
-            accL[k2N + e] = neg ? 0ull - k2Mu : k2Mu;
-        }
-    }
-    __syncthreads();
-
-    const int wj = wave / k2L, wd = wave % k2L;               // this wave's TRGSW row = wj * l + wd
-    const WaveCtx ctx_tile = make_wave_ctx_gtab(smem, k2LdsTiles + wave * kTileBytes, gt2, lane);
-    const bool inv_wave = wave < k2Prods;
-#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
-    // timing-only: cycles of this wave per phase: [0] decompose, [1 + 4h] forward, [2 + 4h] products, [3 + 4h] barrier,
-    // [4] sums of half 0 to registers + barrier, [8] inverse phase A, [9] barrier, [10] inverse phase B + recombination, [11] barrier
-    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
-#define CUFHE_AMD_PHASE2(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
-#else
-#define CUFHE_AMD_PHASE2(k)
-#endif
-#pragma unroll 1
-    for (int i = 0; i < steps; i++) {
-        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
-        const int alo = (int)(abar & (k2N - 1));
-        const bool ahi = (abar >> k2Nbit) != 0;
-#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)      // timing-only diagnostic: every step reads step 0's key (cache resident)
-        const double* key = bk_ntt + (size_t)(i & 1) * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
-#else
-        const double* key = bk_ntt + (size_t)i * k2BkStepDoubles + (size_t)wave * (k2Prods * k2Half);
-#endif
-        // Key polynomials of this row, step i: P0..P5 (half 0: out x limb), P6..P11 (half 1).  Three register buffers,
-        // loads issued two polynomials ahead of their use: one ahead left the product phase waiting on L2 for twice its
-        // issue time (tools/lvl2_phases.py).
-        double2 kb[3][8];
-#define CUFHE_AMD_KEYPOLY(k) (key + (size_t)((k) / k2Prods) * (k2BkRows * k2Prods * k2Half) + ((k) % k2Prods) * k2Half)
-        load_key_poly(kb[0], CUFHE_AMD_KEYPOLY(0), lane);     // in flight during the decomposition + NTT
-        load_key_poly(kb[1], CUFHE_AMD_KEYPOLY(1), lane);
-
-        // Decomposition of (X^abar - 1) acc_wj, shared by the four waves of group wj: this wave forms the words at the
-        // pairs (e, e + 1024), e = 256 wd + lane + 64 m, extracts all four digits and writes digit d, packed per pair,
-        // into the transpose tile of wave (wj, d) -- free at this point of the step; after the barrier every wave
-        // picks up its own digit for all of e.  (Each wave used to read all of acc_wj for its one digit.)
-        uint32_t ab[kRegs];
-        {
-            const char* accj = (const char*)(accL + wj * k2N);
-            const int e_first = 256 * wd + lane;
-            const int rb = (e_first - alo) & (k2N - 1);
-            const char* cbase = accj + opaque(8 * e_first);
-            uint64_t rot0[4], rot1[4], cur0[4], cur1[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int i0 = (rb + 64 * m) & (k2N - 1);
-                rot0[m] = *(const uint64_t*)(accj + 8 * i0);
-                rot1[m] = *(const uint64_t*)(accj + 8 * (i0 ^ k2Half));
-                cur0[m] = *(const uint64_t*)(cbase + 512 * m);
-                cur1[m] = *(const uint64_t*)(cbase + 512 * m + 8 * k2Half);
-            }
-            char* dig_out = smem + opaque(k2LdsTiles + (wj * k2L) * kTileBytes + 4 * e_first);
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int e0 = e_first + 64 * m;
-                const bool neg0 = (e0 < alo) != ahi, neg1 = (e0 + k2Half < alo) != ahi;
-                const uint64_t t0 = ((neg0 ? 0ull - rot0[m] : rot0[m]) - cur0[m] + decomp_offset2()) ^ decomp_signmask2();
-                const uint64_t t1 = ((neg1 ? 0ull - rot1[m] : rot1[m]) - cur1[m] + decomp_offset2()) ^ decomp_signmask2();
-#pragma unroll
-                for (int dd = 0; dd < k2L; dd++) {
-                    // the 9-bit field at bit 64 - 9 (dd + 1) of t, sign-extended, with 32-bit operations: dd = 0..2 lie in the
-                    // high word, dd = 3 straddles the words (v_alignbit brings it to bit 0)
-                    constexpr int kTop = 64 - k2Bgbit;
-                    const int pos = kTop - k2Bgbit * dd;
-                    uint32_t a, b;
-                    if (pos >= 32) {
-                        a = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t0 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
-                        b = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(t1 >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
-                    } else {
-                        a = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t0 >> 32), (uint32_t)t0, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
-                        b = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), (uint32_t)t1, (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
-                    }
-                    *(uint32_t*)(dig_out + dd * kTileBytes + 256 * m) = __builtin_amdgcn_perm(b, a, 0x05040100u);   // (a & 0xffff) | (b << 16)
-                }
-            }
-            __syncthreads();
-            const char* dig_in = smem + opaque(k2LdsTiles + wave * kTileBytes + 4 * lane);
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) ab[r] = *(const uint32_t*)(dig_in + 256 * r);
-        }
-        CUFHE_AMD_PHASE2(0)
-        // table addresses of half hh, rebuilt where needed (a few address adds) instead of being carried in 16
-        // registers through the whole step
-        auto half_ctx = [&](int hh) {
-            WaveCtx c = ctx_tile;
-            int o16 = 8 * (lane & 15), o64 = 8 * lane;
-            asm volatile("" : "+v"(o16), "+v"(o64));
-            const NttTables* gth = gt2 + hh;
-            c.tb_fwd = smem + (k2LdsTb + hh * k2TbBytes) + o16;
-            c.tb_inv = c.tb_fwd + 8 * kTbCount * 16;
-            c.tc_fwd = (const char*)gth->tc_fwd + o64;
-            c.tc_inv = (const char*)gth->tc_inv + o64;
-            c.gt = gth;
-            return c;
-        };
-        double S0[kRegs];         // waves 0-5: half 0 of sum `wave`, first as read from LDS, then inverse-transformed
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const WaveCtx ctx = half_ctx(h);
-            double x[kRegs];
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                // first forward stage (a, b) -> a +- I b: exact, |I b| < 2^33
-                uint32_t w = ab[r];
-                asm volatile("" : "+v"(w));      // re-derive per half: keeps 16 registers live, not 64
-                const double a = (double)(int)(int16_t)(w & 0xffffu), b = (double)((int)w >> 16);
-                x[r] = __builtin_fma(h ? -b : b, fpf::ROOT4, a);
-            }
-            ntt_forward<false>(x, ctx);
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);
-            CUFHE_AMD_PHASE2(1 + 4 * h)
-#pragma unroll
-            for (int pp = 0; pp < k2Prods; pp++) {
-                const int k = k2Prods * h + pp;            // compile-time: both loops are unrolled
-                if (k + 2 < 2 * k2Prods) load_key_poly(kb[(k + 2) % 3], CUFHE_AMD_KEYPOLY(k + 2), lane);
-                accumulate_poly(sumL + pp * k2Half, x, kb[k % 3], lane);
-            }
-            CUFHE_AMD_PHASE2(2 + 4 * h)
-            __syncthreads();              // the six sums of half h are complete
-            CUFHE_AMD_PHASE2(3 + 4 * h)
-            if (h == 0) {
-                // The sums of half 0 only move into registers here; their inverse transforms wait for those of half 1,
-                // so that the twelve inverse jobs of the step can be spread evenly over the four SIMDs (below).
-                if (inv_wave) {
-                    double* s = sumL + wave * k2Half + lane;
-#pragma unroll
-                    for (int r = 0; r < kRegs; r++) { S0[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-                }
-                __syncthreads();          // the sums are zero again before any wave adds products of half 1
-                CUFHE_AMD_PHASE2(4)
-            }
-        }
-        // Twelve inverse half-transforms (6 sums x 2 halves) on 8 waves = 4 SIMDs x 2: three per SIMD.
-        //   phase A: waves 0-5 transform half 0 of their sum (from registers), waves 6-7 half 1 of sums 4 and 5, which they
-        //            leave in the sum's LDS slot for waves 4-5;
-        //   phase B: waves 0-3 transform half 1 of their sum and recombine; waves 4-5 only recombine.
-        // (Before: six jobs per phase, two on each of SIMDs 0-1 and one on each of SIMDs 2-3, twice per step.)
-        {
-            const bool own = inv_wave;
-            const WaveCtx ctx = half_ctx(own ? 0 : 1);
-            double* s = sumL + (own ? wave : wave - 2) * k2Half + lane;
-            double A[kRegs];
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) A[r] = own ? S0[r] : fpf::reduce(s[r * 64]);
-            ntt_inverse(A, ctx);                               // |A| <= 2 p, natural order
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                if (own) S0[r] = A[r];
-                else s[r * 64] = A[r];
-            }
-        }
-        CUFHE_AMD_PHASE2(8)
-        __syncthreads();
-        CUFHE_AMD_PHASE2(9)
-        if (inv_wave) {
-            double* s = sumL + wave * k2Half + lane;
-            double A[kRegs];
-            if (wave < 4) {
-                const WaveCtx ctx = half_ctx(1);
-#pragma unroll
-                for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-                ntt_inverse(A, ctx);
-            } else {
-#pragma unroll
-                for (int r = 0; r < kRegs; r++) { A[r] = s[r * 64]; s[r * 64] = 0.0; }     // transformed by wave + 2
-            }
-            // last inverse stage (a, b) -> (a + b, (a - b) I^-1), I^-1 = -I, then each wave adds its limb of
-            // the exact sum, shifted, into the 64-bit accumulator
-            const int out = wave / k2Limbs, shl = k2LimbBits * (wave % k2Limbs);
-            unsigned long long* acck = (unsigned long long*)(accL + out * k2N) + lane;
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                const double lo = fpf::reduce(S0[r] + A[r]);
-                const double hi = fpf::reduce(fpf::mulmod(S0[r] - A[r], -fpf::ROOT4));
-                __hip_atomic_fetch_add(acck + 64 * r, to_u64(lo) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acck + k2Half + 64 * r, to_u64(hi) << shl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        CUFHE_AMD_PHASE2(10)
-        __syncthreads();
-        CUFHE_AMD_PHASE2(11)
-    }
-
-    if (acc_dump) {
-        uint64_t* o = acc_dump + (size_t)g * 2 * k2N;
-        for (int e = tid; e < 2 * k2N; e += k2Threads) o[e] = accL[e];
-    }
-#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
-    if (acc_dump && lane == 0 && g == 0) {
-        __syncthreads();
-        unsigned long long* o = (unsigned long long*)acc_dump + 2048 + wave * 16;     // overwrites part of the dump: timing only
-        for (int k = 0; k < 12; k++) o[k] = ph[k];
-    }
-#endif
-    if (d.out) {   // __SampleExtractIndex__<lvl2param,0>, src/bootstrap_gpu.cu:366-381
-        uint64_t* o = d.out;
-        for (int e = tid; e < k2N; e += k2Threads) {
-            if (e == 0) { o[0] = accL[0]; o[k2N] = accL[k2N]; }
-            else o[k2N - e] = 0ull - accL[e];
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------------
-// Blind rotate lvl02 + sample extract, round-3 schedule (same arithmetic, same words as the kernel above).
+// The schedule (round 3; the round-2 kernel it replaces -- one sum region reused by the two halves, accumulator in LDS,
+// 64-bit LDS atomics, inverse jobs 8 + 4 -- is in the history of this file; its per-phase cycle counters are
+// profiles/r03_lvl2_phases_round2_kernel.txt).
 //
-// What the per-phase cycle counters of the kernel above showed (tools/lvl2_phases.py, profiles/r03_lvl2_phases_before.txt):
+// What those counters showed (tools/lvl2_phases.py):
 // the two waves of a SIMD run the same phase, the older one is served first, finishes its forward transform and products
 // while the younger one transforms, and then waits at the barrier while the younger one runs its products ALONE -- a phase
 // bound by the CU's vector-memory path (768 KiB of key per step at 64 B/clk = 12.3 k of the step's 56.8 k cycles; without key
@@ -474,7 +230,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_v2_kernel(
 //     slice only they read, zeroed again after the rotated reads.
 // Five workgroup barriers per step (six before).
 // LDS: 8 half tiles 33 KiB, sums 2 x 48 KiB, abar list, stage 4-7 twiddles 7.5 KiB, stage 8-9 forward twiddles 12 KiB
-// (the inverse ones, 12 KiB more, do not fit and stay in global memory: no key load is in flight when they are read) = 153 360 B.
+// (the inverse ones are read out of them, mirrored and negated), stage 0-3 twiddles 0.5 KiB = 153 872 B.
 // ----------------------------------------------------------------------------------
 constexpr int k3LdsTiles = 0;
 constexpr int k3LdsSum = k3LdsTiles + 8 * kHalfTileBytes;        // 33792: [half][out * 3 + limb][1024] f64
@@ -571,17 +327,21 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         c.tu_l = smem + (k3LdsTu + hh * 256);
         return c;
     };
-    // inverse half-transform of sum (o, hh), left in place in natural order.  The stage 9-8 twiddles come from global
-    // memory (no room in LDS): they are requested ahead of the barrier in front of the job (load_twc).
+    // inverse half-transform of sum (o, hh), left in place in natural order.  Its stage 9-8 twiddles are not stored: with
+    // root[i] = psi^bitrev(i) and psi^2048 = -1, root^-1[M + G] = -root[M + (M - 1 - G)], which for the half tables reads
+    // inv_h[m + g] = -fwd_{1-h}[m + (m - 1 - g)]: the inverse twiddle of lane L is minus the FORWARD twiddle of the other
+    // half at lane 63 - L, levels in reverse order -- read from the forward tables already in LDS (the sign rides on the
+    // multiplications' source modifiers).
     double twc[kTcCount];
     auto load_twc = [&](int hh) {
-        int o64 = 8 * lane;
-        asm volatile("" : "+v"(o64));
-        const char* t = (const char*)gt2[hh].tc_inv + o64;
+        int o63 = 8 * (63 - lane);
+        asm volatile("" : "+v"(o63));
+        const char* t = smem + (k3LdsTc + (1 - hh) * k3TcBytes) + o63;
 #pragma unroll
-        for (int k = 0; k < kTcCount; k++) twc[k] = *(const double*)(t + 512 * k);
+        for (int k = 0; k < kTcCount; k++) twc[k] = -lds_ld(t, 512 * (k < 4 ? 3 - k : 15 - k));
     };
     auto inverse_job = [&](int o, int hh) {
+        load_twc(hh);
         const WaveCtx ctx = half_ctx(hh);
         double* s = sumL + hh * k3SumDoubles + o * k2Half + lane;
         double A[kRegs];
@@ -593,6 +353,7 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
     };
     // two sums of one half in one wave
     auto inverse_job2 = [&](int o1, int o2, int hh) {
+        load_twc(hh);
         const WaveCtx ctx = half_ctx(hh);
         double* s1 = sumL + hh * k3SumDoubles + o1 * k2Half + lane;
         double* s2 = sumL + hh * k3SumDoubles + o2 * k2Half + lane;
@@ -741,7 +502,6 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
         //   wave 0: (3, 4 | h0)   wave 1: (5, 0 | h0)   wave 2: (3, 4 | h1)   wave 3: (5, 0 | h1)
         //   wave 4: (1 | h0)      wave 5: (2 | h0)      wave 6: (1 | h1)      wave 7: (2 | h1)
         const int jh = (wave >> 1) & 1;
-        load_twc(jh);
         __syncthreads();                                      // the twelve sums are complete
         CUFHE_AMD_PHASE3(7)
         // L2 warming: the 32 workgroups that share an XCD (blocks b, b + 8, ...: round-robin dispatch, for speed only) walk

@@ -51,15 +51,10 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
     }
     if (!s.br2_lds_opt_in) {
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3LdsBytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2LdsBytes));
         s.br2_lds_opt_in = true;
     }
-    if (g_lvl2_kernel == 2)
-        hipLaunchKernelGGL(blind_rotate_lvl2_v2_kernel, dim3((unsigned)count), dim3(k2Threads), k2LdsBytes, st, d, (int)count,
-                           s.bk2_ntt, s.tables2, steps, acc_dump);
-    else
-        hipLaunchKernelGGL(blind_rotate_lvl2_kernel, dim3((unsigned)count), dim3(k2Threads), k3LdsBytes, st, d, (int)count,
-                           s.bk2_ntt, s.tables2, steps, acc_dump);
+    hipLaunchKernelGGL(blind_rotate_lvl2_kernel, dim3((unsigned)count), dim3(k2Threads), k3LdsBytes, st, d, (int)count,
+                       s.bk2_ntt, s.tables2, steps, acc_dump);
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));

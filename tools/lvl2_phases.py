@@ -13,12 +13,7 @@ ksk = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.
 eng.SetGPUNum(1)
 eng.api.lvl2_initialize(bk, ksk)
 n, N = int(p2.n), int(p2.N)
-kernel = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-eng.api.set_option("lvl2_kernel", kernel)
-if kernel == 2:
-    names = ["decompose", "fwd h0", "prod h0", "barrier", "sums h0 -> regs", "fwd h1", "prod h1", "barrier", "inverse A", "barrier", "inverse B + recombine", "barrier"]
-else:
-    names = ["barrier", "rot reads+barrier", "digits+barrier", "fwd h0", "prod h0", "fwd h1", "prod h1", "barrier", "inverse jobs", "barrier", "-", "-", "recombine"]
+names = ["barrier", "rot reads+barrier", "digits+barrier", "fwd h0", "prod h0", "fwd h1", "prod h1", "barrier", "inverse jobs", "barrier", "-", "-", "recombine"]
 for count in (1, 4096):
     tl = rng.integers(0, 2**32, size=(count, n + 1), dtype=np.uint64).astype(np.uint32)
     d = eng.api.DeviceBuffer(tl.size).upload(tl)

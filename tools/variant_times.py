@@ -47,14 +47,8 @@ if "lvl2" not in skip:
     ksk2 = rng.integers(0, 2**32, size=int(p2.ksk_words), dtype=np.uint64).astype(np.uint32)
     api.lvl2_initialize(bk2, ksk2)
     for count in (4096, 1):
-        for kern in (2, 3, 2, 3):          # the round-2 kernel as the same-box reference
-            try:
-                api.set_option("lvl2_kernel", kern)
-            except Exception:
-                if kern == 2:
-                    continue
-            b, k = br_ms(lambda: api.lvl2_gate_batch(api.NAND, out, d0, d1, None, count=count), reps=2)
-            print(f"[{tag}] lvl2 kernel {kern} {count:5d} NAND: blind rotate {b:8.3f} ms  key switch {k:6.3f} ms", flush=True)
+        b, k = br_ms(lambda: api.lvl2_gate_batch(api.NAND, out, d0, d1, None, count=count), reps=2)
+        print(f"[{tag}] lvl2 {count:5d} NAND: blind rotate {b:8.3f} ms  key switch {k:6.3f} ms", flush=True)
 if "ps" not in skip:
     for ps in range(api.ps_count()):
         p = api.ps_params(ps)
