@@ -7,7 +7,11 @@
  * torch or C++ types.  All functions return 0 on success and a negative code on failure
  * (cufhe_amd_last_error() gives the text); the reference aborts instead
  * (include/details/error_gpu.cuh:40-60) and the C++ shim include/cufhe_amd.hpp restores
- * that behaviour.
+ * that behaviour.  Codes: -1 bad argument, -2 a HIP call failed, -3 keys not initialised,
+ * -5 a kernel reported through the device's fault word that its own result cannot be trusted
+ * (a bounded device-side wait expired): returned by cufhe_amd_synchronize / _stream_query /
+ * _stream_synchronize and by the call that makes the scheduler observe the completion,
+ * sticky until cufhe_amd_cleanup; ciphertexts produced since Initialize must be discarded.
  *
  * Conventions
  *   - "device" is the reference's GPU index in [0, gpuNum) (Stream::device_id(),
