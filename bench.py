@@ -4,25 +4,30 @@
 One "step" = one pass of the hot path over one batch: 4096 independent NAND gates
 (BASELINE.json configs[1]) per GPU, inputs and keys already resident in HBM, one
 cufhe_amd_gate_batch call = one blind-rotate launch + one key-switch launch.  With N > 1
-ranks (one per GPU, launched by torch.distributed.run) every rank runs its own 4096 gates
-against its own BK/KSK replica: weak scaling, no data-path collective.
-`--workload mixed --total-gates 32768` is BASELINE configs[2] instead: the 32 768 mixed gates of
-SURVEY.md 8(d) config 3 split contiguously over the ranks (strong scaling).
+ranks (one per GPU) every rank runs its own 4096 gates against its own BK/KSK replica: weak
+scaling, no data-path collective.  `python bench.py --gpus N` run plainly starts
+the N ranks itself (before torch or the HIP library are imported); under
+`torch.distributed.run` it is one of the ranks.  `--workload mixed --total-gates 32768` is
+BASELINE configs[2] instead: the 32 768 mixed gates of SURVEY.md 8(d) config 3 split
+contiguously over the ranks (strong scaling).
 
 Prints ONE JSON line (rank 0):
   value / ms_per_step      the timed region: K steps, no profiling hooks inside
+  value_pcie_inclusive     the same 4096 gates through the reference-style per-gate API on host-resident
+                           ciphertexts, enqueue -> Synchronize; details in
+                           api_pcie_inclusive (+ a depth-first adder netlist, both renaming modes)
   ms_per_gate_latency_single_gate   one gate alone on the idle device (the metric's second half)
   roofline                 the dominant kernel (blind rotate) priced with the BK-sweep accounting of
                            SURVEY.md 8(d) (61 931 520 algorithmic bytes per rotation) over its launch
                            time, measured with HIP events on the launch stream in a SEPARATE pass;
-                           `traffic` and `valu` come from the committed rocprofv3 PMC passes and are
-                           printed only while the kernel sources still hash to what was profiled
-  api_pcie_inclusive       the reference-style per-gate API on host-resident ciphertexts over 256
-                           streams, enqueue -> Synchronize (test/test_util.h:29-72), and the host cost
-                           per gate of that path
-  extra_workloads          mux (configs[3]), mixed (configs[2] op mix), nand_lvl2 (configs[4]): rate,
-                           roofline fraction and a word-for-word oracle check each; param_sets: the other
-                           compiled parameter sets through the generic kernels
+                           `bound` names the real limiter (FP64 vector issue) and `valu` prices it:
+                           instruction count and HBM bytes per rotation from the committed rocprofv3
+                           PMC passes of this command (valid only while every file with device code
+                           hashes to what was profiled), launch time and shader clock from THIS run
+  extra_workloads          mux (configs[3]), mixed (configs[2] op mix), nand_lvl2 (configs[4]), a
+                           512-gate launch (paired low-latency kernel), the key switch: rate, roofline
+                           fraction, `valu` block and a word-for-word oracle check each; param_sets: the
+                           other compiled parameter sets through the generic kernels
   cpu_baseline             an optimised CPU implementation of the same gate (oracle/cpu_fast.c: same
                            exact FP64 field, AVX-512/AVX2, OpenMP over gates) timed on this box's host
                            cores on a bounded sample; the CPU oracle checks both its words and the GPU's
