@@ -125,3 +125,19 @@ def test_parameter_sets_match_the_oracle_builds():
         assert p.ksk_words == p.k * p.N * p.t * (1 << (p.basebit - 1)) * (p.n + 1)
     assert names == list(ol.SETS)
     assert lib.cufhe_amd_ps_get_params(99, ctypes.byref(PsParams())) < 0
+
+
+def test_recorded_pmc_facts_belong_to_the_committed_device_code():
+    """bench.py prints `roofline.traffic` / `valu` only while profiles/kernel_facts.json was recorded for the device code in the
+    tree: a kernel edit without new rocprofv3 passes (tools/profile_round.sh + tools/kernel_facts.py) must not go unnoticed."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    ns = {"os": os, "hashlib": hashlib, "ROOT": root}
+    exec(src[src.index("DEVICE_SOURCES = "):src.index("_FACTS = None")], ns)
+    facts = json.load(open(os.path.join(root, "profiles", "kernel_facts.json")))
+    assert facts["source_sha256"] == ns["source_hash"](), "profiles/kernel_facts.json is stale: re-run the PMC passes"
+    for k in ("blind_rotate_kernel", "blind_rotate_lvl2_kernel", "blind_rotate_ll2_kernel", "keyswitch_kernel",
+              "blind_rotate_ps_batch_kernel<default>", "blind_rotate_ps_batch_kernel<k2n512>", "blind_rotate_ps_batch_kernel<cggi16>"):
+        assert facts["kernels"][k]["valu_insts_per_rotation"] > 0
