@@ -104,6 +104,9 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
     };
     if (row_wave && steps > 0) load_row(0);
+    double tu[7];                                             // this wave's stage 0-2 twiddles: forward for a row wave, inverse otherwise
+#pragma unroll
+    for (int k = 0; k < 7; k++) tu[k] = row_wave ? gt2[h].tu_fwd[k] : gt2[h].tu_inv[k];
     // The coefficient-wise tail of a step is spread over all 16 waves: wave k owns the slices (out, hh, rr) =
     // (m, k >> 3, k & 7), m = 0, 1, i.e. coefficients lane + 64 rr + 512 hh of accumulator component m.
     const int hh = wave >> 3, rr = wave & 7;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
                 const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(r < 4 ? q1.x : q1.y, 8u * (r & 3), 8u);
                 x[r] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);       // exact: |I a| < 2^30
             }
-            ntt512_forward(x, ctx);
+            ntt512_forward_tu(x, ctx, tu);
             double* s0 = sumL + h * kH + lane;
 #pragma unroll
             for (int o = 0; o < 2; o++)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             double* s = sumL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) { u[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-            ntt512_inverse(u, ctx);                           // u_h[e], e = lane + 64 r, |u| <= p
+            ntt512_inverse_tu(u, ctx, tu);                    // u_h[e], e = lane + 64 r, |u| <= p
             double* hd = handL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) hd[r * 64] = u[r];
@@ -323,6 +326,9 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
             for (int cc = 0; cc < 4; cc++) b[4 * o + cc] = rowp[o * (kN / 2) + key_idx + 64 * cc];
     };
     if (row_wave && steps > 0) load_row(0);
+    double tu[7];                                             // this wave's stage 0-2 twiddles: forward for a row wave, inverse otherwise
+#pragma unroll
+    for (int k = 0; k < 7; k++) tu[k] = row_wave ? gt2[h].tu_fwd[k] : gt2[h].tu_inv[k];
     const int hh = wave >> 3, rr = wave & 7;
     const int ecoef = lane + 64 * rr + kH * hh;
 
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
             const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(k < 4 ? q1.x : q1.y, 8u * (k & 3), 8u);
             x[k] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);
         }
-        ntt512_forward(x, ctx);
+        ntt512_forward_tu(x, ctx, tu);
         double* s0 = r.sum + h * kH + lane;
 #pragma unroll
         for (int o = 0; o < 2; o++)
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         double u[kRegs8];
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) u[k] = fpf::reduce(s[k * 64]);
-        ntt512_inverse(u, ctx);
+        ntt512_inverse_tu(u, ctx, tu);
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) s[k * 64] = u[k];
         inv_sync();

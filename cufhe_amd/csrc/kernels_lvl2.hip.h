@@ -60,6 +60,8 @@ static_assert(k2L == 4 && k2N == 4 * 512, "the decomposition is shared by the l 
 // reduced before the products: each product <= 0.5 + 0.0973 * 0.5, 2 l rows accumulate in LDS
 static_assert((double)(1u << (k2Bgbit - 1)) * (1.0 + fpf::ROOT4) < 9007199254740992.0 / 1024.0, "first split stage is not exact");
 static_assert(k2BkRows * fpf::after_mulmod(0.5001) < fpf::LIM_WIDE, "lvl2 row sums exceed 2^53");
+// half 0, stage 0 without reduction: (Bg/2) (1 + I) (1 + zeta) = 2^45.2 stays an exact double with 7 bits to spare, 0.05 p
+static_assert((double)(1u << (k2Bgbit - 1)) * (1.0 + fpf::ROOT4) * (1.0 + fpf::ROOT8) < 9007199254740992.0 / 128.0, "exact stage 0 of half 0");
 
 struct RotDesc2 {          // lvl0 operands, lvl2 result (sample-extracted TLWE)
     const uint32_t* in0;
@@ -484,7 +486,9 @@ __global__ __launch_bounds__(k2Threads) void blind_rotate_lvl2_kernel(
                 const double a = (double)(int)(int16_t)(w & 0xffffu), b = (double)((int)w >> 16);
                 x[r] = __builtin_fma(h ? -b : b, fpf::ROOT4, a);      // first forward stage, exact: |I b| < 2^33
             }
-            ntt_forward_a_tu<false>(x, tu);
+            // half 0: stage 0 multiplies by psi^512 = zeta = 5440, exact on |x| < 2^33 (2 FMAs instead of a modular product)
+            if (h == 0) ntt_forward_a_tu<false, true>(x, tu);
+            else ntt_forward_a_tu<false>(x, tu);
             ntt_forward_bc<true, true>(x, ctx);
 #pragma unroll
             for (int r = 0; r < kRegs; r++) x[r] = fpf::reduce(x[r]);

@@ -221,7 +221,9 @@ __device__ __forceinline__ void ct_bfly_exact(double& a, double& b, double w)
 
 // SMALL_IN: |x| <= 32 on entry and the twiddles are those of stages 0-3 (tw(0) = I,
 // tw(1) = zeta): stage 0 and the first group of stage 1 use ct_bfly_exact.
-template <bool SMALL_IN, class TW>
+// EXACT0 (with SMALL_IN false): stage 0 multiplies by a root so small -- tw(0) = zeta, 13 bits, against inputs below
+// 2^33 -- that the product is exact (the first stage of half 0 of the N = 2048 transform)
+template <bool SMALL_IN, class TW, bool EXACT0 = false>
 __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
 {
     if (SMALL_IN) {
@@ -235,7 +237,10 @@ __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
     } else {
         const double w0 = tw(0);
 #pragma unroll
-        for (int r = 0; r < 8; r++) ct_bfly<false>(x[r], x[r + 8], w0);
+        for (int r = 0; r < 8; r++) {
+            if (EXACT0) ct_bfly_exact(x[r], x[r + 8], w0);
+            else ct_bfly<false>(x[r], x[r + 8], w0);
+        }
 #pragma unroll
         for (int g = 0; g < 2; g++) {
             const double w = tw(1 + g);
@@ -471,10 +476,10 @@ __device__ __forceinline__ void load_tu(double (&tu)[15], const char* tu_lds)
 #pragma unroll
     for (int k = 0; k < 15; k++) tu[k] = lds_ld(tu_lds, 8 * k);
 }
-template <bool SMALL_IN>
+template <bool SMALL_IN, bool EXACT0 = false>
 __device__ __forceinline__ void ntt_forward_a_tu(double (&x)[kRegs], const double (&tu)[15])
 {
-    ct_four_stages<SMALL_IN>(x, TwArr{tu});
+    ct_four_stages<SMALL_IN, TwArr, EXACT0>(x, TwArr{tu});
 }
 // forward, phases B and C: out in layout C (spectrum order).  WIDE8: stage 8 inputs may
 // exceed 5.142 p (true for 32-bit inputs, not for gadget digits).

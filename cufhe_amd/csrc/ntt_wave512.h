@@ -128,7 +128,37 @@ __device__ __forceinline__ void gs_three_stages(double (&x)[kRegs8], const TW& t
         _Pragma("unroll") for (int r = 0; r < kRegs8; r++) x[r] = lds_ld(RBASE, (RSTRIDE) * r); \
     }
 
-// forward half transform: x = u_h in layout A (|x| far below p), out in layout C, |out| <= 7.22 p
+// forward half transform: x = u_h in layout A (|x| far below p), out in layout C, |out| <= 7.22 p.
+// tu: the seven stage 0-2 twiddles held by the caller (a wave whose role is fixed loads them once per kernel instead of an
+// s_load followed by a full lgkmcnt drain in every transform)
+__device__ __forceinline__ void ntt512_forward_tu(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7])
+{
+    ct_three_stages<false>(x, TwArr{tu});
+    double twb[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twb[k] = lds_ld(c.tb_fwd, 64 * k);
+    CUFHE_AMD_XPOSE8(c.a1, 8 * 68, c.b1, 64)          // A -> B
+    ct_three_stages<false>(x, TwArr{twb});
+    double twc[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
+    CUFHE_AMD_XPOSE8(c.b2, 64, c.c2, 8 * 72)          // B -> C
+    ct_three_stages<true>(x, TwArr{twc});
+}
+__device__ __forceinline__ void ntt512_inverse_tu(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7])
+{
+    double twc[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
+    double twb[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twb[k] = lds_ld(c.tb_inv, 64 * k);
+    gs_three_stages<-1>(x, TwArr{twc});               // s8 s7 s6: .5 -> 4
+    CUFHE_AMD_XPOSE8(c.c2, 8 * 72, c.b2, 64)          // C -> B
+    gs_three_stages<0>(x, TwArr{twb});                // s5 (wide, reduce) s4 s3: -> 2
+    CUFHE_AMD_XPOSE8(c.b1, 64, c.a1, 8 * 68)          // B -> A
+    gs_three_stages<1>(x, TwArr{tu});                 // s2 s1 (wide, reduce) s0: -> 1
+}
 __device__ __forceinline__ void ntt512_forward(double (&x)[kRegs8], const Wave512Ctx& c)
 {
     ct_three_stages<false>(x, TwUniform{c.gt->tu_fwd});

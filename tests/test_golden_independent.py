@@ -76,29 +76,41 @@ def test_oracle_words_match_independent_generator(oracle):
         assert np.array_equal(got, want), f"oracle words differ from the independent generator: ring {case['ring']} {case['op']}"
 
 
+GPU_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_golden_independent as tg
+import cufhe_amd as eng
+api = eng.api
+eng.SetGPUNum(1)
+for case in tg.cases():
+    bk, ksk = tg.keys_for(case)
+    if case["ring"] == 1024:
+        eng.Initialize(bk, ksk)
+    else:
+        eng.Initialize()
+        api.lvl2_initialize(bk, ksk)
+    ins = [np.array(x, np.uint32) for x in case["inputs"]]
+    d = [api.DeviceBuffer(631).upload(x) for x in ins]
+    out = api.DeviceBuffer(631)
+    third = d[2] if len(d) > 2 else None
+    if case["ring"] == 1024:
+        api.gate_batch(tg.OPS[case["op"]], 0, out, d[0], d[1], third, count=1)
+    else:
+        api.lvl2_gate_batch(tg.OPS[case["op"]], out, d[0], d[1], third, count=1)
+    eng.Synchronize()
+    assert np.array_equal(out.download(), np.array(case["expected"], np.uint32)), \
+        f"HIP words differ from the independent generator: ring {case['ring']} {case['op']}"
+eng.CleanUp()
+print("child ok")
+'''
+
+
 @pytest.mark.gpu
 def test_gpu_words_match_independent_generator():
-    import cufhe_amd as eng
-    api = eng.api
-    eng.SetGPUNum(1)
-    try:
-        for case in cases():
-            bk, ksk = keys_for(case)
-            if case["ring"] == 1024:
-                eng.Initialize(bk, ksk)
-            else:
-                eng.Initialize()
-                api.lvl2_initialize(bk, ksk)
-            ins = [np.array(x, np.uint32) for x in case["inputs"]]
-            d = [api.DeviceBuffer(631).upload(x) for x in ins]
-            out = api.DeviceBuffer(631)
-            third = d[2] if len(d) > 2 else None
-            if case["ring"] == 1024:
-                api.gate_batch(OPS[case["op"]], 0, out, d[0], d[1], third, count=1)
-            else:
-                api.lvl2_gate_batch(OPS[case["op"]], out, d[0], d[1], third, count=1)
-            eng.Synchronize()
-            assert np.array_equal(out.download(), np.array(case["expected"], np.uint32)), \
-                f"HIP words differ from the independent generator: ring {case['ring']} {case['op']}"
-    finally:
-        eng.CleanUp()
+    """In a process of its own: the keys of the fixture replace whatever the session's engine holds."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, "-c", f"ROOT={ol.ROOT!r}\n" + GPU_CHILD], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "child ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
