@@ -6,15 +6,17 @@ misreading of the reference shared by the oracle and the kernels would pass unno
 oracle/ or cufhe_amd/: numpy and Python integers only, the external product as an exact SCHOOLBOOK negacyclic
 convolution in 64-bit integers (no transform, no prime, no floating point), written from the reference's text:
 
-  gate constants, pre-add            src/bootstrap_gpu.cu:402-421 (__HomGate__), :515-550 (__MuxBootstrap__)
+  gate constants, pre-add            src/bootstrap_gpu.cu:402-421 (__HomGate__), :424-512 (the ten gates), :515-588 (Mux, NMux)
   modulus switch, test vector         include/gatebootstrapping_gpu.cuh:10-52, :287-345 (__BlindRotatePreAdd__)
   (X^abar - 1) acc, gadget digits     include/gatebootstrapping_gpu.cuh:140-181
   key indexing [step][row][out][N]    include/gatebootstrapping_gpu.cuh:207-217, src/bootstrap_gpu.cu:43-49
   sample extract at index 0           src/bootstrap_gpu.cu:366-381
   key switch                          include/keyswitch_gpu.cuh:13-23 (iksoffsetgen), :83-134 (KeySwitchFromTLWE)
 
-It writes tests/golden/golden_independent_v1.json: one NAND and one MUX on the BASELINE set (n = 630, N = 1024) and
-one NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
+It writes tests/golden/golden_independent_v2.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
+NMUX on level-0 ciphertexts (blind rotate, then key switch), NAND on level-1 ciphertexts (the other order:
+IdentityKeySwitchPreAdd, then __BlindRotate__; src/bootstrap_gpu.cu:383-400, include/keyswitch_gpu.cuh:136-188), and one
+NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
 defines that path).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
 key words define a word-level check); the fixture stores the seeds, a sha256 of each generated key, the inputs and the
 expected output words.  Takes a few minutes; run in the build container only:  python tests/golden/make_golden_independent.py
@@ -147,19 +149,37 @@ def lincomb(ca, in0, cb, in1, off):
     return c
 
 
-def gate_nand(in0, in1, bk, ksk, R):
-    """__HomGate__<casign -1, cbsign -1, offset +mu0>"""
-    acc = blind_rotate(lincomb(-1, in0, -1, in1, MU0), bk, R)
+# (casign, cbsign, offset in units of mu0), src/bootstrap_gpu.cu:424-512
+GATES = {"NAND": (-1, -1, 1), "NOR": (-1, -1, -1), "XNOR": (-2, -2, -2), "AND": (1, 1, -1), "OR": (1, 1, 1), "XOR": (2, 2, 2),
+         "ANDNY": (-1, 1, -1), "ANDYN": (1, -1, -1), "ORNY": (-1, 1, 1), "ORYN": (1, -1, 1)}
+
+
+def gate2(op, in0, in1, bk, ksk, R):
+    """__HomGate__<brP, mu, iksP, casign, cbsign, offset> on level-0 ciphertexts: blind rotate, extract, key switch"""
+    ca, cb, off = GATES[op]
+    acc = blind_rotate(lincomb(ca, in0, cb, in1, off * MU0), bk, R)
     return keyswitch(sample_extract0(acc, R), ksk, R)
 
 
-def gate_mux(inc, in1, in0, bk, ksk, R):
-    """__MuxBootstrap__: BR(inc + in1 - mu0) + BR(-inc + in0 - mu0) + (0, mu), sample extract, key switch"""
+def gate_mux(inc, in1, in0, bk, ksk, R, negate=False):
+    """__MuxBootstrap__: BR(inc + in1 - mu0) + BR(-inc + in0 - mu0) + (0, mu), sample extract, key switch;
+    __NMuxBootstrap__: -BR(..) - BR(..) - (0, mu)"""
     a1 = blind_rotate(lincomb(1, inc, 1, in1, -MU0), bk, R)
     a0 = blind_rotate(lincomb(-1, inc, 1, in0, -MU0), bk, R)
-    acc = [[(x + y) & R.mask for x, y in zip(a1[j], a0[j])] for j in range(2)]
-    acc[1][0] = (acc[1][0] + R.mu) & R.mask
+    sgn = -1 if negate else 1
+    acc = [[(sgn * (x + y)) & R.mask for x, y in zip(a1[j], a0[j])] for j in range(2)]
+    acc[1][0] = (acc[1][0] + sgn * R.mu) & R.mask
     return keyswitch(sample_extract0(acc, R), ksk, R)
+
+
+def gate2_level1(op, in0, in1, bk, ksk, R):
+    """__HomGate__<iksP, brP, mu, casign, cbsign, offset> on level-1 ciphertexts (N + 1 words): IdentityKeySwitchPreAdd
+    (the key switch of the linear combination), then __BlindRotate__ with the test vector mu, sample extract"""
+    ca, cb, off = GATES[op]
+    pre = [(ca * int(a) + cb * int(b)) & R.mask for a, b in zip(in0, in1)]
+    pre[R.N] = (pre[R.N] + off * MU0) & R.mask
+    acc = blind_rotate(keyswitch(pre, ksk, R), bk, R)
+    return sample_extract0(acc, R)
 
 
 def random_words(rng, count, bits=32):
@@ -169,31 +189,37 @@ def random_words(rng, count, bits=32):
 
 
 def main():
-    out = {"format": 1, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
+    out = {"format": 2, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
     t0 = time.time()
+    irng = np.random.default_rng(777)
+    ins0 = [random_words(irng, 631) for _ in range(3)]
+    ins1 = [random_words(irng, 1025) for _ in range(2)]
+    out["inputs_level0"] = [x.tolist() for x in ins0]
+    out["inputs_level1"] = [x.tolist() for x in ins1]
     # --- BASELINE set: n = 630, N = 1024
     krng = np.random.default_rng(20261004)
     bk = random_words(krng, LVL0_N * 6 * 2 * 1024).reshape(LVL0_N, 6, 2, 1024)
     ksk = random_words(krng, 1024 * 8 * 2 * 631).reshape(1024, 8, 2, 631)
-    irng = np.random.default_rng(777)
-    ins = [random_words(irng, 631) for _ in range(3)]
     key1 = {"seed": 20261004, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
-    print("NAND, N = 1024", flush=True)
-    out["cases"].append({"ring": 1024, "op": "NAND", "key": key1, "inputs": [x.tolist() for x in ins[:2]],
-                         "expected": gate_nand(ins[0], ins[1], bk, ksk, LVL1)})
-    print("MUX, N = 1024", flush=True)
-    out["cases"].append({"ring": 1024, "op": "MUX", "key": key1, "inputs": [x.tolist() for x in ins],
-                         "expected": gate_mux(ins[0], ins[1], ins[2], bk, ksk, LVL1)})
+    for op in GATES:
+        print(op, "N = 1024, level 0", flush=True)
+        out["cases"].append({"ring": 1024, "level": 0, "op": op, "key": key1, "operands": [0, 1], "expected": gate2(op, ins0[0], ins0[1], bk, ksk, LVL1)})
+    for op, neg in (("MUX", False), ("NMUX", True)):
+        print(op, "N = 1024, level 0", flush=True)
+        out["cases"].append({"ring": 1024, "level": 0, "op": op, "key": key1, "operands": [0, 1, 2],
+                             "expected": gate_mux(ins0[0], ins0[1], ins0[2], bk, ksk, LVL1, negate=neg)})
+    print("NAND, N = 1024, level 1", flush=True)
+    out["cases"].append({"ring": 1024, "level": 1, "op": "NAND", "key": key1, "operands": [0, 1],
+                         "expected": gate2_level1("NAND", ins1[0], ins1[1], bk, ksk, LVL1)})
     # --- N = 2048 ring, 64-bit torus
     krng = np.random.default_rng(20261005)
     bk2 = random_words(krng, LVL0_N * 8 * 2 * 2048, 64).reshape(LVL0_N, 8, 2, 2048)
     ksk2 = random_words(krng, 2048 * 7 * 2 * 631).reshape(2048, 7, 2, 631)
     key2 = {"seed": 20261005, "bk_sha256": hashlib.sha256(bk2.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk2.tobytes()).hexdigest()}
     print("NAND, N = 2048", flush=True)
-    out["cases"].append({"ring": 2048, "op": "NAND", "key": key2, "inputs": [x.tolist() for x in ins[:2]],
-                         "expected": gate_nand(ins[0], ins[1], bk2, ksk2, LVL2)})
+    out["cases"].append({"ring": 2048, "level": 0, "op": "NAND", "key": key2, "operands": [0, 1], "expected": gate2("NAND", ins0[0], ins0[1], bk2, ksk2, LVL2)})
     out["seconds"] = round(time.time() - t0, 1)
-    dst = os.path.join(HERE, "golden_independent_v1.json")
+    dst = os.path.join(HERE, "golden_independent_v2.json")
     json.dump(out, open(dst, "w"))
     print("wrote", dst, out["seconds"], "s")
 

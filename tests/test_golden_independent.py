@@ -1,9 +1,10 @@
 """Words of full-size gates against a fixture that shares no code with the oracle or the kernels.
 
-tests/golden/golden_independent_v1.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
+tests/golden/golden_independent_v2.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
 integers, the external product as an exact schoolbook negacyclic convolution (no transform), restated from the
-reference's text.  Both the C oracle (CPU test) and the HIP path (GPU test) must reproduce its words: one NAND and one
-MUX on the BASELINE set, one NAND through the N = 2048 ring.  Keys are regenerated from the fixture's seeds and checked
+reference's text.  Both the C oracle (CPU test) and the HIP path (GPU test) must reproduce its words: all ten two-input
+gates, MUX and NMUX on level-0 ciphertexts and NAND on level-1 ciphertexts of the BASELINE set, one NAND through the
+N = 2048 ring.  Keys are regenerated from the fixture's seeds and checked
 against its sha256 sums -- a mismatch there is a failure, not a skip."""
 import hashlib
 import json
@@ -14,8 +15,8 @@ import pytest
 
 import oracle_lib as ol
 
-FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v1.json")
-OPS = {"NAND": 0, "MUX": 10}
+FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v2.json")
+OPS = {n: i for i, n in enumerate(ol.OPS)}
 
 
 def words(count, rng, bits=32):
@@ -44,36 +45,43 @@ def keys_for(case):
     return _keys[(ring, seed)]
 
 
+def fixture():
+    return json.load(open(FIXTURE))
+
+
 def cases():
-    return json.load(open(FIXTURE))["cases"]
+    """(case, operand arrays, expected words)"""
+    fx = fixture()
+    for c in fx["cases"]:
+        ins = [np.array(fx["inputs_level%d" % c["level"]][i], np.uint32) for i in c["operands"]]
+        yield c, ins, np.array(c["expected"], np.uint32)
 
 
 def test_fixture_is_what_the_generator_describes():
-    fx = json.load(open(FIXTURE))
-    assert [(c["ring"], c["op"]) for c in fx["cases"]] == [(1024, "NAND"), (1024, "MUX"), (2048, "NAND")]
-    assert all(len(c["expected"]) == 631 for c in fx["cases"])
+    fx = fixture()
+    got = [(c["ring"], c["level"], c["op"]) for c in fx["cases"]]
+    assert got == [(1024, 0, op) for op in ol.OPS[:12]] + [(1024, 1, "NAND"), (2048, 0, "NAND")]
+    assert all(len(c["expected"]) == (1025 if c["level"] else 631) for c in fx["cases"])
     src = open(os.path.join(ol.ROOT, "tests", "golden", "make_golden_independent.py")).read()
     assert "import oracle" not in src and "cufhe_amd" not in src.split('"""')[2], "the generator must not share code with the oracle or the product"
 
 
 def test_oracle_words_match_independent_generator(oracle):
     L = oracle
-    for case in cases():
+    for case, ins, want in cases():
         bk, ksk = keys_for(case)
-        ins = [np.array(x, np.uint32) for x in case["inputs"]]
-        want = np.array(case["expected"], np.uint32)
-        got = np.zeros(631, np.uint32)
+        got = np.zeros(want.size, np.uint32)
         op = np.array([OPS[case["op"]]], np.int32)
         third = ins[2].ctypes.data if len(ins) > 2 else None
         if case["ring"] == 1024:
             ek = L.orc_evalkey_create(bk, ksk)
-            L.orc_gate_batch(ek, op, 0, 0, 1, got, ins[0], ins[1].ctypes.data, third, 1)
+            L.orc_gate_batch(ek, op, 0, case["level"], 1, got, ins[0], ins[1].ctypes.data, third, 1)
             L.orc_evalkey_destroy(ek)
         else:
             ek = L.orc2_evalkey_create(bk, ksk)
             L.orc2_gate_batch(ek, op, 0, 1, got, ins[0], ins[1].ctypes.data, third, 1)
             L.orc2_evalkey_destroy(ek)
-        assert np.array_equal(got, want), f"oracle words differ from the independent generator: ring {case['ring']} {case['op']}"
+        assert np.array_equal(got, want), f"oracle words differ from the independent generator: ring {case['ring']} level {case['level']} {case['op']}"
 
 
 GPU_CHILD = r'''
@@ -84,24 +92,26 @@ import test_golden_independent as tg
 import cufhe_amd as eng
 api = eng.api
 eng.SetGPUNum(1)
-for case in tg.cases():
+loaded = None
+for case, ins, want in tg.cases():
     bk, ksk = tg.keys_for(case)
-    if case["ring"] == 1024:
-        eng.Initialize(bk, ksk)
-    else:
-        eng.Initialize()
-        api.lvl2_initialize(bk, ksk)
-    ins = [np.array(x, np.uint32) for x in case["inputs"]]
-    d = [api.DeviceBuffer(631).upload(x) for x in ins]
-    out = api.DeviceBuffer(631)
+    if loaded != case["ring"]:
+        if case["ring"] == 1024:
+            eng.Initialize(bk, ksk)
+        else:
+            eng.Initialize()
+            api.lvl2_initialize(bk, ksk)
+        loaded = case["ring"]
+    d = [api.DeviceBuffer(x.size).upload(x) for x in ins]
+    out = api.DeviceBuffer(want.size)
     third = d[2] if len(d) > 2 else None
     if case["ring"] == 1024:
-        api.gate_batch(tg.OPS[case["op"]], 0, out, d[0], d[1], third, count=1)
+        api.gate_batch(tg.OPS[case["op"]], case["level"], out, d[0], d[1], third, count=1)
     else:
         api.lvl2_gate_batch(tg.OPS[case["op"]], out, d[0], d[1], third, count=1)
     eng.Synchronize()
-    assert np.array_equal(out.download(), np.array(case["expected"], np.uint32)), \
-        f"HIP words differ from the independent generator: ring {case['ring']} {case['op']}"
+    assert np.array_equal(out.download(), want), \
+        f"HIP words differ from the independent generator: ring {case['ring']} level {case['level']} {case['op']}"
 eng.CleanUp()
 print("child ok")
 '''
