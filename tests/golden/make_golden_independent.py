@@ -13,11 +13,12 @@ convolution in 64-bit integers (no transform, no prime, no floating point), writ
   sample extract at index 0           src/bootstrap_gpu.cu:366-381
   key switch                          include/keyswitch_gpu.cuh:13-23 (iksoffsetgen), :83-134 (KeySwitchFromTLWE)
 
-It writes tests/golden/golden_independent_v2.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
+It writes tests/golden/golden_independent_v3.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
 NMUX on level-0 ciphertexts (blind rotate, then key switch), NAND on level-1 ciphertexts (the other order:
 IdentityKeySwitchPreAdd, then __BlindRotate__; src/bootstrap_gpu.cu:383-400, include/keyswitch_gpu.cuh:136-188), and one
 NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
-defines that path).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
+defines that path); NAND, XOR and MUX on the k = 2 / N = 512 set and NAND, ORYN on the n = 500 / l = 2 / Bg = 2^10 set
+(DESIGN.md 5b).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
 key words define a word-level check); the fixture stores the seeds, a sha256 of each generated key, the inputs and the
 expected output words.  Takes a few minutes; run in the build container only:  python tests/golden/make_golden_independent.py
 """
@@ -31,15 +32,15 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-LVL0_N = 630
 MU0 = 1 << 29            # lvl0 / lvl1 message scale
 
 
 class Ring:
     """the target ring of a blind rotation and the key switch back to lvl0"""
 
-    def __init__(self, N, nbit, l, Bgbit, bits, mu, t, basebit):
+    def __init__(self, N, nbit, l, Bgbit, bits, mu, t, basebit, n=630, k=1):
         self.N, self.nbit, self.l, self.Bgbit, self.bits, self.mu, self.t, self.basebit = N, nbit, l, Bgbit, bits, mu, t, basebit
+        self.n, self.k = n, k                            # lvl0 dimension; mask polynomials of the ring
         self.mask = (1 << bits) - 1
         i = np.arange(N)[:, None]
         m = np.arange(N)[None, :]
@@ -49,6 +50,10 @@ class Ring:
 
 LVL1 = Ring(N=1024, nbit=10, l=3, Bgbit=6, bits=32, mu=1 << 29, t=8, basebit=2)
 LVL2 = Ring(N=2048, nbit=11, l=4, Bgbit=9, bits=64, mu=1 << 61, t=7, basebit=2)
+# the other parameter sets compiled into the library (cufhe_amd/csrc/kernels_ps.hip.h; the reference selects them at build
+# time, CMakeLists.txt:8-24; k > 1: src/bootstrap_gpu.cu:402-421, include/gatebootstrapping_gpu.cuh:153-224)
+K2N512 = Ring(N=512, nbit=9, l=3, Bgbit=6, bits=32, mu=1 << 29, t=8, basebit=2, n=630, k=2)
+CGGI16 = Ring(N=1024, nbit=10, l=2, Bgbit=10, bits=32, mu=1 << 29, t=8, basebit=2, n=500, k=1)
 
 
 def modswitch(phase32, R):
@@ -57,7 +62,7 @@ def modswitch(phase32, R):
 
 
 def rotated_test_vector(bar, R):
-    """RotatedTestVector: a = 0, b = X^bar * (mu + mu X + ...), python ints mod 2^bits"""
+    """RotatedTestVector: the k mask polynomials 0, b = X^bar * (mu + mu X + ...), python ints mod 2^bits"""
     b = []
     for i in range(R.N):
         if bar == 2 * R.N:
@@ -65,7 +70,7 @@ def rotated_test_vector(bar, R):
         else:
             neg = (i < (bar & (R.N - 1))) ^ ((bar >> R.nbit) & 1)
             b.append((-R.mu) & R.mask if neg else R.mu)
-    return [[0] * R.N, b]
+    return [[0] * R.N for _ in range(R.k)] + [b]
 
 
 def gadget_digits(acc_j, abar, R):
@@ -85,24 +90,24 @@ def gadget_digits(acc_j, abar, R):
 
 
 def blind_rotate(c, bk, R):
-    """__BlindRotatePreAdd__ after the pre-add: c = 631 words of the linear combination (32-bit python ints).
-    bk: uint32 (lvl1) or uint64 (lvl2) array [n][(k+1) l][k+1][N].  Returns the accumulator [2][N] (python ints)."""
-    N = R.N
-    acc = rotated_test_vector(2 * N - modswitch(c[LVL0_N], R), R)
+    """__BlindRotatePreAdd__ after the pre-add: c = n + 1 words of the linear combination (32-bit python ints).
+    bk: uint32 or uint64 array [n][(k+1) l][k+1][N].  Returns the accumulator [k+1][N] (python ints)."""
+    N, K1 = R.N, R.k + 1
+    acc = rotated_test_vector(2 * N - modswitch(c[R.n], R), R)
     roundoffset = 1 << (32 - 2 - R.nbit)
-    rows = 2 * R.l
-    for i in range(LVL0_N):
+    rows = K1 * R.l
+    for i in range(R.n):
         abar = modswitch(c[i] + roundoffset, R)
         # negacyclic matrices of the (k+1) l digit polynomials, side by side: [N][rows * N]
         T = np.empty((N, rows * N), np.int64)
-        for j in range(2):
+        for j in range(K1):
             for d, dig in enumerate(gadget_digits(acc[j], abar, R)):
                 r = j * R.l + d
                 T[:, r * N:(r + 1) * N] = dig[R.conv_idx] * R.conv_sign
-        key = bk[i]                                          # [rows][2][N]
-        for o in range(2):
+        key = bk[i]                                          # [rows][k+1][N]
+        for o in range(K1):
             if R.bits == 32:
-                col = key[:, o, :].reshape(rows * N).astype(np.int64)     # < 2^32: exact in int64, |sum| < 2^50
+                col = key[:, o, :].reshape(rows * N).astype(np.int64)     # < 2^32: exact in int64, |sum| < 2^53
                 s = T @ col
                 add = [int(v) & R.mask for v in s]
             else:
@@ -113,25 +118,28 @@ def blind_rotate(c, bk, R):
                 add = [(int(a) + (int(b) << 32)) & R.mask for a, b in zip(slo, shi)]
             acc[o] = [(x + y) & R.mask for x, y in zip(acc[o], add)]
         if i % 90 == 0:
-            print(f"    step {i}/{LVL0_N}", flush=True)
+            print(f"    step {i}/{R.n}", flush=True)
     return acc
 
 
 def sample_extract0(acc, R):
-    """__SampleExtractIndex__<P, 0>: N + 1 words"""
+    """__SampleExtractIndex__<P, 0>: k N + 1 words"""
     N = R.N
-    out = [acc[0][0]] + [(-acc[0][N - m]) & R.mask for m in range(1, N)]
-    return out + [acc[1][0]]
+    out = []
+    for kk in range(R.k):
+        out += [acc[kk][0]] + [(-acc[kk][N - m]) & R.mask for m in range(1, N)]
+    return out + [acc[R.k][0]]
 
 
 def keyswitch(tlwe, ksk, R):
-    """KeySwitchFromTLWE: tlwe N + 1 words of R.bits bits -> 631 32-bit words.  ksk: uint32 [N][t][2][631]"""
+    """KeySwitchFromTLWE: tlwe k N + 1 words of R.bits bits -> n + 1 32-bit words.  ksk: uint32 [k N][t][2][n + 1]"""
     roundoffset = 1 << (R.bits - (1 + R.basebit * R.t))
     decompoffset = sum((1 << (R.basebit - 1)) << (R.bits - i * R.basebit) for i in range(1, R.t + 1))
-    res = np.zeros(LVL0_N + 1, np.int64)
-    b = tlwe[R.N]
-    res[LVL0_N] = b if R.bits == 32 else ((b + (1 << 31)) & R.mask) >> 32
-    for j in range(R.N):
+    kN = R.k * R.N
+    res = np.zeros(R.n + 1, np.int64)
+    b = tlwe[kN]
+    res[R.n] = b if R.bits == 32 else ((b + (1 << 31)) & R.mask) >> 32
+    for j in range(kN):
         tmp = (tlwe[j] + decompoffset + roundoffset) & R.mask
         for k in range(R.t):
             val = ((tmp >> (R.bits - (k + 1) * R.basebit)) & ((1 << R.basebit) - 1)) - (1 << (R.basebit - 1))
@@ -145,7 +153,7 @@ def keyswitch(tlwe, ksk, R):
 
 def lincomb(ca, in0, cb, in1, off):
     c = [(ca * int(a) + cb * int(b)) & 0xFFFFFFFF for a, b in zip(in0, in1)]
-    c[LVL0_N] = (c[LVL0_N] + off) & 0xFFFFFFFF
+    c[-1] = (c[-1] + off) & 0xFFFFFFFF
     return c
 
 
@@ -167,8 +175,8 @@ def gate_mux(inc, in1, in0, bk, ksk, R, negate=False):
     a1 = blind_rotate(lincomb(1, inc, 1, in1, -MU0), bk, R)
     a0 = blind_rotate(lincomb(-1, inc, 1, in0, -MU0), bk, R)
     sgn = -1 if negate else 1
-    acc = [[(sgn * (x + y)) & R.mask for x, y in zip(a1[j], a0[j])] for j in range(2)]
-    acc[1][0] = (acc[1][0] + sgn * R.mu) & R.mask
+    acc = [[(sgn * (x + y)) & R.mask for x, y in zip(a1[j], a0[j])] for j in range(R.k + 1)]
+    acc[R.k][0] = (acc[R.k][0] + sgn * R.mu) & R.mask
     return keyswitch(sample_extract0(acc, R), ksk, R)
 
 
@@ -177,7 +185,7 @@ def gate2_level1(op, in0, in1, bk, ksk, R):
     (the key switch of the linear combination), then __BlindRotate__ with the test vector mu, sample extract"""
     ca, cb, off = GATES[op]
     pre = [(ca * int(a) + cb * int(b)) & R.mask for a, b in zip(in0, in1)]
-    pre[R.N] = (pre[R.N] + off * MU0) & R.mask
+    pre[R.k * R.N] = (pre[R.k * R.N] + off * MU0) & R.mask
     acc = blind_rotate(keyswitch(pre, ksk, R), bk, R)
     return sample_extract0(acc, R)
 
@@ -188,38 +196,56 @@ def random_words(rng, count, bits=32):
     return rng.integers(0, 2**64, size=count, dtype=np.uint64)
 
 
+def key_for(seed, R):
+    rng = np.random.default_rng(seed)
+    K1 = R.k + 1
+    bk = random_words(rng, R.n * K1 * R.l * K1 * R.N, R.bits).reshape(R.n, K1 * R.l, K1, R.N)
+    ksk = random_words(rng, R.k * R.N * R.t * 2 * (R.n + 1)).reshape(R.k * R.N, R.t, 2, R.n + 1)
+    return bk, ksk, {"seed": seed, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
+
+
 def main():
-    out = {"format": 2, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
+    out = {"format": 3, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
     t0 = time.time()
     irng = np.random.default_rng(777)
     ins0 = [random_words(irng, 631) for _ in range(3)]
     ins1 = [random_words(irng, 1025) for _ in range(2)]
-    out["inputs_level0"] = [x.tolist() for x in ins0]
-    out["inputs_level1"] = [x.tolist() for x in ins1]
+    ins500 = [random_words(irng, 501) for _ in range(2)]
+    out["inputs"] = {"level0": [x.tolist() for x in ins0], "level1": [x.tolist() for x in ins1], "level0_n500": [x.tolist() for x in ins500]}
     # --- BASELINE set: n = 630, N = 1024
-    krng = np.random.default_rng(20261004)
-    bk = random_words(krng, LVL0_N * 6 * 2 * 1024).reshape(LVL0_N, 6, 2, 1024)
-    ksk = random_words(krng, 1024 * 8 * 2 * 631).reshape(1024, 8, 2, 631)
-    key1 = {"seed": 20261004, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
+    bk, ksk, key1 = key_for(20261004, LVL1)
     for op in GATES:
-        print(op, "N = 1024, level 0", flush=True)
-        out["cases"].append({"ring": 1024, "level": 0, "op": op, "key": key1, "operands": [0, 1], "expected": gate2(op, ins0[0], ins0[1], bk, ksk, LVL1)})
+        print(op, "default set, level 0", flush=True)
+        out["cases"].append({"set": "default", "level": 0, "op": op, "key": key1, "inputs": "level0", "operands": [0, 1],
+                             "expected": gate2(op, ins0[0], ins0[1], bk, ksk, LVL1)})
     for op, neg in (("MUX", False), ("NMUX", True)):
-        print(op, "N = 1024, level 0", flush=True)
-        out["cases"].append({"ring": 1024, "level": 0, "op": op, "key": key1, "operands": [0, 1, 2],
+        print(op, "default set, level 0", flush=True)
+        out["cases"].append({"set": "default", "level": 0, "op": op, "key": key1, "inputs": "level0", "operands": [0, 1, 2],
                              "expected": gate_mux(ins0[0], ins0[1], ins0[2], bk, ksk, LVL1, negate=neg)})
-    print("NAND, N = 1024, level 1", flush=True)
-    out["cases"].append({"ring": 1024, "level": 1, "op": "NAND", "key": key1, "operands": [0, 1],
+    print("NAND, default set, level 1", flush=True)
+    out["cases"].append({"set": "default", "level": 1, "op": "NAND", "key": key1, "inputs": "level1", "operands": [0, 1],
                          "expected": gate2_level1("NAND", ins1[0], ins1[1], bk, ksk, LVL1)})
+    # --- the other compiled parameter sets
+    bk, ksk, key = key_for(20261006, K2N512)
+    for op in ("NAND", "XOR"):
+        print(op, "k2n512 (N = 512, k = 2)", flush=True)
+        out["cases"].append({"set": "k2n512", "level": 0, "op": op, "key": key, "inputs": "level0", "operands": [0, 1],
+                             "expected": gate2(op, ins0[0], ins0[1], bk, ksk, K2N512)})
+    print("MUX, k2n512", flush=True)
+    out["cases"].append({"set": "k2n512", "level": 0, "op": "MUX", "key": key, "inputs": "level0", "operands": [0, 1, 2],
+                         "expected": gate_mux(ins0[0], ins0[1], ins0[2], bk, ksk, K2N512)})
+    bk, ksk, key = key_for(20261007, CGGI16)
+    for op in ("NAND", "ORYN"):
+        print(op, "cggi16 (n = 500, l = 2, Bg = 2^10)", flush=True)
+        out["cases"].append({"set": "cggi16", "level": 0, "op": op, "key": key, "inputs": "level0_n500", "operands": [0, 1],
+                             "expected": gate2(op, ins500[0], ins500[1], bk, ksk, CGGI16)})
     # --- N = 2048 ring, 64-bit torus
-    krng = np.random.default_rng(20261005)
-    bk2 = random_words(krng, LVL0_N * 8 * 2 * 2048, 64).reshape(LVL0_N, 8, 2, 2048)
-    ksk2 = random_words(krng, 2048 * 7 * 2 * 631).reshape(2048, 7, 2, 631)
-    key2 = {"seed": 20261005, "bk_sha256": hashlib.sha256(bk2.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk2.tobytes()).hexdigest()}
+    bk2, ksk2, key2 = key_for(20261005, LVL2)
     print("NAND, N = 2048", flush=True)
-    out["cases"].append({"ring": 2048, "level": 0, "op": "NAND", "key": key2, "operands": [0, 1], "expected": gate2("NAND", ins0[0], ins0[1], bk2, ksk2, LVL2)})
+    out["cases"].append({"set": "lvl2", "level": 0, "op": "NAND", "key": key2, "inputs": "level0", "operands": [0, 1],
+                         "expected": gate2("NAND", ins0[0], ins0[1], bk2, ksk2, LVL2)})
     out["seconds"] = round(time.time() - t0, 1)
-    dst = os.path.join(HERE, "golden_independent_v2.json")
+    dst = os.path.join(HERE, "golden_independent_v3.json")
     json.dump(out, open(dst, "w"))
     print("wrote", dst, out["seconds"], "s")
 
