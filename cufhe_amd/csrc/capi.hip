@@ -87,14 +87,22 @@ int phys_device(int device)
 }
 long g_wg_threshold = 0;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_split_threshold = -1; // key switches per launch up to which each ciphertext is split over 8 workgroups
-// Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, MI355X, ms per launch of n key switches):
+// Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, tools/ks_per_wg.py, MI355X, ms per launch of n key switches):
 //   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.66 (2048)
-//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.18 (1536)  1.57 (2048)  3.10 (4096)
-//   16 ciphertexts per workgroup, table through LDS: 1.5 - 1.6 whatever n <= 4096 (1024 dependent steps)
-// so: split up to 192, one workgroup per ciphertext up to 1900, the shared-table kernel above.
-constexpr long kKsAutoSplit = 192, kKsAutoWg = 1900;
+//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.18 (1536)  1.38 (1792)  1.57 (2048)  3.10 (4096)
+//   table through LDS, ceil(n / 256) ciphertexts per workgroup (one grid round, every CU busy):
+//                                 0.94 (256)  1.07 (512)  1.17 (1024)  1.23 (1536)  1.27 (2048)  1.39 (3072)  1.55 (4096)
+//     (round 2 always put 16 per workgroup: 1.53 - 1.59 whatever n <= 4096)
+// so: split up to 192, one workgroup per ciphertext up to 1600, the shared-table kernel above.
+constexpr long kKsAutoSplit = 192, kKsAutoWg = 1600;
 long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
+long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16
+int ks_auto_per_wg(size_t count)
+{
+    const size_t p = (count + 255) / 256;      // one grid round of 256 workgroups with the fewest ciphertexts each
+    return (int)(p < 1 ? 1 : p > 16 ? 16 : p);
+}
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
@@ -461,8 +469,10 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
     } else if ((long)count <= wg_max) {
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
-        const unsigned ks_blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
-        hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk);
+        // as few ciphertexts per workgroup as still fit one grid round of 256 workgroups (g_ks_per_wg: -1 by count, else 1..16)
+        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count);
+        const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg);
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk, per_wg);
     }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
@@ -1143,6 +1153,11 @@ int cufhe_amd_set_option(const char* key, long value)
             if ((int)p.lvl0_words != kLvl0Words) return fail(-1, "lvl0_param_set: the set's lvl0 ciphertexts differ in size from the per-gate API's (n must be 630)");
         }
         g_lvl0_param_set = value;
+        return 0;
+    }
+    if (!strcmp(key, "ks_per_wg")) {
+        if (value != -1 && (value < 1 || value > 16)) return fail(-1, "ks_per_wg must be -1 or 1..16");
+        g_ks_per_wg = value;
         return 0;
     }
     if (!strcmp(key, "lvl0_ring")) {

@@ -39,7 +39,9 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
                 HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
                 s.ks_lds_opt_in = true;
             }
-            hipLaunchKernelGGL(keyswitch_kernel, dim3(blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, ps.ksk_padded);
+            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count);
+            hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count,
+                               ps.ksk_padded, per_wg);
         } else {
             if (!ps.ks_lds_opt_in) {
                 HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_ps_shared_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsKs<PS>::lds_bytes));
