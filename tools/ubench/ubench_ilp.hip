@@ -25,7 +25,12 @@ __global__ void k(double* out, unsigned long long* cyc, double w, double c)
             double& v = x[u % ILP];
             if (OP == 0) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v) : "v"(w), "v"(c));
             else if (OP == 1) asm volatile("v_add_f64 %0, %0, %1" : "+v"(v) : "v"(c));
-            else asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v) : "v"(w));
+            else if (OP == 2) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(v) : "v"(w));
+            else if (OP == 3) { int t; asm volatile("v_cvt_i32_f64 %0, %1\n\tv_cvt_f64_i32 %1, %0" : "=&v"(t), "+v"(v)); }      // two conversions
+            else if (OP == 4) { unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+                                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi)); v = __hiloint2double((int)hi, (int)lo); }
+            else if (OP == 5) { unsigned lo = (unsigned)__double2loint(v); asm volatile("v_bfe_i32 %0, %0, 3, 6" : "+v"(lo)); v = __hiloint2double(__double2hiint(v), (int)lo); }
+            else { unsigned lo = (unsigned)__double2loint(v); asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(lo)); v = __hiloint2double(__double2hiint(v), (int)lo); }
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -58,6 +63,10 @@ int main()
         run<1, 0>("v_fma_f64", threads); run<2, 0>("v_fma_f64", threads); run<3, 0>("v_fma_f64", threads); run<4, 0>("v_fma_f64", threads); run<8, 0>("v_fma_f64", threads);
         run<1, 1>("v_add_f64", threads); run<2, 1>("v_add_f64", threads); run<4, 1>("v_add_f64", threads);
         run<1, 2>("v_mul_f64", threads); run<2, 2>("v_mul_f64", threads); run<4, 2>("v_mul_f64", threads);
+        run<1, 3>("2 x cvt", threads); run<4, 3>("2 x cvt", threads);
+        run<1, 4>("permlane32", threads); run<4, 4>("permlane32", threads);
+        run<1, 5>("v_bfe_i32", threads); run<4, 5>("v_bfe_i32", threads);
+        run<1, 6>("v_add_u32", threads); run<4, 6>("v_add_u32", threads);
     }
     return 0;
 }
