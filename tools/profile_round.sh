@@ -2,7 +2,7 @@
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* and profiles/kernel_facts.json.
 # Run on the GPU box from the repo root (gpurun -- 'bash tools/profile_round.sh r03').  The profiled command is the default
 # bench run (every workload of the driver line: the headline batch, mux, mixed, the N = 2048 ring, a 512-gate launch on the
-# paired low-latency kernel, the three parameter sets, the key switches): one --stats pass and four --pmc passes, each its own
+# paired low-latency kernel, the three parameter sets, the key switches): one --stats pass and five --pmc passes, each its own
 # process with python3 directly behind `--`, --pmc never combined with --stats / sys traces (MI355X_MICROARCH.md, rocprofv3
 # PMC slots: 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -e
@@ -22,4 +22,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc --output-form
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
 echo "tcc pass done"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU \
+    --kernel-trace -d $OUT/pmc_mix -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+echo "instruction-mix pass done"
 find $OUT -name "*.csv" | head -40
