@@ -64,6 +64,14 @@ def parse_args(argv=None):
     ap.add_argument("--gates", type=int, default=4096, help="gates per GPU per step")
     ap.add_argument("--total-gates", type=int, default=0,
                     help="strong scaling: this many gates per step split contiguously over the ranks (configs[2]: 32768)")
+    ap.add_argument("--mode", choices=["ranks", "api"], default="ranks",
+                    help="ranks = one process per GPU (the driver's form; default).  api = ONE process drives --gpus G devices through "
+                         "SetGPUNum(G) and round-robin Streams, the reference's own multi-GPU shape (include/cufhe_gpu.cuh:154-165, "
+                         "test/test_gate_gpu_multi.cc:36-93): per-gate API on host ciphertexts, PCIe-inclusive")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let ranks (or logical devices) share a physical GPU: a rehearsal, labelled shared_gpu in the line with "
+                         "n_gpus = the distinct GPUs; without it such a run exits non-zero")
+    ap.add_argument("--no-api", action="store_true", help="skip the per-gate API subprocess (profiling passes: one launch shape per kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_workloads / api_pcie_inclusive / latency")
     ap.add_argument("--workload", choices=["nand", "mux", "mixed", "nand_lvl2"], default="nand",
@@ -87,8 +95,47 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def api_mode(args):
+    """`--mode api --gpus G`: ONE process, SetGPUNum(G), Streams round-robin over the devices -- the reference's
+    multi-GPU shape (include/cufhe_gpu.cuh:154-165; test/test_gate_gpu_multi.cc:36-93).  The host side is C++ over the C
+    ABI (tools/bench_api.cpp, the cuFHE names of include/cufhe_amd.hpp); this process only starts it and relays one line.
+    A step = gates * G cufhe::Nand calls on host-resident ciphertexts over 256 streams, then Synchronize(): H2D and D2H of
+    every ciphertext are inside the timed region (test/test_util.h:29-72), so `value` here is the PCIe-inclusive rate."""
+    exe = os.path.join(ROOT, "tools", "bench_api")
+    total = args.gates * args.gpus
+    cmd = [exe, str(total), "gpus=%d" % args.gpus, "reps=%d" % (args.steps + args.warmup), "netlist=0", "identify=1"]
+    if args.allow_shared_gpu:
+        cmd.append("share_devices=1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("CUFHE_AMD_BENCH_LAUNCH_TIMEOUT", "1500")))
+    sys.stderr.write(p.stderr[-4000:])
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write("bench.py --mode api: tools/bench_api exited with %d\n" % p.returncode)
+        sys.exit(p.returncode or 1)
+    r = lines[0]
+    res = {
+        "metric": "nand_gate_bootstraps_per_sec", "value": r["gates_per_s"], "unit": "gate-bootstraps/s",
+        "n_gpus": r["distinct_gpus"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["total_ms"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.gates} independent NAND gates per GPU per step (BASELINE configs[1] per device), one process: "
+                               f"SetGPUNum({args.gpus}), 256 Streams round-robin over the devices, per-gate API on HOST ciphertexts "
+                               "(PCIe-inclusive: enqueue -> Synchronize), TFHE n=630 N=1024 k=1 l=3 Bgbit=6 t=8 basebit=2",
+                   "mode": "api", "gates_per_gpu": args.gates, "logical_devices": args.gpus,
+                   "sharding": "stream i -> device i mod G (include/cufhe_gpu.cuh:154-159), per-GPU BK/KSK replica, no collective"},
+        "per_device": r.get("per_device"), "distinct_gpus": r["distinct_gpus"],
+        "value_is": "PCIe-inclusive (best of the timed repetitions); the inputs-resident metric of the driver line is --mode ranks",
+        "api": r,
+    }
+    if r["distinct_gpus"] < args.gpus:
+        res["shared_gpu"] = True
+    print(json.dumps(res), flush=True)
+    sys.exit(0)
+
+
 if __name__ == "__main__":
     ARGS = parse_args()
+    if ARGS.mode == "api":
+        api_mode(ARGS)               # does not return; this process never touches the GPU
     if "WORLD_SIZE" not in os.environ and ARGS.gpus > 1:
         self_launch(ARGS)            # does not return
 
@@ -104,8 +151,9 @@ SIMDS = 1024                              # 256 CUs x 4
 
 FP64_ISSUE_CYCLES_SPEC = 4.0              # data sheet: 64 lanes over a 16-lane FP64 pipe (78.6 TFLOP/s)
 FP64_ISSUE_CYCLES_MEASURED = 4.34         # tools/ubench/ubench_ilp.hip on MI355X: two waves per SIMD, v_fma_f64 back to back
+# device code AND the host files that decide launch shapes (units per workgroup are part of what the PMC facts assume)
 DEVICE_SOURCES = ("fpfield.h", "ntt_wave.h", "ntt_wave512.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_ll.hip.h",
-                  "kernels_lvl2.hip.h", "kernels_ks2.hip.h", "kernels_ps.hip.h")
+                  "kernels_lvl2.hip.h", "kernels_lvl2q.hip.h", "kernels_ks2.hip.h", "kernels_ps.hip.h", "capi.hip", "lvl2.inc.h", "paramsets.inc.h")
 
 
 def source_hash():
@@ -113,6 +161,8 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "cufhe_amd", "csrc")
     for f in DEVICE_SOURCES:
+        if not os.path.exists(os.path.join(d, f)):
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()
@@ -141,6 +191,13 @@ def kernel_facts(kernel):
     return k, _FACTS.get("recorded", "")
 
 
+def replayed_from(passes):
+    """names of the committed rocprofv3 CSVs a replayed figure comes from (profiles/kernel_facts.json lists them)"""
+    src = (_FACTS or {}).get("sources") or []
+    pick = [f for f in src if any(("_pmc_%s_" % p) in f for p in passes)]
+    return ["profiles/" + f for f in (pick or src)] or "profiles/kernel_facts.json"
+
+
 def valu_block(kernel, rotations, launch_ms, clock_hz):
     """What actually bounds these kernels: FP64 VALU issue.  Instruction count per rotation from the PMC pass (a property
     of the code), launch time and shader clock from this run."""
@@ -159,6 +216,7 @@ def valu_block(kernel, rotations, launch_ms, clock_hz):
         "lds_bank_conflict_frac": facts.get("lds_bank_conflict_frac"),
         "waves_per_simd": facts.get("waves_per_simd"),
         "pmc_source": note,
+        "replayed_from": replayed_from(("sq", "lds", "mix")),
     }
 
 
@@ -242,6 +300,20 @@ def main():
     import cufhe_amd as eng                  # fails loudly if the HIP library is missing
     eng.api.set_option("device_base", DEV)   # logical device 0 of this process = this rank's GPU
     api = eng.api
+    # Which PHYSICAL GPU is this rank on?  device_for_rank wraps when fewer devices are visible than ranks, and a line that says
+    # n_gpus = N must have been measured on N GPUs: every rank reports the PCI function / UUID of its device (HIP runtime, through
+    # the C ABI), all ranks see the gathered list and all take the same decision before any work is done.
+    identity = api.device_identity(0)
+    identities = distutil.gather_objects(identity, dist)
+    try:
+        distinct_gpus, shared_gpu = distutil.check_distinct_gpus(identities, args.allow_shared_gpu)
+    except distutil.SharedGpuError as e:
+        if RANK == 0:
+            sys.stderr.write("bench.py: %s\n" % e)
+        if WORLD > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
 
     class ol:                                 # sizes come from the library, not from the oracle
         n, N = int(eng.PARAMS.n), int(eng.PARAMS.N)
@@ -299,13 +371,20 @@ def main():
         eng.Synchronize()
         torch.cuda.synchronize()
 
+    own = {}
+
     def timed(workload, steps, warmup):
+        """K steps bracketed by barrier + synchronize on both sides; own["s"] = this rank's own time (its GPU idle again,
+        before it waits for the other ranks)"""
         for _ in range(warmup):
             run_step(workload)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             run_step(workload)
+        eng.Synchronize()
+        torch.cuda.synchronize()
+        own["s"] = time.perf_counter() - t0
         barrier()
         return time.perf_counter() - t0
 
@@ -341,13 +420,24 @@ def main():
         }
         if facts:
             r["traffic"] = facts["hbm_bytes_per_rotation"] * rotations
+            r["traffic_replayed_from"] = replayed_from(("fetch", "tcc"))
         r["valu"] = valu_block(kernel, rotations, br_ms, clock_hz)
-        return r
+        # the number that says how close the kernel is to what bounds it, next to the accounting fraction
+        r["frac_valu_fp64"] = r["valu"].get("frac_of_fp64_issue")
+        r["frac_valu_fp64_is"] = ("VALU instructions of the launch (replayed PMC count per rotation) x 4 cycles / SIMD-cycles of the launch "
+                                  "(launch_ms and shader clock measured in THIS run)")
+        return {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_valu_fp64", "traffic")} | r
 
     wl = args.workload
     elapsed = distutil.max_over_ranks(timed(wl, args.steps, args.warmup), dist)
+    own_s = own["s"]
     br_ms, ks_ms = kernel_times(wl)
     clock_hz = api.probe_clock()          # shader clock under an FP64 load, this box, this run (prices `valu`)
+    # every rank's own rate, device and launch times, gathered on all ranks (gloo): rank 0 prints them
+    reports = distutil.gather_objects({
+        "rank": RANK, "local_rank": LOCAL_RANK, "hip_device": DEV, "gpu": identity, "gates_per_step": count,
+        "value": count * args.steps / own_s if own_s > 0 else None, "ms_per_step": 1e3 * own_s / args.steps,
+        "blind_rotate_launch_ms": br_ms, "keyswitch_launch_ms": ks_ms, "clock_hz": clock_hz}, dist)
 
     extras_on = RANK == 0 and WORLD == 1 and not args.no_extra and not strong
     latency_ms = None
@@ -369,7 +459,8 @@ def main():
             "metric": "nand_gate_bootstraps_per_sec" if wl == "nand" else f"{wl}_gates_per_sec",
             "value": gates_per_step * args.steps / elapsed,
             "unit": "gate-bootstraps/s",
-            "n_gpus": WORLD,
+            "n_gpus": distinct_gpus,       # == WORLD unless ranks share a GPU (--allow-shared-gpu: `shared_gpu`, `ranks`)
+            "ranks": WORLD,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -388,12 +479,13 @@ def main():
                 "sharding": "gates split across ranks, per-GPU BK/KSK replica, no collective",
             },
             "ms_per_gate_throughput": 1e3 * elapsed / (gates_per_step * args.steps) * WORLD,
+            **distutil.rank_summary(reports, args.allow_shared_gpu),
             "ms_per_gate_latency_single_gate": latency_ms,
             "roofline": roofline(wl, br_ms, ks_ms),
         }
         main_out = dout.download().reshape(max(count, 1), ol.n + 1)[:count]
 
-        if extras_on:
+        if extras_on and not args.no_api:
             # the reference-style per-gate API, PCIe-inclusive (host-resident ciphertexts, 256 streams,
             # enqueue -> Synchronize): its own process, this one is idle meanwhile
             exe = os.path.join(ROOT, "tools", "bench_api")
@@ -474,15 +566,23 @@ def main():
                     extra["nand_512"] = {"ms_per_step": mbr + mp.keyswitch_ms / max(mp.keyswitch_launches, 1),
                                          "blind_rotate_launch_ms": mbr, "kernel": "blind_rotate_ll2_kernel", "bound": "valu_fp64",
                                          "valu": valu_block("blind_rotate_ll2_kernel", 512, mbr, clock_hz)}
-                    kfacts, knote = kernel_facts("keyswitch_kernel")
-                    extra["keyswitch_4096"] = {"launch_ms": ks_ms, "kernel": "keyswitch_kernel", "bound": "lds",
-                                               "algorithmic_bytes": 4096 * 15507456,
-                                               "lds_pipe_busy_under_profiler": kfacts.get("lds_pipe_busy") if kfacts else None,
-                                               "valu_pipe_busy_under_profiler": kfacts.get("valu_pipe_busy") if kfacts else None,
-                                               "lds_bank_conflict_frac": kfacts.get("lds_bank_conflict_frac") if kfacts else None,
-                                               "pmc_source": knote}
                 except Exception as e:
                     extra["nand_512"] = {"error": repr(e)}
+                try:
+                    if count > 1600:        # launch_keyswitch: above 1600 ciphertexts the shared-table kernel (capi.hip, kKsAutoWg)
+                        kfacts, knote = kernel_facts("keyswitch_kernel")
+                        per_wg = -(-count // 256)
+                        extra["keyswitch_%d" % count] = {
+                            "launch_ms": ks_ms, "kernel": "keyswitch_kernel", "bound": "lds", "ciphertexts": count,
+                            "ciphertexts_per_workgroup": min(16, per_wg),
+                            "algorithmic_bytes": count * 15507456,
+                            # the PMC facts were recorded on launches of 4096 ciphertexts (16 per workgroup): only then do they describe this launch
+                            "lds_pipe_busy_under_profiler": kfacts.get("lds_pipe_busy") if kfacts and count == 4096 else None,
+                            "valu_pipe_busy_under_profiler": kfacts.get("valu_pipe_busy") if kfacts and count == 4096 else None,
+                            "lds_bank_conflict_frac": kfacts.get("lds_bank_conflict_frac") if kfacts and count == 4096 else None,
+                            "pmc_source": knote, "replayed_from": replayed_from(("sq", "lds"))}
+                except Exception as e:
+                    extra["keyswitch_%d" % count] = {"error": repr(e)}
                 # the other compiled parameter sets through the generic kernels (kernels_ps.hip.h),
                 # 4096 NAND on random keys, sampled words against the oracle compiled for the set
                 psets = {}

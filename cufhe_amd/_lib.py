@@ -50,7 +50,9 @@ class PsParams(ctypes.Structure):
 class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
-                                               "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames")]
+                                               "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames",
+                                               "worker_cpus", "moved_gates", "tl_gather_ns", "tl_submit_ns",
+                                               "tl_h2d_ns", "tl_gates_ns", "tl_d2h_ns")]
 
 
 # every symbol include/cufhe_amd.h declares, with its signature
@@ -60,6 +62,7 @@ SIGNATURES = {
     "cufhe_amd_set_gpu_num": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_get_gpu_num": (ctypes.c_int, []),
     "cufhe_amd_device_count": (ctypes.c_int, []),
+    "cufhe_amd_device_identity": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
     "cufhe_amd_initialize_ntt": (ctypes.c_int, []),
     "cufhe_amd_initialize": (ctypes.c_int, [c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
     "cufhe_amd_cleanup": (ctypes.c_int, []),
@@ -84,6 +87,8 @@ SIGNATURES = {
     "cufhe_amd_ctxt_device_ptr": (c_void, [c_void, ctypes.c_int]),
     "cufhe_amd_enqueue_gate": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, c_void, c_void]),
     "cufhe_amd_enqueue_trlwe_op": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
+    "cufhe_amd_enqueue_cmux": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, c_void, c_void, c_void, c_void]),
+    "cufhe_amd_trgsw_to_ntt_host": (ctypes.c_int, [ctypes.c_int, c_void, c_void, c_void]),
     "cufhe_amd_enqueue_copy": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),

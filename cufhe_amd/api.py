@@ -47,6 +47,13 @@ def DeviceCount():
     return lib.cufhe_amd_device_count()
 
 
+def device_identity(device=0):
+    """Which physical GPU a logical device is: {'pci': ..., 'uuid': ..., 'hip_device': ..., 'local_cpus': ...}."""
+    buf = ctypes.create_string_buffer(512)
+    check(lib.cufhe_amd_device_identity(int(device), buf, len(buf)))
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
+
 def Initialize(bk=None, ksk=None):
     """Initialize() / Initialize(ek): bk, ksk are the torus-domain keys as uint32 arrays."""
     if bk is None:

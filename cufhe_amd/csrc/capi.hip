@@ -3,8 +3,11 @@
 // src/bootstrap_gpu.cu:97-155, src/keyswitch_gpu.cu:6-24) and the launch sequences that
 // replace the per-gate launchers of src/bootstrap_gpu.cu:834-1292.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -55,6 +58,7 @@ struct Workspace { char* base = nullptr; size_t bytes = 0; };
 
 struct DeviceState {
     bool ntt_ready = false, keys_ready = false;
+    int cus = 0;                         // hipDeviceProp_t::multiProcessorCount (launch-shape rules: one grid round = a workgroup per CU)
     NttTables* tables = nullptr;
     Ntt512Tables* tables512 = nullptr;   // [3]: the two 512-point halves (low-latency kernel), stand-alone N = 512
     double* bk_ntt = nullptr;
@@ -74,6 +78,8 @@ struct DeviceState {
     std::deque<PinnedBlock> staging;
     std::map<hipStream_t, Workspace> workspaces;
     std::mutex staging_mu;
+    // device-side spans of the newest scheduler flush with ciphertext copies (HIP events, only while profiling): ns
+    uint64_t tl_h2d_ns = 0, tl_gates_ns = 0, tl_d2h_ns = 0;
 };
 
 int g_gpu_num = 1;
@@ -98,9 +104,12 @@ constexpr long kKsAutoSplit = 192, kKsAutoWg = 1600;
 long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16
-int ks_auto_per_wg(size_t count)
+int ks_auto_per_wg(size_t count, int cus)
 {
-    const size_t p = (count + 255) / 256;      // one grid round of 256 workgroups with the fewest ciphertexts each
+    // one grid round -- a workgroup per CU (256 on MI355X; hipDeviceProp_t::multiProcessorCount, cached in DeviceState) --
+    // with the fewest ciphertexts each
+    const size_t c = cus > 0 ? (size_t)cus : 256;
+    const size_t p = (count + c - 1) / c;
     return (int)(p < 1 ? 1 : p > 16 ? 16 : p);
 }
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
@@ -216,6 +225,23 @@ void build_tables_512(Ntt512Tables (&t)[3])
                     [&](int idx) { return balanced(powmod_u64(psi2_inv, bitrev((uint32_t)idx, 9))); });
 }
 
+// /sys/bus/pci/devices/<domain:bus:dev.fn>/local_cpulist of a physical HIP device ("" when it cannot be read)
+std::string device_local_cpulist(int phys)
+{
+    char pci[64];
+    if (hipDeviceGetPCIBusId(pci, (int)sizeof pci, phys) != hipSuccess) { (void)hipGetLastError(); return ""; }
+    std::string id(pci);
+    for (auto& ch : id) ch = (char)tolower((unsigned char)ch);
+    FILE* f = fopen(("/sys/bus/pci/devices/" + id + "/local_cpulist").c_str(), "r");
+    if (!f) return "";
+    char line[1024] = "";
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    std::string out(ok ? line : "");
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+    return out;
+}
+
 int check_device(int device)
 {
     if (device < 0 || device >= g_gpu_num) return fail(-1, "device index out of range (SetGPUNum first)");
@@ -233,17 +259,37 @@ int ensure_ntt(int device)
     DeviceState& s = g_dev[device];
     if (s.ntt_ready) return 0;
     HIP_TRY(hipSetDevice(phys_device(device)));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device)));
+        s.cus = prop.multiProcessorCount;
+    }
+    // every allocation of this function is released again when a later one fails: a retry starts from nothing
+    auto undo = [&]() {
+        if (s.fault_host) { (void)hipHostFree(s.fault_host); s.fault_host = nullptr; s.fault = nullptr; }
+        if (s.tables) { (void)hipFree(s.tables); s.tables = nullptr; }
+        if (s.tables512) { (void)hipFree(s.tables512); s.tables512 = nullptr; }
+    };
+#define CUFHE_AMD_TRY_UNDO(expr)                                                               \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            undo();                                                                            \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+        }                                                                                      \
+    } while (0)
+    CUFHE_AMD_TRY_UNDO(hipHostMalloc((void**)&s.fault_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *s.fault_host = 0;
+    CUFHE_AMD_TRY_UNDO(hipHostGetDevicePointer((void**)&s.fault, s.fault_host, 0));
     NttTables host;
     build_tables(host);
-    HIP_TRY(hipMalloc((void**)&s.tables, sizeof(NttTables)));
-    HIP_TRY(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
+    CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables, sizeof(NttTables)));
+    CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
     static Ntt512Tables host512[3];
     build_tables_512(host512);
-    HIP_TRY(hipMalloc((void**)&s.tables512, sizeof(host512)));
-    HIP_TRY(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
-    HIP_TRY(hipHostMalloc((void**)&s.fault_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *s.fault_host = 0;
-    HIP_TRY(hipHostGetDevicePointer((void**)&s.fault, s.fault_host, 0));
+    CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables512, sizeof(host512)));
+    CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
+#undef CUFHE_AMD_TRY_UNDO
     s.ntt_ready = true;
     return 0;
 }
@@ -470,7 +516,7 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
         // as few ciphertexts per workgroup as still fit one grid round of 256 workgroups (g_ks_per_wg: -1 by count, else 1..16)
-        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count);
+        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, s.cus);
         const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg);
         hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk, per_wg);
     }
@@ -612,22 +658,40 @@ int run_trlwe_ops(int device, void* stream, const GateRef* g, size_t n)
 {
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
-    if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    size_t n_se = 0, n_rot = 0, n_t0 = 0;
+    size_t n_se = 0, n_rot = 0, n_t0 = 0, n_cmux = 0;
     for (size_t i = 0; i < n; i++) {
         if (!g[i].out || !g[i].in0) return fail(-1, "null operand");
         switch (g[i].op) {
             case CUFHE_AMD_TL_BOOTSTRAP: n_rot++; break;
             case CUFHE_AMD_TL_REFRESH: n_se++; n_rot++; n_t0++; break;
             case CUFHE_AMD_TL_SEIKS: n_se++; break;
+            case CUFHE_AMD_TL_CMUX:
+                if (!g[i].in1 || !g[i].in2) return fail(-1, "CMUXNTT: null operand");
+                n_cmux++;
+                break;
             default: return fail(-1, "unknown TRLWE-level op");
         }
     }
+    if (n_cmux < n && !s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (n_cmux && !s.ntt_ready) return fail(-3, "Initialize() has not been called for this device");
     Scratch sc;
-    const size_t need = n_se * kLvl1Words * 4 + n_t0 * kLvl0Words * 4 + n_rot * 2 * kN * 4 + (3 * n + 8) * sizeof(LinDesc) + 16384;
+    const size_t need = n_se * kLvl1Words * 4 + n_t0 * kLvl0Words * 4 + n_rot * 2 * kN * 4 + (3 * n + 8) * sizeof(LinDesc) +
+                        n_cmux * sizeof(CmuxDesc) + 16384;
     if (int rc = open_scratch(s, st, need, &sc)) return rc;
+    if (n_cmux) {      // the CMUXNTT calls of this level: independent of the other operations of the level (the scheduler's contract)
+        std::vector<CmuxDesc> cm;
+        cm.reserve(n_cmux);
+        for (size_t i = 0; i < n; i++)
+            if (g[i].op == CUFHE_AMD_TL_CMUX) cm.push_back({g[i].in0, g[i].in1, g[i].out, (const double*)g[i].in2});
+        CmuxDesc* dcm;
+        if (int rc = upload_descs(s, sc, cm, &dcm)) return rc;
+        const unsigned blocks = (unsigned)((cm.size() + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+        hipLaunchKernelGGL(cmux_desc_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, st, dcm, (int)cm.size(), s.tables);
+        HIP_TRY(hipGetLastError());
+        if (n_cmux == n) return 0;
+    }
     uint32_t *t1 = nullptr, *t0 = nullptr, *dump = nullptr;
     if (n_se) if (int rc = sc.alloc((void**)&t1, n_se * kLvl1Words * 4)) return rc;
     if (n_t0) if (int rc = sc.alloc((void**)&t0, n_t0 * kLvl0Words * 4)) return rc;
@@ -635,6 +699,7 @@ int run_trlwe_ops(int device, void* stream, const GateRef* g, size_t n)
     std::vector<LinDesc> se, ks, rot, scat;
     size_t i_se = 0, i_t0 = 0, i_rot = 0;
     for (size_t i = 0; i < n; i++) {
+        if (g[i].op == CUFHE_AMD_TL_CMUX) continue;
         if (g[i].op == CUFHE_AMD_TL_BOOTSTRAP) {
             rot.push_back({g[i].in0, g[i].in0, nullptr, 1, 0, 0u, 0u});
         } else {
@@ -692,6 +757,25 @@ int cufhe_amd_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int cufhe_amd_device_identity(int device, char* buf, size_t len)
+{
+    if (int rc = check_device(device)) return rc;
+    if (!buf || len < 2) return fail(-1, "null / short buffer");
+    const int phys = phys_device(device);
+    char pci[64] = "?";
+    HIP_TRY(hipDeviceGetPCIBusId(pci, (int)sizeof pci, phys));
+    hipUUID uuid;
+    memset(&uuid, 0, sizeof uuid);
+    char hex[2 * sizeof(uuid.bytes) + 1] = "";
+    if (hipDeviceGetUuid(&uuid, phys) == hipSuccess)
+        for (size_t i = 0; i < sizeof(uuid.bytes); i++) snprintf(hex + 2 * i, 3, "%02x", (unsigned char)uuid.bytes[i]);
+    (void)hipGetLastError();
+    // CPUs close to the device (what the launch worker of this device is pinned to, "sched_affinity")
+    std::string cpus = device_local_cpulist(phys);
+    snprintf(buf, len, "pci=%s uuid=%s hip_device=%d local_cpus=%s", pci, hex[0] ? hex : "?", phys, cpus.empty() ? "?" : cpus.c_str());
+    return 0;
 }
 
 int cufhe_amd_set_gpu_num(int gpu_num)
@@ -839,7 +923,7 @@ int cufhe_amd_stream_destroy(int device, void* stream)
         if (g_scheduler && device < g_scheduler->gpu_num()) g_scheduler->dev(device).forget_stream(stream);
     }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
-    return 0;
+    return device_fault(device);      // the workspace release above may have waited for the stream
 }
 int cufhe_amd_stream_query(int device, void* stream)
 {
@@ -1000,6 +1084,42 @@ int cufhe_amd_trgsw_to_ntt_batch(int device, void* stream, size_t count, const u
     return 0;
 }
 
+int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_host, double* trgsw_ntt_host)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (!trgsw_host || !trgsw_ntt_host) return fail(-1, "null pointer");
+    DeviceState& s = g_dev[device];
+    hipStream_t st = (hipStream_t)stream;
+    // torus words in, NTT-domain doubles out: both staged in the stream's grow-only workspace and in recycled pinned
+    // blocks, nothing is allocated or freed per call (the reference's TRGSW2NTT is allocation-free as well,
+    // src/bootstrap_gpu.cu:75-94)
+    constexpr size_t in_bytes = kBkStepDoubles * sizeof(uint32_t), out_bytes = kBkStepDoubles * sizeof(double);
+    Scratch sc;
+    if (int rc = open_scratch(s, st, in_bytes + out_bytes + 4096, &sc)) return rc;
+    uint32_t* d_in;
+    double* d_out;
+    if (int rc = sc.alloc((void**)&d_in, in_bytes)) return rc;
+    if (int rc = sc.alloc((void**)&d_out, out_bytes)) return rc;
+    PinnedBlock* blk = nullptr;
+    if (int rc = acquire_staging(s, in_bytes + out_bytes, &blk)) return rc;
+    memcpy(blk->host, trgsw_host, in_bytes);
+    HIP_TRY(hipMemcpyAsync(d_in, blk->host, in_bytes, hipMemcpyHostToDevice, st));
+    const unsigned blocks = (unsigned)((kBkPolysPerStep + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, st, d_out, d_in, (size_t)kBkPolysPerStep,
+                       s.tables, n_inverse_balanced());
+    HIP_TRY(hipGetLastError());
+    char* pin_out = (char*)blk->host + in_bytes;
+    HIP_TRY(hipMemcpyAsync(pin_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(blk->done, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(trgsw_ntt_host, pin_out, out_bytes);
+    return device_fault(device);
+}
+
 int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* trgsw_ntt, const uint32_t* c1,
                          const uint32_t* c0, uint32_t* res)
 {
@@ -1137,6 +1257,7 @@ int cufhe_amd_set_option(const char* key, long value)
             for (int d = 0; d < g_scheduler->gpu_num(); d++) g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
         return 0;
     }
+    if (!strcmp(key, "sched_affinity")) { g_sched_affinity = value != 0; return 0; }
     if (!strcmp(key, "share_devices")) { g_share_devices = value; g_phys_count = cufhe_amd_device_count(); return 0; }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
@@ -1185,9 +1306,10 @@ int cufhe_amd_probe_clock(int device, double* hz)
     std::vector<double> h(kBlocks * kWaves);
     for (int rep = 0; rep < 2; rep++)        // the second launch runs on a chip that is already under load
         hipLaunchKernelGGL(clock_probe_kernel, dim3(kBlocks), dim3(64 * kWaves), 0, 0, d, d + kBlocks * kWaves, 3000);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(-2, std::string("clock probe: ") + hipGetErrorString(e));
     std::sort(h.begin(), h.end());
     *hz = h[h.size() / 2];
     return 0;
@@ -1218,7 +1340,7 @@ int cufhe_amd_profile_get(int device, cufhe_amd_profile* out, int reset)
     if (int rc = drain(ks, s.prof.keyswitch_ms, s.prof.keyswitch_launches, s.prof.keyswitches)) return rc;
     if (out) *out = s.prof;
     if (reset) s.prof = cufhe_amd_profile{};
-    return 0;
+    return device_fault(device);      // hipEventSynchronize above observed completions
 }
 
 }  // extern "C"

@@ -780,21 +780,9 @@ __global__ __launch_bounds__(256) void sample_extract_desc_kernel(const LinDesc*
 // res = c0 + trgsw [x] (c1 - c0), __CMUXNTT__ src/bootstrap_gpu.cu:197-285.  trgsw_ntt holds
 // (k+1)l rows of two polynomials in the layout bk_to_ntt_kernel writes.
 // ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kNttThreads) void cmux_kernel(
-    uint32_t* __restrict__ res, const double* __restrict__ trgsw_ntt,
-    const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c0, int count,
-    const NttTables* __restrict__ gt)
+__device__ __forceinline__ void cmux_wave(uint32_t* o, const double2* key, const uint32_t* p1, const uint32_t* p0,
+                                          const WaveCtx& ctx, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    load_tables_to_lds((double*)smem, gt);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * kNttWavesPerBlock + wave;
-    if (g >= count) return;
-    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
-    const uint32_t* p1 = c1 + (size_t)g * 2 * kN;
-    const uint32_t* p0 = c0 + (size_t)g * 2 * kN;
-    const double2* key = (const double2*)(trgsw_ntt + (size_t)g * kBkStepDoubles);
     double A0[kRegs], A1[kRegs];
 #pragma unroll
     for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
@@ -824,15 +812,54 @@ __global__ __launch_bounds__(kNttThreads) void cmux_kernel(
             }
         }
     }
-    uint32_t* o = res + (size_t)g * 2 * kN;
 #pragma unroll
     for (int r = 0; r < kRegs; r++) { A0[r] = fpf::reduce(A0[r]); A1[r] = fpf::reduce(A1[r]); }
-    ntt_inverse(A0, ctx);
+    // c0 is read in full before the first word of `res` is written: res may be c0 (or c1) itself
+    uint32_t base[2 * kRegs];
 #pragma unroll
-    for (int r = 0; r < kRegs; r++) o[lane + 64 * r] = p0[lane + 64 * r] + fpf::lift_u32(A0[r]);
+    for (int r = 0; r < kRegs; r++) { base[r] = p0[lane + 64 * r]; base[kRegs + r] = p0[kN + lane + 64 * r]; }
+    ntt_inverse(A0, ctx);
     ntt_inverse(A1, ctx);
 #pragma unroll
-    for (int r = 0; r < kRegs; r++) o[kN + lane + 64 * r] = p0[kN + lane + 64 * r] + fpf::lift_u32(A1[r]);
+    for (int r = 0; r < kRegs; r++) {
+        o[lane + 64 * r] = base[r] + fpf::lift_u32(A0[r]);
+        o[kN + lane + 64 * r] = base[kRegs + r] + fpf::lift_u32(A1[r]);
+    }
+}
+
+__global__ __launch_bounds__(kNttThreads) void cmux_kernel(
+    uint32_t* res, const double* __restrict__ trgsw_ntt, const uint32_t* c1, const uint32_t* c0, int count,
+    const NttTables* __restrict__ gt)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    load_tables_to_lds((double*)smem, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
+    if (g >= count) return;
+    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
+    cmux_wave(res + (size_t)g * 2 * kN, (const double2*)(trgsw_ntt + (size_t)g * kBkStepDoubles), c1 + (size_t)g * 2 * kN,
+              c0 + (size_t)g * 2 * kN, ctx, lane);
+}
+
+// the same on per-operation pointers: what the stream scheduler launches for the CMUXNTT calls of one dependence level
+struct CmuxDesc {
+    const uint32_t* c1;
+    const uint32_t* c0;
+    uint32_t* res;
+    const double* trgsw_ntt;
+};
+__global__ __launch_bounds__(kNttThreads) void cmux_desc_kernel(const CmuxDesc* __restrict__ descs, int count, const NttTables* __restrict__ gt)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    load_tables_to_lds((double*)smem, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
+    if (g >= count) return;
+    const WaveCtx ctx = make_wave_ctx(smem, kLdsTableBytes + wave * kTileBytes, 0, gt, lane);
+    const CmuxDesc d = descs[g];
+    cmux_wave(d.res, (const double2*)d.trgsw_ntt, d.c1, d.c0, ctx, lane);
 }
 
 // out = ca*in0 + cb*in1 + (0,..,off) over `words` words; grid-stride over ciphertexts

@@ -39,7 +39,7 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
                 HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
                 s.ks_lds_opt_in = true;
             }
-            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count);
+            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, s.cus);
             hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count,
                                ps.ksk_padded, per_wg);
         } else {

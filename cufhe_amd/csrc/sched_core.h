@@ -55,6 +55,9 @@ struct GateRef { int op; uint32_t* out; const uint32_t* in0; const uint32_t* in1
 // include/cufhe_gpu.cuh:124-134).  Gates are launched per kind of their OUTPUT, except the TRLWE-level
 // operations (bootstrap to TRLWE, Refresh, SampleExtractAndKeySwitch), which mix kinds and form kind 2.
 constexpr int kKinds = 3;
+// Buffer kinds a ciphertext handle can have: the three above plus 3 = a TRGSW in the NTT domain (struct
+// cuFHETRGSWNTTlvl1, include/cufhe_gpu.cuh:136-146), which is only ever an INPUT (of CMUXNTT, a kind-2 operation).
+constexpr int kLevels = 4;
 struct CopyRec { uint32_t* dev; size_t slot; int level; };      // staging word offset <-> a ciphertext's device buffer
 
 // The device layer of ONE device.  Every method returns 0 or a negative status (text through
@@ -64,6 +67,9 @@ class Backend {
    public:
     virtual ~Backend() {}
     virtual void bind_thread() = 0;                                   // make this device current in the calling thread
+    // the same for the device's launch worker, which may also be placed on the CPUs close to the device;
+    // returns the number of CPUs the thread was pinned to (0: left to the OS)
+    virtual int bind_worker_thread() { bind_thread(); return 0; }
     virtual int num_streams() = 0;
     virtual int words(int level) = 0;                                 // words of a level-`level` ciphertext
     virtual int alloc_device(size_t bytes, void** p) = 0;
@@ -137,6 +143,10 @@ struct Stats {
     uint64_t max_level_gates = 0;
     uint64_t cross_stream_waits = 0;
     uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
+    uint64_t moved_gates = 0;         // gates that left their dependence level for a later one with room (fill_levels)
+    std::atomic<uint64_t> worker_cpus{0};   // CPUs the launch worker is pinned to
+    // timeline of the newest flush that carried ciphertext copies, ns from its hand-over to the worker (launch thread)
+    std::atomic<uint64_t> tl_gather_ns{0}, tl_submit_ns{0};
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
     std::atomic<uint64_t> launch_ns{0};
@@ -147,8 +157,11 @@ struct Stats {
         gates = o.gates; groups = o.groups; levels = o.levels; launch_sequences = o.launch_sequences;
         uploads = o.uploads; uploads_shared = o.uploads_shared; downloads = o.downloads; forced_syncs = o.forced_syncs;
         max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits; renames = o.renames;
+        moved_gates = o.moved_gates;
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
+        worker_cpus.store(o.worker_cpus.load());
+        tl_gather_ns.store(o.tl_gather_ns.load()); tl_submit_ns.store(o.tl_submit_ns.load());
         return *this;
     }
 };
@@ -425,6 +438,7 @@ class DeviceSched {
     bool threaded_;
     int nstreams_ = 1;
     int rr_ = 0;
+    uint64_t worker_cpus_ = 0;
     std::string err_;
     Stats stats_;
 
@@ -440,7 +454,7 @@ class DeviceSched {
     std::deque<Group*> live_;                   // launched or queued groups, oldest first
     int sticky_error_ = 0;
 
-    std::vector<uint32_t*> free_slots_[kKinds];
+    std::vector<uint32_t*> free_slots_[kLevels];
     std::vector<void*> slabs_;
 
     std::mutex copy_mu_;                        // held while the launch thread copies out of tlwehost memory
@@ -586,7 +600,7 @@ inline int DeviceSched::slot_alloc(int level, uint32_t** out)
     std::vector<uint32_t*>& fl = free_slots_[level];
     if (fl.empty()) {
         const size_t slot_bytes = ((size_t)be_->words(level) * 4 + 255) & ~(size_t)255;
-        const size_t count = 512;
+        const size_t count = std::max<size_t>(16, std::min<size_t>(512, ((size_t)4 << 20) / slot_bytes));    // slabs of <= 4 MiB
         void* slab = nullptr;
         be_->bind_thread();
         if (int rc = be_->alloc_device(slot_bytes * count, &slab)) return fail(rc, be_->error_text());
@@ -889,7 +903,8 @@ inline int DeviceSched::flush(size_t max_levels)
 
 inline void DeviceSched::worker_loop()
 {
-    be_->bind_thread();
+    worker_cpus_ = (uint64_t)std::max(0, be_->bind_worker_thread());
+    stats_.worker_cpus.store(worker_cpus_);
     for (;;) {
         Group* g;
         {

@@ -15,13 +15,57 @@ long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: lau
 long g_sched_level_gates = 2048; // a dependence level this full is launched at once
 long g_sched_total_gates = 32768;
 long g_sched_rename = 0;          // 1: outputs take fresh device buffers instead of waiting for the old one's users (sched_core.h)
+long g_sched_affinity = 1;        // 1: a device's launch worker runs on the CPUs local to that GPU (NUMA node of its PCI function)
+
+// "0-15,128-143" -> CPU set; returns the number of CPUs parsed
+int parse_cpulist(const std::string& list, cpu_set_t* set)
+{
+    CPU_ZERO(set);
+    int n = 0;
+    size_t i = 0;
+    while (i < list.size()) {
+        char* end = nullptr;
+        const long a = strtol(list.c_str() + i, &end, 10);
+        if (end == list.c_str() + i) break;
+        long b = a;
+        i = (size_t)(end - list.c_str());
+        if (i < list.size() && list[i] == '-') {
+            b = strtol(list.c_str() + i + 1, &end, 10);
+            i = (size_t)(end - list.c_str());
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) { CPU_SET((int)c, set); n++; }
+        if (i < list.size() && list[i] == ',') i++;
+    }
+    return n;
+}
 
 class HipBackend : public sched::Backend {
    public:
     explicit HipBackend(int device) : device_(device) {}
     void bind_thread() override { (void)hipSetDevice(phys_device(device_)); }
+    // The launch worker of a device: one per GPU in a process that drives a whole node (SetGPUNum(8), the reference's
+    // multi-GPU shape, test/test_gate_gpu_multi.cc:36-93).  Eight workers gathering ciphertexts into pinned memory and
+    // submitting launches should each sit next to their GPU, not wherever the OS put them: pin to the GPU's local CPUs,
+    // restricted to what the process is allowed to use (a container's cpuset); leave the thread alone if that is empty.
+    int bind_worker_thread() override
+    {
+        bind_thread();
+        if (!g_sched_affinity) return 0;
+        cpu_set_t local, allowed, both;
+        if (parse_cpulist(device_local_cpulist(phys_device(device_)), &local) == 0) return 0;
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return 0;
+        CPU_AND(&both, &local, &allowed);
+        const int n = CPU_COUNT(&both);
+        if (n == 0 || n == CPU_COUNT(&allowed)) return 0;        // nothing to narrow
+        if (pthread_setaffinity_np(pthread_self(), sizeof both, &both) != 0) return 0;
+        return n;
+    }
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
-    int words(int level) override { return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : 2 * kN; }
+    int words(int level) override
+    {
+        return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : level == 2 ? 2 * kN : (int)(2 * kBkStepDoubles);     // 3: TRGSW, NTT domain (doubles)
+    }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
     int free_device(void* p) override { return chk(hipFree(p), "hipFree"); }
     int alloc_pinned(size_t bytes, void** p) override { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
@@ -43,7 +87,7 @@ class HipBackend : public sched::Backend {
         hipStream_t st;
         if (int rc = stream(s, &st)) return rc;
         DeviceState& ds = g_dev[device_];
-        for (int level = 0; level < sched::kKinds; level++) {     // one lincomb (COPY) launch per ciphertext kind
+        for (int level = 0; level < sched::kLevels; level++) {     // one lincomb (COPY) launch per ciphertext kind
             std::vector<LinDesc> d;
             for (size_t i = 0; i < n; i++)
                 if (recs[i].level == level) {
@@ -238,7 +282,7 @@ extern "C" {
 
 int cufhe_amd_ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out)
 {
-    if (level < 0 || level > 2) return fail(-1, "level must be 0, 1 or 2 (TRLWE)");
+    if (level < 0 || level >= sched::kLevels) return fail(-1, "level must be 0, 1, 2 (TRLWE) or 3 (TRGSW in the NTT domain)");
     if (!host_words || !out) return fail(-1, "null pointer");
     std::lock_guard<std::mutex> lk(g_sched_mu);
     sched::Scheduler* S = scheduler();
@@ -324,6 +368,29 @@ int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cu
     return 0;
 }
 
+/* CMUXNTT (src/cufhe_gates_gpu.cu:68-85, __CMUXNTT__ src/bootstrap_gpu.cu:197-285) recorded like a gate: res = c0 + cs [x] (c1 - c0).
+ * copying != 0 is the reference's form (cs, c1, c0 taken from their host members in stream order, res delivered to
+ * res.trlwehost); 0 uses device buffers only.  Needs Initialize() (the NTT tables), no evaluation key. */
+int cufhe_amd_enqueue_cmux(int device, void* stream, int copying, cufhe_amd_ctxt* res, cufhe_amd_ctxt* cs, cufhe_amd_ctxt* c1,
+                           cufhe_amd_ctxt* c0)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = check_device(device)) return rc;
+        HIP_TRY(hipSetDevice(phys_device(device)));
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (!res || !cs || !c1 || !c0) return fail(-1, "null operand");
+    sched::Scheduler* S = scheduler();
+    for (cufhe_amd_ctxt* c : {res, cs, c1, c0})
+        if (int rc = sched_check_ctxt(S, c)) return rc;
+    if (res->level != 2 || c1->level != 2 || c0->level != 2 || cs->level != 3) return fail(-1, "CMUXNTT takes TRLWEs and a TRGSW in the NTT domain");
+    cufhe_amd_ctxt* ins[3] = {c1, c0, cs};
+    if (int rc = S->dev(device).record_gate(stream, CUFHE_AMD_TL_CMUX, copying != 0, res, ins, 2)) return sched_error(S->dev(device), rc);
+    return 0;
+}
+
 /* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207) in issue order.
  * to_device != 0: tlwehost -> device buffer; else device buffer -> tlwehost, visible after
  * Synchronize / StreamQuery like a gate result. */
@@ -370,7 +437,19 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->forced_syncs = s.forced_syncs; out->max_level_gates = s.max_level_gates; out->cross_stream_waits = s.cross_stream_waits;
     out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
     out->renames = s.renames;
-    if (reset) s = sched::Stats();
+    out->worker_cpus = s.worker_cpus.load();
+    out->moved_gates = s.moved_gates;
+    out->tl_gather_ns = s.tl_gather_ns.load(); out->tl_submit_ns = s.tl_submit_ns.load();
+    {
+        DeviceState& ds = g_dev[device];
+        std::lock_guard<std::mutex> lk2(ds.staging_mu);
+        out->tl_h2d_ns = ds.tl_h2d_ns; out->tl_gates_ns = ds.tl_gates_ns; out->tl_d2h_ns = ds.tl_d2h_ns;
+    }
+    if (reset) {
+        const uint64_t cpus = s.worker_cpus.load();      // a property of the worker thread, not a counter
+        s = sched::Stats();
+        s.worker_cpus.store(cpus);
+    }
     return 0;
 }
 

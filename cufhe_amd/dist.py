@@ -54,6 +54,55 @@ def max_over_ranks(value, dist=None):
     return float(t.item())
 
 
+class SharedGpuError(RuntimeError):
+    """Fewer distinct physical GPUs than ranks (and sharing was not asked for)."""
+
+
+def gpu_key(identity):
+    """What makes two ranks 'the same GPU': the UUID when the runtime reports one, else the PCI function."""
+    if isinstance(identity, dict):
+        u = identity.get("uuid")
+        return u if u and u != "?" else identity.get("pci", "?")
+    return str(identity)
+
+
+def check_distinct_gpus(identities, allow_shared=False):
+    """identities: one entry per rank (dicts from cufhe_amd.api.device_identity, or strings).  Returns
+    (distinct_gpus, shared).  A run whose ranks share a GPU measures nothing about N GPUs: it is refused
+    (SharedGpuError) unless allow_shared, and then the caller must label its line `shared_gpu` and report
+    n_gpus = distinct_gpus."""
+    keys = [gpu_key(i) for i in identities]
+    distinct = len(set(keys))
+    shared = distinct < len(keys)
+    if shared and not allow_shared:
+        dup = sorted({k for k in keys if keys.count(k) > 1})
+        raise SharedGpuError("%d ranks on %d distinct GPU(s) (shared: %s): this would print a multi-GPU line measured on fewer "
+                             "GPUs; pass --allow-shared-gpu to rehearse on this box" % (len(keys), distinct, ", ".join(dup)))
+    return distinct, shared
+
+
+def gather_objects(obj, dist=None):
+    """all_gather_object over the default process group (gloo): [obj of rank 0, obj of rank 1, ...]"""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def rank_summary(reports, allow_shared=False):
+    """reports: per-rank dicts {rank, gpu: identity, value, ms_per_step, ...} as gathered on rank 0.  Returns the
+    fields every multi-rank bench line carries: per_rank, distinct_gpus, value_min_rank / value_max_rank and, when
+    ranks share a GPU (allowed explicitly), shared_gpu.  Raises SharedGpuError otherwise."""
+    distinct, shared = check_distinct_gpus([r["gpu"] for r in reports], allow_shared)
+    vals = [r["value"] for r in reports if r.get("value") is not None]
+    out = {"per_rank": reports, "distinct_gpus": distinct,
+           "value_min_rank": min(vals) if vals else None, "value_max_rank": max(vals) if vals else None}
+    if shared:
+        out["shared_gpu"] = True
+    return out
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -70,7 +119,9 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
     (exit_code, stdout_of_rank_0).  The caller must not have touched the GPU: children are fresh
     processes, nothing is exec'd over a process that initialised HIP.  A rank that fails (or the
     timeout) ends the others -- they would wait for it in the barrier forever -- by their exact
-    PIDs, and the launcher reports a non-zero exit code.  Ranks other than 0 inherit stderr, their
+    process groups (each rank is started as the leader of its own session, so whatever a rank spawned goes with it and
+    cannot keep rank 0's stdout pipe open), and the launcher reports a non-zero exit code.  If starting a rank fails
+    (ENOMEM, EAGAIN) the ranks already running are ended before the error is re-raised.  Ranks other than 0 inherit stderr, their
     stdout is dropped (rank 0 prints the one JSON line)."""
     import subprocess
     import time
@@ -81,10 +132,35 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
     base["WORLD_SIZE"] = str(world)
     base["LOCAL_WORLD_SIZE"] = str(world)
     procs = []
-    for r in range(world):
-        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(list(child_cmd), env=e, stdin=subprocess.DEVNULL,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+
+    def end_all(which):
+        """terminate, then kill, the given ranks AND what they started: every rank leads its own process group"""
+        import signal
+        for r in which:
+            try:
+                os.killpg(procs[r].pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        deadline = time.monotonic() + 10
+        for r in which:
+            try:
+                procs[r].wait(max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pass
+            try:
+                os.killpg(procs[r].pid, signal.SIGKILL)       # whatever is left of the group (a grandchild holding the pipe)
+            except (ProcessLookupError, PermissionError):
+                pass
+            procs[r].wait()
+
+    try:
+        for r in range(world):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(list(child_cmd), env=e, stdin=subprocess.DEVNULL, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    except OSError:
+        end_all(range(len(procs)))      # the ranks already started would wait in the barrier forever
+        raise
     # rank 0's stdout is drained by a thread so that a long line can never block the child
     import threading
     chunks = []
@@ -103,18 +179,17 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
         if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
             if rc == 0:
                 rc = 124
-            for r in pending:
-                procs[r].terminate()
-            deadline = time.monotonic() + 10
-            for r in pending:
-                try:
-                    procs[r].wait(max(0.1, deadline - time.monotonic()))
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-                    procs[r].wait()
+            end_all(sorted(pending))
             pending = set()
         if pending:
             time.sleep(poll)
+    # every rank has exited; anything a rank left behind in its process group could still hold rank 0's pipe open
+    import signal
+    for pr in procs:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
     reader.join(10)
     out = chunks[0].decode(errors="replace") if chunks else ""
     return rc, out

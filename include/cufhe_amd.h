@@ -55,6 +55,12 @@ const char* cufhe_amd_last_error(void);
 int cufhe_amd_set_gpu_num(int gpu_num);                 /* SetGPUNum             :38 */
 int cufhe_amd_get_gpu_num(void);
 int cufhe_amd_device_count(void);                       /* physical GPUs visible     */
+/* Which physical GPU logical device `device` is: "pci=<domain:bus:dev.fn> uuid=<hex> hip_device=<index> local_cpus=<list>"
+ * (hipDeviceGetPCIBusId / hipDeviceGetUuid; local_cpus = /sys/bus/pci/devices/<pci>/local_cpulist, the CPUs the
+ * device's launch worker is pinned to).  The reference has no counterpart: it addresses GPUs by index
+ * (cudaSetDevice(i), include/cufhe_gpu.cuh:68-74); bench.py uses this to prove that N ranks / N logical devices
+ * are N distinct GPUs (test/test_gate_gpu_multi.cc:36-93 assumes it). */
+int cufhe_amd_device_identity(int device, char* buf, size_t len);
 int cufhe_amd_initialize_ntt(void);                     /* Initialize()          :40 */
 /* Initialize(const EvalKey&) :42-47 = InitializeNTThandlers + BootstrappingKeyToNTT
  * (src/bootstrap_gpu.cu:111-138) + KeySwitchingKeyToDevice (src/keyswitch_gpu.cu:6-16).
@@ -121,8 +127,16 @@ int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_
  * gGateBootstrappingTLWE2TRLWElvl01NTT / gRefresh / gSampleExtractAndKeySwitch (src/cufhe_gates_gpu.cu:86-146;
  * copying != 0: their upload-and-fetch forms) are recorded with their dependences and launched level by level:
  * 4096 Refresh calls on 800 streams (test/test_perf.cc:63-81) become a handful of launches. */
-enum cufhe_amd_trlwe_op { CUFHE_AMD_TL_BOOTSTRAP = 100, CUFHE_AMD_TL_REFRESH = 101, CUFHE_AMD_TL_SEIKS = 102 };
+enum cufhe_amd_trlwe_op { CUFHE_AMD_TL_BOOTSTRAP = 100, CUFHE_AMD_TL_REFRESH = 101, CUFHE_AMD_TL_SEIKS = 102, CUFHE_AMD_TL_CMUX = 103 };
 int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* in);
+/* CMUXNTT(res, cs, c1, c0, st) (src/cufhe_gates_gpu.cu:68-85; kernel __CMUXNTT__ src/bootstrap_gpu.cu:197-285): res = c0 + cs [x] (c1 - c0),
+ * recorded like a gate and ordered against its operands by the scheduler -- as in the reference it returns at once and the
+ * result is in res.trlwehost after Synchronize() / StreamQuery(st).  `cs` is a handle of level 3 (struct cuFHETRGSWNTTlvl1,
+ * include/cufhe_gpu.cuh:136-146: cufhe_amd_ctxt_create(3, trgswhost as words, ..): (k+1)l (k+1) N doubles in this library's NTT
+ * domain), res / c1 / c0 are TRLWE handles (level 2).  copying != 0: operands from their host members, result delivered to
+ * the host (the reference's only form); 0: device buffers only.  Needs Initialize() only, like the reference. */
+int cufhe_amd_enqueue_cmux(int device, void* stream, int copying, cufhe_amd_ctxt* res, cufhe_amd_ctxt* cs,
+                           cufhe_amd_ctxt* c1, cufhe_amd_ctxt* c0);
 /* CtxtCopyH2D / CtxtCopyD2H (include/cufhe_gpu.cuh:193-207), ordered with the recorded gates */
 int cufhe_amd_enqueue_copy(int device, void* stream, cufhe_amd_ctxt* c, int to_device);
 int cufhe_amd_flush(int device);                        /* launch what is recorded, do not wait */
@@ -141,6 +155,13 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t record_ns, retire_ns;  /* host time on the issuing thread: recording gates, delivering results */
     uint64_t launch_ns;             /* host time on the device's launch worker */
     uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
+    uint64_t worker_cpus;           /* CPUs the device's launch worker is pinned to (0: not pinned; "sched_affinity") */
+    uint64_t moved_gates;           /* gates that left their dependence level for a later one with room ("sched_fill") */
+    /* timeline of the most recent flush that carried ciphertext copies (ns, relative to its hand-over to the launch
+     * worker): inputs gathered out of tlwehost, everything submitted; and, from HIP events when profiling is enabled
+     * (cufhe_amd_profile_enable), the device-side spans of the H2D copy, the gates and the D2H copy */
+    uint64_t tl_gather_ns, tl_submit_ns;
+    uint64_t tl_h2d_ns, tl_gates_ns, tl_d2h_ns;
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 
@@ -167,7 +188,11 @@ int cufhe_amd_refresh_batch(int device, void* stream, size_t count, const uint32
  * trgsw_ntt[count][(k+1)l][k+1][N] doubles (this library's NTT domain; opaque to callers) */
 int cufhe_amd_trgsw_to_ntt_batch(int device, void* stream, size_t count, const uint32_t* trgsw,
                                  double* trgsw_ntt);
-/* CMUXNTT (src/bootstrap_gpu.cu:197-285): res = c0 + trgsw [x] (c1 - c0), TRLWEs [count][2N] */
+/* TRGSW2NTT on host memory, as the reference's wrapper runs it (H2D, kernel, D2H on `stream`, complete on return): staging
+ * comes from the stream's workspace and recycled pinned blocks -- no allocation per call.  trgsw_host: (k+1)l (k+1) N
+ * torus words; trgsw_ntt_host: as many doubles. */
+int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_host, double* trgsw_ntt_host);
+/* CMUXNTT (src/bootstrap_gpu.cu:197-285): res = c0 + trgsw [x] (c1 - c0), TRLWEs [count][2N]; res may be c0 or c1 */
 int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* trgsw_ntt,
                          const uint32_t* c1, const uint32_t* c0, uint32_t* res);
 /* NTT product check of test/test_polynomial_mult_1024.cu: res = a * b negacyclic mod 2^32,
@@ -218,7 +243,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * cufhe_amd_ctxt_device_ptr (Ctxt::tlwedevices in the C++ shim) is then only valid until the ciphertext is next
  * written; results, tlwehost and every API call behave the same.
  * "sched_level_gates" (default 2048) / "sched_total_gates" (default 32768): a dependence level this
- * full is launched at once / bound on the recorded program. */
+ * full is launched at once / bound on the recorded program.
+ * "sched_affinity" (default 1): the launch worker thread of a device runs on the CPUs local to that GPU
+ * (local_cpulist of its PCI function, intersected with the CPUs the process may use); 0 leaves it to the OS. */
 int cufhe_amd_set_option(const char* key, long value);
 
 /* ---- N = 2048 ring, 64-bit torus (BASELINE.json configs[4]; lvl2 / lvl02 / lvl20) ----

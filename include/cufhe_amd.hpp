@@ -68,9 +68,22 @@ template <class P> constexpr int level_of() { return P::n == TFHEpp::lvl0param::
 }  // namespace detail
 #define CUFHE_AMD_CHECK(expr) ::cufhe::detail::check((expr), #expr, __FILE__, __LINE__)
 
-inline int& stream_count() { static int c = 0; return c; }      // `streamCount`
+inline int& stream_count() { static int c = 0; return c; }
+namespace detail {
+inline int& gpu_num_mirror() { static int n = cufhe_amd_get_gpu_num(); return n; }
+}  // namespace detail
+/// `extern int _gpuNum; extern int streamCount;` of include/cufhe_gpu.cuh:44-46 (defined in src/cufhe_gates_gpu.cu:35-36):
+/// public globals of the reference that source code reads (loops over devices, stream bookkeeping).  Here they are
+/// references to the shim's state: `_gpuNum` mirrors the library's GPU count (set by SetGPUNum, as in the reference),
+/// `streamCount` is the counter the default Stream constructor round-robins with.
+inline int& _gpuNum = detail::gpu_num_mirror();
+inline int& streamCount = stream_count();
 
-inline void SetGPUNum(int gpuNum) { CUFHE_AMD_CHECK(cufhe_amd_set_gpu_num(gpuNum)); }
+inline void SetGPUNum(int gpuNum)
+{
+    CUFHE_AMD_CHECK(cufhe_amd_set_gpu_num(gpuNum));
+    _gpuNum = gpuNum;
+}
 inline int GetGPUNum() { return cufhe_amd_get_gpu_num(); }
 inline void Initialize() { CUFHE_AMD_CHECK(cufhe_amd_initialize_ntt()); }
 /// bk: [n][(k+1)l][k+1][N], ksk: [kN][t][2^(basebit-1)][n+1] torus words (TFHEpp's in-memory layouts)
@@ -126,19 +139,32 @@ inline void Bootstrap(uint32_t* out, const uint32_t* in, uint32_t mu, void* st, 
     CUFHE_AMD_CHECK(cufhe_amd_bootstrap_batch(gpuNum, st, 1, out, in));
 }
 
+}  // namespace cufhe
+/// The type `Stream::st()` returns (`cudaStream_t` in the reference, include/cufhe_gpu.cuh:183).  hipStream_t IS
+/// `struct ihipStream_t*`; declaring the tag here gives the very same type without pulling the HIP headers into host
+/// code, so a caller that does include <hip/hip_runtime_api.h> can hand `st.st()` straight to hipMemcpyAsync & co.
+struct ihipStream_t;
+typedef struct ihipStream_t* cufheStream_t;
+namespace cufhe {
+
 /// class Stream, include/cufhe_gpu.cuh:152-189 (passed by value, never auto-destroyed)
 class Stream {
    public:
-    inline Stream() : st_(nullptr), _device_id(stream_count() % GetGPUNum()) { stream_count()++; }
-    inline Stream(int device_id) : st_(nullptr), _device_id(device_id) { stream_count()++; }
+    inline Stream() : st_(nullptr), _device_id(streamCount % _gpuNum) { streamCount++; }
+    inline Stream(int device_id) : st_(nullptr), _device_id(device_id) { streamCount++; }
     inline ~Stream() {}
-    inline void Create() { CUFHE_AMD_CHECK(cufhe_amd_stream_create(_device_id, &st_)); }
+    inline void Create()
+    {
+        void* s = nullptr;
+        CUFHE_AMD_CHECK(cufhe_amd_stream_create(_device_id, &s));
+        st_ = static_cast<cufheStream_t>(s);
+    }
     inline void Destroy() { CUFHE_AMD_CHECK(cufhe_amd_stream_destroy(_device_id, st_)); st_ = nullptr; }
-    inline void* st() { return st_; }
+    inline cufheStream_t st() { return st_; }
     inline int device_id() { return _device_id; }
 
    private:
-    void* st_;
+    cufheStream_t st_;
     int _device_id;
 };
 
@@ -227,39 +253,28 @@ static_assert(sizeof(TFHEpp::TRLWE<TFHEpp::lvl1param>) == 2 * TFHEpp::lvl1param:
 
 /// struct cuFHETRGSWNTTlvl1, :136-146.  The NTT-domain words are this library's (exact
 /// residues mod a 50-bit prime carried in doubles); like the reference's FFP words they are
-/// only meaningful to CMUXNTT.
+/// only meaningful to CMUXNTT.  The device buffers belong to a scheduler handle (level 3), so that CMUXNTT is
+/// ordered against TRGSW2NTT and against other uses of the same TRGSW like any recorded gate.
 struct cuFHETRGSWNTTlvl1 {
-    std::array<double, (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::l * (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::n> trgswhost;
+    alignas(64) std::array<double, (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::l * (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::n> trgswhost;
     std::vector<double*> trgswdevices;
+    cufhe_amd_ctxt* handle = nullptr;
     cuFHETRGSWNTTlvl1()
     {
+        CUFHE_AMD_CHECK(cufhe_amd_ctxt_create(3, reinterpret_cast<uint32_t*>(trgswhost.data()), &handle));
         trgswdevices.resize(GetGPUNum());
-        for (int i = 0; i < GetGPUNum(); i++) CUFHE_AMD_CHECK(cufhe_amd_malloc(i, sizeof(trgswhost), (void**)&trgswdevices[i]));
+        for (int i = 0; i < GetGPUNum(); i++) trgswdevices[i] = reinterpret_cast<double*>(cufhe_amd_ctxt_device_ptr(handle, i));
     }
-    ~cuFHETRGSWNTTlvl1() { for (size_t i = 0; i < trgswdevices.size(); i++) cufhe_amd_free((int)i, trgswdevices[i]); }
+    ~cuFHETRGSWNTTlvl1() { cufhe_amd_ctxt_destroy(handle); }
     cuFHETRGSWNTTlvl1(const cuFHETRGSWNTTlvl1&) = delete;
     cuFHETRGSWNTTlvl1& operator=(const cuFHETRGSWNTTlvl1&) = delete;
 };
 
-namespace detail {
-inline void h2d(Stream st, void* d, const void* h, size_t bytes) { CUFHE_AMD_CHECK(cufhe_amd_memcpy_h2d(st.device_id(), st.st(), d, h, bytes)); }
-inline void d2h_wait(Stream st, void* h, const void* d, size_t bytes)
-{
-    CUFHE_AMD_CHECK(cufhe_amd_memcpy_d2h(st.device_id(), st.st(), h, d, bytes));
-    CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(st.device_id(), st.st()));
-}
-}  // namespace detail
-
-/// TRGSW2NTT, src/bootstrap_gpu.cu:75-94
+/// TRGSW2NTT, src/bootstrap_gpu.cu:75-94: torus-domain TRGSW -> trgswntt.trgswhost, complete on return (the reference
+/// waits for its D2H as well).  Staging is pooled inside the library: nothing is allocated per call.
 inline void TRGSW2NTT(cuFHETRGSWNTTlvl1& trgswntt, const TFHEpp::TRGSW<TFHEpp::lvl1param>& trgsw, Stream& st)
 {
-    const int dev = st.device_id();
-    void* d_trgsw = nullptr;
-    CUFHE_AMD_CHECK(cufhe_amd_malloc(dev, sizeof(trgsw), &d_trgsw));
-    detail::h2d(st, d_trgsw, trgsw.data(), sizeof(trgsw));
-    CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt_batch(dev, st.st(), 1, (const uint32_t*)d_trgsw, trgswntt.trgswdevices[dev]));
-    detail::d2h_wait(st, trgswntt.trgswhost.data(), trgswntt.trgswdevices[dev], sizeof(trgswntt.trgswhost));
-    CUFHE_AMD_CHECK(cufhe_amd_free(dev, d_trgsw));
+    CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt_host(st.device_id(), st.st(), reinterpret_cast<const uint32_t*>(trgsw.data()), trgswntt.trgswhost.data()));
 }
 /// gGateBootstrappingTLWE2TRLWElvl01NTT / GateBootstrappingTLWE2TRLWElvl01NTT, src/cufhe_gates_gpu.cu:86-104
 inline void gGateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
@@ -291,17 +306,17 @@ inline void SampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHET
     gSampleExtractAndKeySwitch(out, in, st);
     CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), out.handle, 0));
 }
-/// CMUXNTT, src/cufhe_gates_gpu.cu:68-85: res = cs ? c1 : c0
+/// CMUXNTT, src/cufhe_gates_gpu.cu:68-85: res = cs ? c1 : c0.  Like the reference it uploads cs, c1, c0 from their host
+/// members in stream order, returns at once, and res.trlwehost holds the result after Synchronize() / StreamQuery(st);
+/// operands that are results of earlier recorded operations are picked up by the scheduler's dependence tracking (no
+/// global synchronisation).  gCMUXNTT: the same on device buffers only.
 inline void CMUXNTT(cuFHETRLWElvl1& res, cuFHETRGSWNTTlvl1& cs, cuFHETRLWElvl1& c1, cuFHETRLWElvl1& c0, Stream st)
 {
-    Synchronize();      // operands may be results of recorded operations
-    const int dev = st.device_id();
-    detail::h2d(st, cs.trgswdevices[dev], cs.trgswhost.data(), sizeof(cs.trgswhost));
-    detail::h2d(st, c1.trlwedevices[dev], c1.trlwehost.data(), sizeof(c1.trlwehost));
-    detail::h2d(st, c0.trlwedevices[dev], c0.trlwehost.data(), sizeof(c0.trlwehost));
-    CUFHE_AMD_CHECK(cufhe_amd_cmux_batch(dev, st.st(), 1, cs.trgswdevices[dev], c1.trlwedevices[dev], c0.trlwedevices[dev], res.trlwedevices[dev]));
-    detail::d2h_wait(st, res.trlwehost.data(), res.trlwedevices[dev], sizeof(res.trlwehost));
-    CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(dev, st.st(), res.handle, 1));     // tell the scheduler the buffer changed
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_cmux(st.device_id(), st.st(), 1, res.handle, cs.handle, c1.handle, c0.handle));
+}
+inline void gCMUXNTT(cuFHETRLWElvl1& res, cuFHETRGSWNTTlvl1& cs, cuFHETRLWElvl1& c1, cuFHETRLWElvl1& c0, Stream st)
+{
+    CUFHE_AMD_CHECK(cufhe_amd_enqueue_cmux(st.device_id(), st.st(), 0, res.handle, cs.handle, c1.handle, c0.handle));
 }
 
 #undef CUFHE_AMD_GATE1

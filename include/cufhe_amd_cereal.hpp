@@ -259,5 +259,26 @@ inline EvalKeyFound LoadEvalKey(const std::string& path, const KeyShape& shape, 
     return r;
 }
 
+/// Write an EvalKey-shaped archive: endianness flag, `header` (stands for TFHEpp's lweParams block), then the optional
+/// members in the order {bkfft: empty, bk, bkntt: empty, ksk}: cereal's encoding of std::unique_ptr members (a validity
+/// byte, then the payload).  The counterpart of LoadEvalKey for round trips and for handing keys to other processes; like
+/// the reader it is UNVERIFIED against a TFHEpp-produced file.
+inline void SaveEvalKey(const std::string& path, const KeyShape& shape, const std::vector<uint32_t>& bk,
+                        const std::vector<uint32_t>& ksk, const std::vector<uint8_t>& header = {})
+{
+    if (bk.size() * 4 != shape.bk_bytes() || ksk.size() * 4 != shape.ksk_bytes()) throw std::runtime_error("SaveEvalKey: key sizes do not fit the shape");
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot create " + path);
+    PortableBinaryWriter ar(f);
+    ar.array(header.data(), header.size());
+    ar.unique_ptr_valid(false);                 // bkfftlvl01: not generated
+    ar.unique_ptr_valid(true);
+    ar.array(bk.data(), bk.size());             // bklvl01
+    ar.unique_ptr_valid(false);                 // bknttlvl01: not generated
+    ar.unique_ptr_valid(true);
+    ar.array(ksk.data(), ksk.size());           // iksklvl10
+    if (!f) throw std::runtime_error("write error on " + path);
+}
+
 }  // namespace cereal_io
 }  // namespace cufhe

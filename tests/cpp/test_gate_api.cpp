@@ -278,10 +278,15 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         TRGSW2NTT(cs, trgsw, st);
         Ctxt<lvl0param> other;
         encrypt(other, 1 - bit);
-        cuFHETRLWElvl1 t_other, res;
+        cuFHETRLWElvl1 t_other, res, res2;
         GateBootstrappingTLWE2TRLWElvl01NTT(t_other, other, st);
-        CMUXNTT(res, cs, t, t_other, st);          // synchronises first          // s0[i] ? t : t_other
+        // recorded like the reference's (src/cufhe_gates_gpu.cu:68-85: asynchronous on st): t_other is still on its way
+        // to its trlwehost when CMUXNTT is called -- the scheduler orders the CMUX behind the bootstrap, no Synchronize
+        CMUXNTT(res, cs, t, t_other, st);          // s0[i] ? t : t_other
+        CMUXNTT(res2, cs, t_other, res, st);       // chained on a recorded result, operands swapped: s0[i] ? t_other : res
+        Synchronize();
         bad += coeff0(res) != (g_s0[i] ? bit : 1 - bit); total++;
+        bad += coeff0(res2) != 1 - bit; total++;   // either branch holds 1 - bit
     }
     std::printf("TRLWE-level primitives: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, total);
     g_failures += bad;
@@ -356,6 +361,28 @@ void Lvl2Gates(std::mt19937& eng)
     CUFHE_AMD_CHECK(cufhe_amd_set_option("lvl0_ring", 1024));
 }
 
+// Source written against the reference's header touches its public globals and the stream type directly
+// (include/cufhe_gpu.cuh:44-46 `extern int _gpuNum; extern int streamCount;`, :154-165 the default Stream constructor,
+// :183 `cudaStream_t st()`): the same lines must compile and behave here.
+void ReferenceGlobals(int gpus)
+{
+    int bad = 0;
+    bad += cufhe::_gpuNum != gpus;                          // set by SetGPUNum, src/cufhe_gates_gpu.cu:38
+    const int before = cufhe::streamCount;
+    Stream a, b(0);
+    bad += cufhe::streamCount != before + 2;                // both constructors count, :154-165
+    bad += a.device_id() != before % cufhe::_gpuNum;        // round-robin over the devices
+    for (int i = 0; i < cufhe::_gpuNum; i++) bad += i >= GetGPUNum();        // the reference's `for (i < _gpuNum)` loops
+    a.Create();
+    cufheStream_t raw = a.st();                             // the type st() returns: hipStream_t without the HIP headers
+    bad += raw == nullptr;
+    bad += !StreamQuery(a);                                 // an idle stream
+    a.Destroy();
+    bad += a.st() != nullptr;
+    std::printf("reference globals (_gpuNum, streamCount, cufheStream_t): %s\n", bad ? "FAIL" : "PASS");
+    g_failures += bad;
+}
+
 int main(int argc, char** argv)
 {
     const int gpus = argc > 1 ? atoi(argv[1]) : 1;
@@ -374,6 +401,7 @@ int main(int argc, char** argv)
     if (getenv("CUFHE_AMD_SCHED_RENAME")) CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 1));
     SetGPUNum(gpus);
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
+    ReferenceGlobals(gpus);
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc
     AllGates<TFHEpp::lvl0param>(kNumSMs, kNumTests, eng);   // test_gate_gpu_multi.cc
     Chained(eng);

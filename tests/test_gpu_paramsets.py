@@ -117,7 +117,7 @@ def test_every_gate_words_and_truth_table(engine, pset, keys):
         engine.api.ps_gate_batch(idx, op, dout, dins[0], dins[1], dins[2], count=count)
         got = dout.download().reshape(count, -1)
         assert np.array_equal(got, K.gate_batch(op, 0, ins[0], ins[1], ins[2])), f"{name} {ol.OPS[op]}: words differ from the oracle"
-        assert list(K.decrypt(got, 0)) == [L.orc_truth(op, *map(int, c)) for c in combos], f"{name} {ol.OPS[op]}: decrypt != truth table"
+        assert list(K.decrypt(got, 0)) == [ol.truth(L, op, *map(int, c)) for c in combos], f"{name} {ol.OPS[op]}: decrypt != truth table"
     if name == "default":
         # the generic kernels and the hand-scheduled ones are two implementations of one function
         engine.Initialize(K.bk, K.ksk)
@@ -142,7 +142,7 @@ def test_mixed_batch(engine, pset):
     engine.api.ps_gate_batch(idx, ops, dins[0], dins[0], dins[1], dins[2], count=count)     # out aliases in0
     got = dins[0].download().reshape(count, -1)
     assert np.array_equal(got, K.gate_batch(ops, 0, ins[0], ins[1], ins[2]))
-    assert list(K.decrypt(got, 0)) == [L.orc_truth(int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
+    assert list(K.decrypt(got, 0)) == [ol.truth(L, int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
 
 
 def test_per_gate_api_over_a_parameter_set(engine, pset):

@@ -123,6 +123,66 @@ def test_self_launcher_with_stub_children():
     assert rc == 124 and time.monotonic() - t0 < 60
 
 
+SHARED_GPU_CHILD = r'''
+import json, os, sys, importlib.util
+spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
+d = importlib.util.module_from_spec(spec); spec.loader.exec_module(d)
+rank, local_rank, world = d.rank_env()
+import torch.distributed as dist
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mode, allow = sys.argv[1], sys.argv[2] == "allow"
+# what cufhe_amd.api.device_identity(0) reports: ranks wrapped onto one GPU report the same PCI function and UUID
+same = {"pci": "0000:05:00.0", "uuid": "aa" * 16, "hip_device": "0"}
+mine = same if mode == "shared" else {"pci": "0000:%02x:00.0" % (5 + rank), "uuid": "%02x" % rank * 16, "hip_device": str(rank)}
+ids = d.gather_objects(mine, dist)
+try:
+    distinct, shared = d.check_distinct_gpus(ids, allow)
+except d.SharedGpuError as e:
+    if rank == 0:
+        sys.stderr.write("refused: %s\\n" % e)
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(3)
+reports = d.gather_objects({"rank": rank, "gpu": mine, "value": 100.0 + rank, "ms_per_step": 40.0 - rank}, dist)
+if rank == 0:
+    line = {"n_gpus": distinct, "ranks": world}
+    line.update(d.rank_summary(reports, allow))
+    print(json.dumps(line))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_ranks_sharing_a_gpu_are_refused_unless_allowed():
+    """The multi-GPU bench line proves itself: every rank reports its physical GPU, rank 0 prints per_rank / distinct_gpus,
+    and ranks that share a GPU end the run non-zero unless --allow-shared-gpu (then shared_gpu: true, n_gpus = distinct)."""
+    import json
+    d = _dist()
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    code = f"ROOT={ROOT!r}\n" + SHARED_GPU_CHILD
+    rc, out = d.spawn_ranks([sys.executable, "-c", code, "shared", "refuse"], 2, env=env, timeout=300)
+    assert rc == 3 and not [l for l in out.splitlines() if l.startswith("{")]
+    rc, out = d.spawn_ranks([sys.executable, "-c", code, "shared", "allow"], 2, env=env, timeout=300)
+    assert rc == 0
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert line["shared_gpu"] is True and line["n_gpus"] == 1 and line["distinct_gpus"] == 1 and line["ranks"] == 2
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and line["value_min_rank"] == 100.0 and line["value_max_rank"] == 101.0
+    rc, out = d.spawn_ranks([sys.executable, "-c", code, "distinct", "refuse"], 2, env=env, timeout=300)
+    assert rc == 0
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert "shared_gpu" not in line and line["n_gpus"] == 2 and line["distinct_gpus"] == 2
+    # the pure function, and the identity fallback when the runtime reports no UUID
+    assert d.check_distinct_gpus([{"pci": "a", "uuid": "?"}, {"pci": "b", "uuid": "?"}]) == (2, False)
+    assert d.check_distinct_gpus(["x", "x", "y"], allow_shared=True) == (2, True)
+    import pytest as _pt
+    with _pt.raises(d.SharedGpuError):
+        d.check_distinct_gpus(["x", "x"])
+    # bench.py wires it in: gathered before any work, exit code 3, flag documented
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("check_distinct_gpus(identities") < src.index("eng.Initialize(bk, ksk)")
+    assert "--allow-shared-gpu" in src and "rank_summary(reports" in src
+
+
 def test_bench_refuses_world_mismatch_and_self_launches_before_torch():
     """The launcher branch of bench.py runs before torch / the HIP library are imported (a process
     that touched the GPU must not start ranks), and a WORLD_SIZE that contradicts --gpus is an error."""
@@ -201,13 +261,49 @@ def test_two_ranks_hip_library_words(tmp_path, keys):
 
 @pytest.mark.gpu
 def test_bench_self_launch_two_ranks_on_this_box():
-    """`python bench.py --gpus 2` run plainly prints one line with n_gpus 2 (ranks wrap onto the GPUs present)."""
+    """`python bench.py --gpus 2` run plainly on a box with ONE GPU: refused (both ranks wrap onto the same device: the line
+    would claim two GPUs); with --allow-shared-gpu it runs as a labelled rehearsal: shared_gpu, n_gpus = 1, both ranks listed
+    with the same physical GPU and their own rates."""
     import json
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gates", "512"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    import cufhe_amd as eng
+    one_gpu = eng.api.DeviceCount() == 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gates", "512"]
+    if one_gpu:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 3 and "distinct GPU" in p.stderr, (p.returncode, p.stderr[-2000:])
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run(cmd + ["--allow-shared-gpu"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
+    assert len(lines) == 1 and lines[0]["ranks"] == 2 and lines[0]["value"] > 0
+    line = lines[0]
+    assert len(line["per_rank"]) == 2 and all(r["value"] > 0 and r["gpu"]["pci"] != "?" for r in line["per_rank"])
+    assert line["distinct_gpus"] == line["n_gpus"] == len({r["gpu"]["uuid"] for r in line["per_rank"]})
+    if one_gpu:
+        assert line["shared_gpu"] is True and line["n_gpus"] == 1
+    assert line["value_min_rank"] <= line["value_max_rank"]
+
+
+@pytest.mark.gpu
+def test_bench_api_mode_one_process_many_devices():
+    """`bench.py --mode api --gpus G`: one process, SetGPUNum(G), Streams round-robin the devices (the reference's multi-GPU
+    shape, test/test_gate_gpu_multi.cc:36-93).  On fewer GPUs than G it is refused unless --allow-shared-gpu."""
+    import json
+    import cufhe_amd as eng
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "api", "--gpus", "2", "--steps", "2", "--warmup", "1", "--gates", "1024"]
+    if eng.api.DeviceCount() < 2:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    p = subprocess.run(cmd + ["--allow-shared-gpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["mode"] == "api" and line["config"]["logical_devices"] == 2 and line["value"] > 0
+    assert len(line["per_device"]) == 2 and sum(d["gates"] for d in line["per_device"]) == 2048
+    assert all(d["gates"] == 1024 for d in line["per_device"])          # streams round-robin the devices
+    assert line["n_gpus"] == line["distinct_gpus"] and (line["distinct_gpus"] == 2 or line["shared_gpu"] is True)

@@ -81,38 +81,27 @@ def test_polymul_ntt_equals_schoolbook(oracle):
         assert np.array_equal(r1, r2)
 
 
-REF_NAMES = {   # mangled names of namespace cufhe's truth functions in test/plain.h
-    "NAND": "_ZN5cufhe9NandCheckERhRKhS2_", "OR": "_ZN5cufhe7OrCheckERhRKhS2_",
-    "ORYN": "_ZN5cufhe9OrYNCheckERhRKhS2_", "ORNY": "_ZN5cufhe9OrNYCheckERhRKhS2_",
-    "AND": "_ZN5cufhe8AndCheckERhRKhS2_", "ANDYN": "_ZN5cufhe10AndYNCheckERhRKhS2_",
-    "ANDNY": "_ZN5cufhe10AndNYCheckERhRKhS2_", "XOR": "_ZN5cufhe8XorCheckERhRKhS2_",
-    "XNOR": "_ZN5cufhe9XnorCheckERhRKhS2_", "MUX": "_ZN5cufhe8MuxCheckERhRKhS2_S2_",
-    "NMUX": "_ZN5cufhe9NMuxCheckERhRKhS2_S2_", "NOT": "_ZN5cufhe8NotCheckERhRKh",
-    "COPY": "_ZN5cufhe9CopyCheckERhRKh",
-}
+REF_NAMES = ol.REF_NAMES
 
 
 def test_truth_tables_match_reference_plain_h(oracle):
-    """oracle/_ref/libplain_ref.so is /root/reference/test/plain.h compiled as is."""
+    """oracle/_ref/libplain_ref.so is /root/reference/test/plain.h compiled as is: the one pin the reference itself
+    holds for this path (test/test_util.h:75-94 checks decrypt == these functions).  A missing library is a FAILURE
+    wherever the reference tree is mounted (the build step must have produced it) and wherever a built copy should have
+    travelled with the repo; it may only be absent on a machine that has neither."""
     if not os.path.exists(ol.REF_LIB):
-        pytest.skip("oracle/_ref not built (reference tree not mounted)")
-    ref = ctypes.CDLL(ol.REF_LIB)
-    u8 = ctypes.c_uint8
-    for name, sym in REF_NAMES.items():
-        fn = getattr(ref, sym)
+        assert not os.path.exists("/root/reference/test/plain.h"), \
+            "oracle/_ref/libplain_ref.so is missing although /root/reference is mounted: run `make -C oracle all`"
+        pytest.skip("neither /root/reference nor a built oracle/_ref on this machine")
+    for name in REF_NAMES:
         op = ol.OPS.index(name)
         for a in (0, 1):
             for b in (0, 1):
                 for c in (0, 1):
-                    out, x, y, z = u8(7), u8(a), u8(b), u8(c)
-                    if name in ("NOT", "COPY"):
-                        fn(ctypes.byref(out), ctypes.byref(x))
-                    elif name in ("MUX", "NMUX"):
-                        fn(ctypes.byref(out), ctypes.byref(x), ctypes.byref(y), ctypes.byref(z))
-                    else:
-                        fn(ctypes.byref(out), ctypes.byref(x), ctypes.byref(y))
-                    assert out.value == ol.truth(oracle, op, a, b, c), (name, a, b, c)
+                    assert ol.ref_truth(name, a, b, c) == oracle.orc_truth(op, a, b, c), (name, a, b, c)
+                    assert ol.truth(oracle, op, a, b, c) == ol.ref_truth(name, a, b, c)      # what every GPU truth check uses
     # NOR is in the reference's gate set (src/bootstrap_gpu.cu:433-440) but not in plain.h
+    assert ol.ref_truth("NOR", 0, 0) is None
     assert [ol.truth(oracle, ol.OPS.index("NOR"), a, b) for a in (0, 1) for b in (0, 1)] == [1, 0, 0, 0]
 
 

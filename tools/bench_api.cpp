@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <random>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -19,19 +20,41 @@ int main(int argc, char** argv)
     // further arguments: gpus=G (SetGPUNum(G): streams and gates round-robin the devices like the reference's
     // test_gate_gpu_multi.cc; with share_devices=1 the G logical devices share the visible GPUs) and library options as
     // key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
-    int gpus = 1;
+    // reps=R timed repetitions (the first is a warm-up), netlist=0 skips the adder netlist, identify=1 refuses to run when
+    // the G logical devices are fewer than G distinct physical GPUs (unless share_devices=1 asked for exactly that)
+    int gpus = 1, reps = 4, netlist = 1, identify = 0;
+    long share = 0;
     for (int i = 2; i < argc; i++) {
         std::string kv(argv[i]);
         const size_t eq = kv.find('=');
         if (eq == std::string::npos) continue;
-        if (kv.substr(0, eq) == "gpus") { gpus = atoi(kv.c_str() + eq + 1); continue; }
-        CUFHE_AMD_CHECK(cufhe_amd_set_option(kv.substr(0, eq).c_str(), atol(kv.c_str() + eq + 1)));
+        const std::string key = kv.substr(0, eq);
+        if (key == "gpus") { gpus = atoi(kv.c_str() + eq + 1); continue; }
+        if (key == "reps") { reps = std::max(2, atoi(kv.c_str() + eq + 1)); continue; }
+        if (key == "netlist") { netlist = atoi(kv.c_str() + eq + 1); continue; }
+        if (key == "identify") { identify = atoi(kv.c_str() + eq + 1); continue; }
+        if (key == "share_devices") share = atol(kv.c_str() + eq + 1);
+        CUFHE_AMD_CHECK(cufhe_amd_set_option(key.c_str(), atol(kv.c_str() + eq + 1)));
     }
     std::mt19937 eng(1);
     std::vector<uint32_t> bk((size_t)630 * 6 * 2 * 1024), ksk((size_t)1024 * 8 * 2 * 631);
     for (auto& v : bk) v = eng();
     for (auto& v : ksk) v = eng();
     SetGPUNum(gpus);
+    // which physical GPUs are these?  (cufhe_amd_device_identity: PCI function and UUID from the HIP runtime)
+    std::vector<std::string> ident(gpus);
+    std::set<std::string> distinct;
+    for (int dev = 0; dev < gpus; dev++) {
+        char buf[512];
+        CUFHE_AMD_CHECK(cufhe_amd_device_identity(dev, buf, sizeof buf));
+        ident[dev] = buf;
+        const size_t u = ident[dev].find("uuid="), e = ident[dev].find(' ', u);
+        distinct.insert(ident[dev].substr(u, e - u) == "uuid=?" ? ident[dev].substr(0, ident[dev].find(' ')) : ident[dev].substr(u, e - u));
+    }
+    if (identify && (int)distinct.size() < gpus && !share) {
+        std::fprintf(stderr, "bench_api: %d logical devices on %zu distinct GPU(s); pass share_devices=1 to rehearse on this box\n", gpus, distinct.size());
+        return 3;
+    }
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     std::vector<Ctxt<P>> a(kNumTests), b(kNumTests), o(kNumTests);
     for (int i = 0; i < kNumTests; i++)
@@ -51,7 +74,8 @@ int main(int argc, char** argv)
             sum.max_level_gates = std::max(sum.max_level_gates, one.max_level_gates);
         }
     };
-    for (int rep = 0; rep < 4; rep++) {
+    std::vector<cufhe_amd_sched_stats> per_dev(gpus);
+    for (int rep = 0; rep < reps; rep++) {
         all_stats(ss, 1);
         auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < kNumTests; i++) Nand(o[i], a[i], b[i], st[i % kNumStreams]);
@@ -63,6 +87,7 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "rep %d: %d Nand via per-gate API: enqueue %.2f ms, total %.2f ms, %.0f gates/s, %.4f ms/gate\n", rep,
                      kNumTests, enq, tot, kNumTests / (tot * 1e-3), tot / kNumTests);
         if (rep && tot < best_tot) { best_tot = tot; best_enq = enq; }
+        for (int dev = 0; dev < gpus; dev++) CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(dev, &per_dev[dev], 0));
         all_stats(ss, 0);
     }
     // one JSON line (bench.py reads it): the PCIe-inclusive per-gate API rate and the host cost per gate --
@@ -70,15 +95,21 @@ int main(int argc, char** argv)
     const double issue_us = (ss.record_ns + ss.retire_ns) * 1e-3 / kNumTests, worker_us = ss.launch_ns * 1e-3 / kNumTests;
     std::printf("{\"gates\": %d, \"devices\": %d, \"streams\": %d, \"total_ms\": %.3f, \"enqueue_ms\": %.3f, \"gates_per_s\": %.1f, "
                 "\"host_issue_us_per_gate\": %.4f, \"host_worker_us_per_gate\": %.4f, \"host_issue_gates_per_s\": %.0f, "
-                "\"launch_sequences\": %llu}\n",
+                "\"launch_sequences\": %llu, \"distinct_gpus\": %zu, \"per_device\": [",
                 kNumTests, gpus, kNumStreams, best_tot, best_enq, kNumTests / (best_tot * 1e-3), issue_us, worker_us, 1e6 / issue_us,
-                (unsigned long long)ss.launch_sequences);
+                (unsigned long long)ss.launch_sequences, distinct.size());
+    for (int dev = 0; dev < gpus; dev++)
+        std::printf("%s{\"device\": %d, \"gpu\": \"%s\", \"gates\": %llu, \"launch_sequences\": %llu, \"worker_launch_ms\": %.3f, "
+                    "\"worker_pinned_cpus\": %llu}", dev ? ", " : "", dev, ident[dev].c_str(), (unsigned long long)per_dev[dev].gates,
+                    (unsigned long long)per_dev[dev].launch_sequences, per_dev[dev].launch_ns * 1e-6, (unsigned long long)per_dev[dev].worker_cpus);
+    std::printf("]}\n");
+    std::fflush(stdout);
     // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
     // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
     // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders; once as the reference's
     // buffers dictate (the temporaries t1, t2 re-used bit after bit order the program) and once with "sched_rename"
     // (outputs take fresh device buffers: only the carry chain is left).
-    for (int rename = 0; rename < 2; rename++) {
+    for (int rename = 0; rename < 2 && netlist; rename++) {
         CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", rename));
         const int kAdders = 256, kBits = 16;
         std::vector<Ctxt<P>> x(kAdders * kBits), y(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);

@@ -34,6 +34,9 @@ KERNELS = {
     "blind_rotate_ps_batch_kernel<default>": ("blind_rotate_ps_batch_kernel", ("K2N512", "Cggi16"), 8, 8, 2, STEPS),
     "blind_rotate_ps_batch_kernel<k2n512>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsK2N512", (), 8, 8, 2, STEPS),
     "blind_rotate_ps_batch_kernel<cggi16>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsCggi16", (), 8, 8, 2, 500),
+    # units per workgroup = ceil(count / 256) <= 16 (capi.hip: ks_auto_per_wg): 16 holds for launches of 4096 ciphertexts, which is
+    # every keyswitch_kernel launch of the profiled command -- the PMC passes run `bench.py --no-api` (the per-gate API
+    # subprocess flushes levels of 2048 gates: same grid, 8 per workgroup), and main() below checks the durations agree
     "keyswitch_kernel": ("keyswitch_kernel", ("lvl2", "ps_", "wg_", "split"), 16, 16, 4, None),
     "keyswitch_lvl2_shared_kernel": ("keyswitch_lvl2_shared_kernel", (), 16, 16, 4, None),
 }
@@ -80,7 +83,18 @@ def main():
             dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             vals.setdefault(r["Counter_Name"], {}).setdefault(k, []).append(
                 (int(r["Grid_Size"]), int(r["Workgroup_Size"]), float(r["Counter_Value"]), dur))
-    out = {"source_sha256": bench_module_hash(), "recorded": args.label or args.tag, "kernels": {}}
+    out = {"source_sha256": bench_module_hash(), "recorded": args.label or args.tag,
+           "sources": sorted({f"{args.tag}_{os.path.basename(os.path.dirname(f))}_counter_collection.csv" for f in files}), "kernels": {}}
+    # one launch shape per row: the largest-grid launches of a kernel must have one duration (a launch with fewer units per
+    # workgroup hides behind the same grid -- the key switch with 2048 ciphertexts -- and would be averaged in)
+    for k in KERNELS:
+        rows = vals.get("SQ_INSTS_VALU", {}).get(k)
+        if rows:
+            gmax = max(r[0] for r in rows)
+            durs = sorted(r[3] for r in rows if r[0] == gmax)
+            if durs[-1] > 1.25 * durs[0]:
+                print(f"WARNING {k}: launches of the largest grid differ in duration ({durs[0] * 1e-6:.2f} .. {durs[-1] * 1e-6:.2f} ms): "
+                      "more than one launch shape in this row?", file=sys.stderr)
     for k, (_m, _n, rot_per_wg, waves_per_wg, waves_per_simd, steps) in KERNELS.items():
         def avg(counter):
             rows = vals.get(counter, {}).get(k)

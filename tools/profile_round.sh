@@ -12,17 +12,23 @@ OUT=gpurun_out/${TAG}_prof
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.json
 echo "stats pass done"
+# one launch shape per kernel row: the headline workload alone (4096 NAND: every blind_rotate_kernel launch is 4096 rotations, every
+# keyswitch_kernel launch 4096 ciphertexts), and the N = 2048 ring alone -- the AVERAGE of the row is then the launch the bench line prices
+rocprofv3 --kernel-trace --stats -d $OUT/stats_nand -o st --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-extra --no-cpu-baseline > $OUT/nand_bench_under_rocprof.json
+echo "nand-only stats pass done"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_lvl2 -o st --output-format csv -- python3 bench.py --workload nand_lvl2 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $OUT/nand_lvl2_bench_under_rocprof.json
+echo "lvl2-only stats pass done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
-    --kernel-trace -d $OUT/pmc_sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+    --kernel-trace -d $OUT/pmc_sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "sq pass done"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES \
-    --kernel-trace -d $OUT/pmc_lds -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+    --kernel-trace -d $OUT/pmc_lds -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "lds pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "tcc pass done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU \
-    --kernel-trace -d $OUT/pmc_mix -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 > /dev/null
+    --kernel-trace -d $OUT/pmc_mix -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "instruction-mix pass done"
 find $OUT -name "*.csv" | head -40
