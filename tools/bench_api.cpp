@@ -40,6 +40,11 @@ int main(int argc, char** argv)
     std::vector<uint32_t> bk((size_t)630 * 6 * 2 * 1024), ksk((size_t)1024 * 8 * 2 * 631);
     for (auto& v : bk) v = eng();
     for (auto& v : ksk) v = eng();
+    if (identify && !share && cufhe_amd_device_count() < gpus) {
+        std::fprintf(stderr, "bench_api: %d logical devices asked for, %d distinct GPU(s) visible; pass share_devices=1 to rehearse on this box\n",
+                     gpus, cufhe_amd_device_count());
+        return 3;
+    }
     SetGPUNum(gpus);
     // which physical GPUs are these?  (cufhe_amd_device_identity: PCI function and UUID from the HIP runtime)
     std::vector<std::string> ident(gpus);
