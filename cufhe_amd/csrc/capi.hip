@@ -21,6 +21,7 @@
 #include "sched_core.h"
 #include "kernels.hip.h"
 #include "kernels_lvl2.hip.h"
+#include "kernels_lvl2q.hip.h"
 #include "kernels_ks2.hip.h"
 #define CUFHE_AMD_LL_DECLARATIONS_ONLY      // defined in kernels_ll.hip
 #include "kernels_ll.hip.h"
@@ -72,6 +73,9 @@ struct DeviceState {
     bool keys2_ready = false, br2_lds_opt_in = false, ks2_lds_opt_in = false;
     NttTables* tables2 = nullptr;      // [2]: the two half transforms
     double* bk2_ntt = nullptr;
+    Ntt512Tables* tables2q = nullptr;  // [4]: the four quarter transforms (kernels_lvl2q.hip.h)
+    double* bk2q_ntt = nullptr;        // the same key in the quarter layout
+    bool br2q_lds_opt_in = false;
     uint32_t* ksk2 = nullptr;
     std::vector<EventPair> br_events, ks_events;
     cufhe_amd_profile prof{};
@@ -115,6 +119,7 @@ int ks_auto_per_wg(size_t count, int cus)
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
+long g_lvl2_kernel = 1;         // N = 2048 blind rotation: 1 = four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h); 0 = eight half waves
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 constexpr int kMaxLogicalDevices = 64;    // SetGPUNum bound (per-device tables of fixed size: paramsets.inc.h)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
@@ -865,10 +870,11 @@ int cufhe_amd_cleanup(void)
         }
         if (s.keys_ready) { HIP_TRY(hipFree(s.bk_ntt)); HIP_TRY(hipFree(s.ksk)); }
         ps_release(i);
-        if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.ksk2)); }
+        if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.bk2q_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
-        s.keys2_ready = s.br2_lds_opt_in = s.ks2_lds_opt_in = false;
-        s.tables2 = nullptr; s.bk2_ntt = nullptr; s.ksk2 = nullptr;
+        if (s.tables2q) HIP_TRY(hipFree(s.tables2q));
+        s.keys2_ready = s.br2_lds_opt_in = s.br2q_lds_opt_in = s.ks2_lds_opt_in = false;
+        s.tables2 = nullptr; s.tables2q = nullptr; s.bk2_ntt = nullptr; s.bk2q_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables512)); }
         if (s.fault_host) { (void)hipHostFree(s.fault_host); s.fault_host = nullptr; s.fault = nullptr; }   // the fault, if any, ends with the keys
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
@@ -1279,6 +1285,11 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "ks_per_wg")) {
         if (value != -1 && (value < 1 || value > 16)) return fail(-1, "ks_per_wg must be -1 or 1..16");
         g_ks_per_wg = value;
+        return 0;
+    }
+    if (!strcmp(key, "lvl2_kernel")) {
+        if (value != 0 && value != 1) return fail(-1, "lvl2_kernel must be 0 (eight half waves) or 1 (four quarter waves)");
+        g_lvl2_kernel = value;
         return 0;
     }
     if (!strcmp(key, "lvl0_ring")) {

@@ -28,15 +28,38 @@ void build_tables_lvl2(NttTables (&t)[2])
     }
 }
 
+// Tables of the four quarter transforms (kernels_lvl2q.hip.h): root_q[m + g] = root[4m + q m + g]
+void build_tables_lvl2q(Ntt512Tables (&t)[4])
+{
+    std::vector<double> R(k2N), Rinv(k2N);
+    const uint64_t psi_inv = powmod_u64(kPsi4096, fpf::P_U64 - 2);
+    for (uint32_t i = 0; i < (uint32_t)k2N; i++) {
+        R[i] = balanced(powmod_u64(kPsi4096, bitrev(i, k2Nbit)));
+        Rinv[i] = balanced(powmod_u64(psi_inv, bitrev(i, k2Nbit)));
+    }
+    auto top = [](int idx) { int m = 1; while (2 * m <= idx) m *= 2; return m; };
+    for (int q = 0; q < 4; q++)
+        fill_tables_512(t[q], [&](int idx) { const int m = top(idx); return R[4 * m + q * m + (idx - m)]; },
+                        [&](int idx) { const int m = top(idx); return Rinv[4 * m + q * m + (idx - m)]; });
+}
+
 int ensure_tables_lvl2(int device)
 {
     DeviceState& s = g_dev[device];
-    if (s.tables2) return 0;
+    if (s.tables2 && s.tables2q) return 0;
     HIP_TRY(hipSetDevice(phys_device(device)));
-    static NttTables host[2];
-    build_tables_lvl2(host);
-    HIP_TRY(hipMalloc((void**)&s.tables2, sizeof(host)));
-    HIP_TRY(hipMemcpy(s.tables2, host, sizeof(host), hipMemcpyHostToDevice));
+    if (!s.tables2) {
+        static NttTables host[2];
+        build_tables_lvl2(host);
+        HIP_TRY(hipMalloc((void**)&s.tables2, sizeof(host)));
+        HIP_TRY(hipMemcpy(s.tables2, host, sizeof(host), hipMemcpyHostToDevice));
+    }
+    if (!s.tables2q) {
+        static Ntt512Tables hostq[4];
+        build_tables_lvl2q(hostq);
+        HIP_TRY(hipMalloc((void**)&s.tables2q, sizeof(hostq)));
+        HIP_TRY(hipMemcpy(s.tables2q, hostq, sizeof(hostq), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -49,12 +72,22 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    if (!s.br2_lds_opt_in) {
-        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3LdsBytes));
-        s.br2_lds_opt_in = true;
+    if (g_lvl2_kernel == 1) {
+        // four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h)
+        if (!s.br2q_lds_opt_in) {
+            HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kQLdsBytes));
+            s.br2q_lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(blind_rotate_lvl2q_kernel, dim3((unsigned)count), dim3(kQThreads), kQLdsBytes, st, d, (int)count,
+                           s.bk2q_ntt, s.tables2q, steps, acc_dump);
+    } else {
+        if (!s.br2_lds_opt_in) {
+            HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3LdsBytes));
+            s.br2_lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(blind_rotate_lvl2_kernel, dim3((unsigned)count), dim3(k2Threads), k3LdsBytes, st, d, (int)count,
+                           s.bk2_ntt, s.tables2, steps, acc_dump);
     }
-    hipLaunchKernelGGL(blind_rotate_lvl2_kernel, dim3((unsigned)count), dim3(k2Threads), k3LdsBytes, st, d, (int)count,
-                       s.bk2_ntt, s.tables2, steps, acc_dump);
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
         HIP_TRY(hipEventRecord(ev.b, st));
@@ -195,10 +228,12 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
         if (s.keys2_ready) {
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipFree(s.bk2_ntt));
+            HIP_TRY(hipFree(s.bk2q_ntt));
             HIP_TRY(hipFree(s.ksk2));
             s.keys2_ready = false;
         }
         HIP_TRY(hipMalloc((void**)&s.bk2_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&s.bk2q_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
         const size_t ksk_rows = want_ksk / kKsRowWords;
         HIP_TRY(hipMalloc((void**)&s.ksk2, ksk_rows * kKsRowPad * sizeof(uint32_t)));
         HIP_TRY(hipMemset(s.ksk2, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
@@ -212,6 +247,10 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
         const unsigned blocks = (unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
         hipLaunchKernelGGL(bk2_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttWavesPerBlock * kTileBytes, 0,
                            s.bk2_ntt, d_bk, polys, s.tables2, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
+        HIP_TRY(hipGetLastError());
+        // the same key in the layout of the quarter-transform kernel (both are kept: "lvl2_kernel" selects at run time)
+        hipLaunchKernelGGL(bk2q_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttWavesPerBlock * kTile512Bytes, 0,
+                           s.bk2q_ntt, d_bk, polys, s.tables2q, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(d_bk));

@@ -37,8 +37,17 @@ def test_params(engine2):
     assert p.mu == ol.MU2 and p.bk_words == ol.BK2_WORDS and p.ksk_words == ol.KSK2_WORDS
 
 
+@pytest.fixture(params=["quarter_waves", "half_waves"])
+def br2_kernel(request, engine2):
+    """both blind-rotate kernels of the ring: four quarter waves per rotation (kernels_lvl2q.hip.h, the default) and
+    eight half waves (kernels_lvl2.hip.h); identical words"""
+    engine2.api.set_option("lvl2_kernel", 1 if request.param == "quarter_waves" else 0)
+    yield request.param
+    engine2.api.set_option("lvl2_kernel", 1)
+
+
 @pytest.mark.parametrize("steps", [0, 1, 2, 3, 33, 630])
-def test_blind_rotate_accumulator_words(engine2, keys2, steps):
+def test_blind_rotate_accumulator_words(engine2, keys2, steps, br2_kernel):
     count = 4 if steps == 630 else 8
     rng = np.random.default_rng(200 + steps)
     tl = rng.integers(0, 2**32, size=(count, ol.n + 1), dtype=np.uint64).astype(np.uint32)
