@@ -404,7 +404,7 @@ def main():
         l2 = workload == "nand_lvl2"
         rotations = n * (2 if workload == "mux" else 1)
         bk_bytes = BK2_BYTES_PER_ROTATION if l2 else BK_BYTES_PER_ROTATION
-        kernel = "blind_rotate_lvl2_kernel" if l2 else "blind_rotate_kernel"
+        kernel = "blind_rotate_lvl2q_kernel" if l2 else "blind_rotate_kernel"
         achieved = bk_bytes * rotations / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
         facts, note = kernel_facts(kernel)
         r = {

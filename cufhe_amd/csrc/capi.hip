@@ -119,7 +119,11 @@ int ks_auto_per_wg(size_t count, int cus)
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
-long g_lvl2_kernel = 1;         // N = 2048 blind rotation: 1 = four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h); 0 = eight half waves
+// N = 2048 blind rotation: 1 = four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h); 0 = eight half waves, one
+// rotation per CU (kernels_lvl2.hip.h); -1 = by measured cost: a launch that leaves CUs with a single rotation (<= one per CU) is
+// faster on the eight-wave kernel (256 rotations: 14.5 ms against 17.4), everything above on the four-wave one (512: 27.3 against 28.0,
+// 4096: 192 against 223)
+long g_lvl2_kernel = -1;
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 constexpr int kMaxLogicalDevices = 64;    // SetGPUNum bound (per-device tables of fixed size: paramsets.inc.h)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
@@ -1288,7 +1292,7 @@ int cufhe_amd_set_option(const char* key, long value)
         return 0;
     }
     if (!strcmp(key, "lvl2_kernel")) {
-        if (value != 0 && value != 1) return fail(-1, "lvl2_kernel must be 0 (eight half waves) or 1 (four quarter waves)");
+        if (value < -1 || value > 1) return fail(-1, "lvl2_kernel must be -1 (by cost), 0 (eight half waves) or 1 (four quarter waves)");
         g_lvl2_kernel = value;
         return 0;
     }

@@ -295,7 +295,14 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
     };
 
     double sums[k2Prods][kRegs8];
-    double2 kb[3][4];
+#ifdef CUFHE_AMD_Q_PF3
+    constexpr int kKb = 4;              // key buffers: loads run kKb - 1 polynomials ahead of their use
+#else
+    constexpr int kKb = 3;
+#endif
+    constexpr int kRowUnroll = (kKb == 3) ? 1 : 2;      // (rows per loop body) * 6 polynomials must be a multiple of kKb
+    static_assert((kRowUnroll * k2Prods) % kKb == 0 && k2BkRows % kRowUnroll == 0, "key buffer rotation");
+    double2 kb[kKb][4];
     const double* key_q = bk_ntt + (size_t)wave * kQKeyQuarterDoubles;
     auto step_key = [&](int step) {
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_BK0)
@@ -305,8 +312,8 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
 #endif
     };
     if (steps > 0) {
-        load_key8(kb[0], step_key(0), lane);
-        load_key8(kb[1], step_key(0) + kQKeyPolyDoubles, lane);
+#pragma unroll
+        for (int b = 0; b < kKb - 1; b++) load_key8(kb[b], step_key(0) + (size_t)b * kQKeyPolyDoubles, lane);
     }
     publish_acc();
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
@@ -326,6 +333,15 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
         const int alo = (int)(abar & (k2N - 1));
         const bool ahi = (abar >> k2Nbit) != 0;
         const double* key = step_key(i);
+        // L2 warming: the 64 workgroups resident on an XCD (blocks b, b + 8, ...: round-robin dispatch -- for speed only) walk the
+        // key together, and whoever touches a line first waits for the fabric.  Each workgroup touches 1/64 of the key of step
+        // i + 2 (768 KiB / 64 = 96 lines of 128 bytes: 24 lanes of each wave, one 4-byte load), so that the XCD's L2 holds a step
+        // before anyone needs it.  Nothing waits for these loads: they are "used" after the row loop.
+        uint32_t warm = 0;
+#ifdef CUFHE_AMD_Q_WARM
+        if (lane < 24 && i + 2 < steps)
+            warm = *(const uint32_t*)((const char*)(bk_ntt + (size_t)(i + 2) * k2BkStepDoubles) + (size_t)((blockIdx.x >> 3) & 63) * 12288 + (wave * 24 + lane) * 128);
+#endif
         // (1) the rotated operand (X^abar acc_j) at this lane's positions
         uint64_t rot[2][2][4];
         {
@@ -382,76 +398,103 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
             for (int c = 0; c < kRegs8; c++) sums[p][c] = 0.0;
         const char* dig_in = smem + opaque(kQLdsR + 8 * lane);
 #pragma unroll 1
-        for (int row = 0; row < k2BkRows; row++) {
-            double x[kRegs8];
-            {
-                uint2 w[kRegs8];
+        for (int row0 = 0; row0 < k2BkRows; row0 += kRowUnroll) {
 #pragma unroll
-                for (int c = 0; c < kRegs8; c++) w[c] = *(const uint2*)(dig_in + 4096 * row + 512 * c);
+            for (int rr = 0; rr < kRowUnroll; rr++) {
+                const int row = row0 + rr;
+                double x[kRegs8];
+                {
+                    uint2 w[kRegs8];
 #pragma unroll
-                for (int c = 0; c < kRegs8; c++) {
-                    const double d0 = (double)(int)(int16_t)(w[c].x & 0xffffu), d1 = (double)((int)w[c].x >> 16);
-                    const double d2 = (double)(int)(int16_t)(w[c].y & 0xffffu), d3 = (double)((int)w[c].y >> 16);
-                    x[c] = __builtin_fma(c3, d3, __builtin_fma(c1, d1, __builtin_fma(cI, d2, d0)));      // exact: |x| < 2^46
+                    for (int c = 0; c < kRegs8; c++) w[c] = *(const uint2*)(dig_in + 4096 * row + 512 * c);
+#pragma unroll
+                    for (int c = 0; c < kRegs8; c++) {
+                        const double d0 = (double)(int)(int16_t)(w[c].x & 0xffffu), d1 = (double)((int)w[c].x >> 16);
+                        const double d2 = (double)(int)(int16_t)(w[c].y & 0xffffu), d3 = (double)((int)w[c].y >> 16);
+                        x[c] = __builtin_fma(c3, d3, __builtin_fma(c1, d1, __builtin_fma(cI, d2, d0)));      // exact: |x| < 2^46
+                    }
                 }
-            }
-            quarter_forward(x, ctx);
+                quarter_forward(x, ctx);
 #pragma unroll
-            for (int c = 0; c < kRegs8; c++) x[c] = fpf::reduce(x[c]);
-            CUFHE_AMD_PHASEQ(3)
-            const double* krow = key + (size_t)row * (k2Prods * kQKeyPolyDoubles);
+                for (int c = 0; c < kRegs8; c++) x[c] = fpf::reduce(x[c]);
+                CUFHE_AMD_PHASEQ(3)
+                const double* krow = key + (size_t)row * (k2Prods * kQKeyPolyDoubles);
 #pragma unroll
-            for (int p = 0; p < k2Prods; p++) {
-                // two polynomials ahead; past the last row of the step the stream continues with the next step's block
-                const double* nxt = (row * k2Prods + p + 2 < k2BkRows * k2Prods) ? krow + (size_t)(p + 2) * kQKeyPolyDoubles
-                                                                                    : step_key(i + 1 < steps ? i + 1 : i) + (size_t)(row * k2Prods + p + 2 - k2BkRows * k2Prods) * kQKeyPolyDoubles;
-                load_key8(kb[(p + 2) % 3], nxt, lane);
-                const double2(&b)[4] = kb[p % 3];
+                for (int p = 0; p < k2Prods; p++) {
+                    // kKb - 1 polynomials ahead; past the last row of the step the stream continues with the next step's block
+                    const int ahead = row * k2Prods + p + (kKb - 1);
+                    const double* nxt = (ahead < k2BkRows * k2Prods) ? krow + (size_t)(p + kKb - 1) * kQKeyPolyDoubles
+                                                                      : step_key(i + 1 < steps ? i + 1 : i) + (size_t)(ahead - k2BkRows * k2Prods) * kQKeyPolyDoubles;
+                    load_key8(kb[(rr * k2Prods + p + kKb - 1) % kKb], nxt, lane);
+                    const double2(&b)[4] = kb[(rr * k2Prods + p) % kKb];
 #pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) {
-                    sums[p][2 * c2] += fpf::mulmod(x[2 * c2], b[c2].x);
-                    sums[p][2 * c2 + 1] += fpf::mulmod(x[2 * c2 + 1], b[c2].y);
+                    for (int c2 = 0; c2 < 4; c2++) {
+                        sums[p][2 * c2] += fpf::mulmod(x[2 * c2], b[c2].x);
+                        sums[p][2 * c2 + 1] += fpf::mulmod(x[2 * c2 + 1], b[c2].y);
+                    }
                 }
+                CUFHE_AMD_PHASEQ(4)
             }
-            CUFHE_AMD_PHASEQ(4)
         }
+        asm volatile("" :: "v"(warm));                        // the warming load ends here, long after its issue
         __syncthreads();                                      // every wave has read its last digits: the buffer is dead
         CUFHE_AMD_PHASEQ(5)
         // (4) six rounds: inverse quarter transform of sum (out o, limb l), exchange, last two inverse stages at this lane's
         // positions, lift, shift, add.  Round k uses half k & 1 of the region; its slots [qq][e0] are the accumulator copy's
         // [j = k & 1][e0 + 512 qq], so the copy written after the last round only overwrites slots this lane itself read.
-#pragma unroll
-        for (int k = 0; k < k2Prods; k++) {
-            const int l = k >> 1, o = k & 1;
-            const int p = o * k2Limbs + l;
-            double y[kRegs8];
+        // The inverse transform of round k + 1 runs BEFORE the barrier of round k: the write of round k, the barrier and the reads
+        // of round k have an inverse transform of independent work in between instead of an exposed LDS round trip each.  Round
+        // k + 1 is written after the barrier of round k into the half round k - 1 used: every wave read that before it arrived.
+        auto inverse_of = [&](double (&y)[kRegs8], int k) {
+            const int p = (k & 1) * k2Limbs + (k >> 1);
 #pragma unroll
             for (int c = 0; c < kRegs8; c++) y[c] = fpf::reduce(sums[p][c]);
             quarter_inverse(y, ctx);
-            CUFHE_AMD_PHASEQ(6)
-            {
-                char* ex = smem + opaque(kQLdsR + 16384 * (k & 1) + 4096 * wave + 8 * lane);
+        };
+        auto exchange_write = [&](const double (&y)[kRegs8], int k) {
+            char* ex = smem + opaque(kQLdsR + 16384 * (k & 1) + 4096 * wave + 8 * lane);
 #pragma unroll
-                for (int c = 0; c < kRegs8; c++) *(double*)(ex + 512 * c) = y[c];
-            }
+            for (int c = 0; c < kRegs8; c++) *(double*)(ex + 512 * c) = y[c];
+        };
+        double y[kRegs8];
+        inverse_of(y, 0);
+        exchange_write(y, 0);
+        CUFHE_AMD_PHASEQ(6)
+#pragma unroll
+        for (int k = 0; k < k2Prods; k++) {
+            const int l = k >> 1, o = k & 1;
+            if (k + 1 < k2Prods) inverse_of(y, k + 1);
+            CUFHE_AMD_PHASEQ(6)
             __syncthreads();
             CUFHE_AMD_PHASEQ(7)
+            double v[2][4];
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) v[s][qq] = *(const double*)(own + 16384 * (k & 1) + 512 * s + 4096 * qq);
+            if (k + 1 < k2Prods) exchange_write(y, k + 1);
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                double v[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) v[qq] = *(const double*)(own + 16384 * (k & 1) + 512 * s + 4096 * qq);
                 // inverse of the split: (q0, q1) -> (h0, h0'), (q2, q3) -> (h1, h1'), then the halves; zeta^-1 = -zeta^3, zeta^-3 = -zeta, I^-1 = -I
-                const double s01 = v[0] + v[1], d01 = fpf::mulmod(v[0] - v[1], -kZeta3);
-                const double s23 = v[2] + v[3], d23 = fpf::mulmod(v[2] - v[3], -fpf::ROOT8);
-                const double r0 = fpf::reduce(s01 + s23);
-                const double r2 = fpf::reduce(fpf::mulmod(s01 - s23, -fpf::ROOT4));
-                const double r1 = fpf::reduce(d01 + d23);
-                const double r3 = fpf::reduce(fpf::mulmod(d01 - d23, -fpf::ROOT4));
-                acc[o][s][0] += to_u64(r0) << (k2LimbBits * l);
-                acc[o][s][1] += to_u64(r1) << (k2LimbBits * l);
-                acc[o][s][2] += to_u64(r2) << (k2LimbBits * l);
-                acc[o][s][3] += to_u64(r3) << (k2LimbBits * l);
+                const double s01 = v[s][0] + v[s][1], d01 = fpf::mulmod(v[s][0] - v[s][1], -kZeta3);
+                const double s23 = v[s][2] + v[s][3], d23 = fpf::mulmod(v[s][2] - v[s][3], -fpf::ROOT8);
+                double r[4];
+                r[0] = fpf::reduce(s01 + s23);
+                r[2] = fpf::reduce(fpf::mulmod(s01 - s23, -fpf::ROOT4));
+                r[1] = fpf::reduce(d01 + d23);
+                r[3] = fpf::reduce(fpf::mulmod(d01 - d23, -fpf::ROOT4));
+                // lift: the mantissa of r + 1.5 * 2^52 holds 2^51 + r, i.e. its bit pattern is 0x4338000000000000 + r as a 64-bit
+                // integer; the constant, shifted like the limbs, is taken off once per word and step instead of once per limb
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const double tt = r[t] + fpf::MAGIC0;
+                    uint64_t bits;
+                    __builtin_memcpy(&bits, &tt, 8);
+                    constexpr uint64_t kMagicBits = 0x4338000000000000ull;
+                    constexpr uint64_t kAll = kMagicBits + (kMagicBits << k2LimbBits) + (kMagicBits << (2 * k2LimbBits));
+                    acc[o][s][t] += bits << (k2LimbBits * l);
+                    if (l == 0) acc[o][s][t] -= kAll;
+                }
             }
             CUFHE_AMD_PHASEQ(8)
         }

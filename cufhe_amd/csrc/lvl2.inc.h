@@ -48,6 +48,11 @@ int ensure_tables_lvl2(int device)
     DeviceState& s = g_dev[device];
     if (s.tables2 && s.tables2q) return 0;
     HIP_TRY(hipSetDevice(phys_device(device)));
+    if (!s.cus) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, phys_device(device)));
+        s.cus = prop.multiProcessorCount;
+    }
     if (!s.tables2) {
         static NttTables host[2];
         build_tables_lvl2(host);
@@ -72,7 +77,8 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    if (g_lvl2_kernel == 1) {
+    const bool quarters = g_lvl2_kernel < 0 ? (long)count > (s.cus > 0 ? s.cus : 256) : g_lvl2_kernel == 1;
+    if (quarters) {
         // four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h)
         if (!s.br2q_lds_opt_in) {
             HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kQLdsBytes));

@@ -228,6 +228,8 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * bootstrap: lvl01/lvl10 (cufhe_amd_initialize) or lvl02/lvl20 (cufhe_amd_lvl2_initialize).  With 2048
  * every level-0 entry point (cufhe_amd_gate*, the recorded per-gate API, Nand<lvl0param>() ... in
  * the C++ shim) runs through the N = 2048 path.
+ * "lvl2_kernel" (default -1 = by measured cost): blind-rotate kernel of the N = 2048 ring: 1 = four quarter-transform waves per rotation with
+ * register sums, two rotations per CU (launches above one rotation per CU); 0 = eight half-transform waves, one rotation per CU.
  * "lvl0_param_set" (default -1): index of a cufhe_amd_ps_* parameter set with n = 630 through which every level-0
  * entry point bootstraps instead (cufhe_amd_ps_initialize first).
  * "share_devices" (default 0): 1 lets SetGPUNum(G) exceed the visible GPU count, logical devices wrapping around the

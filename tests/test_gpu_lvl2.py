@@ -43,7 +43,7 @@ def br2_kernel(request, engine2):
     eight half waves (kernels_lvl2.hip.h); identical words"""
     engine2.api.set_option("lvl2_kernel", 1 if request.param == "quarter_waves" else 0)
     yield request.param
-    engine2.api.set_option("lvl2_kernel", 1)
+    engine2.api.set_option("lvl2_kernel", -1)
 
 
 @pytest.mark.parametrize("steps", [0, 1, 2, 3, 33, 630])

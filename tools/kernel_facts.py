@@ -29,6 +29,7 @@ STEPS = 630
 KERNELS = {
     "blind_rotate_kernel": ("blind_rotate_kernel", (), 8, 8, 2, STEPS),
     "blind_rotate_lvl2_kernel": ("blind_rotate_lvl2_kernel", (), 1, 8, 2, STEPS),
+    "blind_rotate_lvl2q_kernel": ("blind_rotate_lvl2q_kernel", (), 1, 4, 2, STEPS),
     "blind_rotate_ll2_kernel": ("blind_rotate_ll2_kernel", (), 2, 16, 4, STEPS),
     "blind_rotate_ll_kernel": ("blind_rotate_ll_kernel", (), 1, 16, 4, STEPS),
     "blind_rotate_ps_batch_kernel<default>": ("blind_rotate_ps_batch_kernel", ("K2N512", "Cggi16"), 8, 8, 2, STEPS),
