@@ -51,8 +51,14 @@ class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
                                                "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames",
-                                               "worker_cpus", "moved_gates", "tl_gather_ns", "tl_submit_ns",
-                                               "tl_h2d_ns", "tl_gates_ns", "tl_d2h_ns")]
+                                               "worker_cpus", "moved_gates")]
+
+
+class GroupTrace(ctypes.Structure):
+    _fields_ = [("id", ctypes.c_uint64), ("levels", ctypes.c_uint32), ("gates", ctypes.c_uint32), ("stream", ctypes.c_uint32),
+                ("pad", ctypes.c_uint32), ("in_bytes", ctypes.c_uint64), ("out_bytes", ctypes.c_uint64)] + \
+               [(k, ctypes.c_int64) for k in ("t_queued", "t_launch_begin", "t_gather_end", "t_submit_end", "t_done_seen", "t_delivered")] + \
+               [(k, ctypes.c_float) for k in ("dev_h2d_ms", "dev_body_ms", "dev_d2h_ms", "pad2")]
 
 
 # every symbol include/cufhe_amd.h declares, with its signature
@@ -93,6 +99,7 @@ SIGNATURES = {
     "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),
     "cufhe_amd_sched_get_stats": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(SchedStats), ctypes.c_int]),
+    "cufhe_amd_sched_get_trace": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(GroupTrace), ctypes.c_int, ctypes.c_int]),
     "cufhe_amd_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_sample_extract_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),

@@ -82,8 +82,6 @@ struct DeviceState {
     std::deque<PinnedBlock> staging;
     std::map<hipStream_t, Workspace> workspaces;
     std::mutex staging_mu;
-    // device-side spans of the newest scheduler flush with ciphertext copies (HIP events, only while profiling): ns
-    uint64_t tl_h2d_ns = 0, tl_gates_ns = 0, tl_d2h_ns = 0;
 };
 
 int g_gpu_num = 1;

@@ -54,8 +54,13 @@ static_assert(kZeta3 == fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8 && fpf::ROOT4 == fp
 // exactness of the split on gadget digits: |q| <= (Bg/2) (1 + I + zeta + zeta^3) stays an exact double with room to spare
 constexpr double kQSplitDigitBound = (double)(1u << (k2Bgbit - 1)) * (1.0 + fpf::ROOT4 + fpf::ROOT8 + kZeta3);
 static_assert(kQSplitDigitBound < 9007199254740992.0 / 128.0, "split of the digits is not exact");
+// ... and of the packed form the kernel evaluates it in: A + cI B + (c1 - 65536) d1 + (c3 - 65536 cI) d3 with |A|, |B| < 2^25, |d| <= 2^8
+static_assert(33554432.0 * (1.0 + fpf::ROOT4) + 256.0 * (kZeta3 + 65536.0) + 256.0 * (kZeta3 + 65536.0 * fpf::ROOT4) < 9007199254740992.0 / 4.0,
+              "packed split: a partial sum leaves the exact range");
+static_assert(k2Bgbit <= 15, "a digit plus Bg/2 must fit the low 16-bit field");
 
-// lazy-reduction schedule of the forward quarter transform below (units of p): nine stages, the last two wide
+// lazy-reduction schedule of the forward quarter transform below (units of p): nine stages, the last two wide, the addend of
+// the last one reduced: the spectrum comes out below the narrow multiplication's limit without a reduction pass of its own
 constexpr double quarter_forward_bound(double in)
 {
     double b = in;
@@ -63,18 +68,17 @@ constexpr double quarter_forward_bound(double in)
         if (b >= fpf::LIM_NARROW) return -1.0;
         b = b + fpf::after_mulmod(b);
     }
-    for (int s = 7; s <= 8; s++) {
-        if (b >= fpf::LIM_WIDE) return -1.0;
-        b = b + fpf::after_mulmod_wide(b);
-    }
-    return b;
+    if (b >= fpf::LIM_WIDE) return -1.0;
+    b = b + fpf::after_mulmod_wide(b);                // stage 7
+    if (b >= fpf::LIM_WIDE) return -1.0;
+    return 0.5001 + fpf::after_mulmod_wide(b);         // stage 8: reduce(a) +- mulmod_wide(b, w)
 }
-static_assert(quarter_forward_bound(kQSplitDigitBound / fpf::P) > 0 && quarter_forward_bound(kQSplitDigitBound / fpf::P) < fpf::LIM_WIDE,
-              "forward quarter transform of digits");
+static_assert(quarter_forward_bound(kQSplitDigitBound / fpf::P) > 0 && quarter_forward_bound(kQSplitDigitBound / fpf::P) < fpf::LIM_NARROW,
+              "forward quarter transform of digits: the spectrum must be a legal operand of mulmod");
+// products of that spectrum with key residues (<= p/2), eight rows into one register sum
+static_assert(k2BkRows * fpf::after_mulmod(quarter_forward_bound(kQSplitDigitBound / fpf::P)) < fpf::LIM_WIDE, "register sums of eight rows");
 // key limbs: |limb| <= 2^21, first split stage exact (2^21 (1 + I) = 2^46), second by a modular product: |in| <= 2^46 / p + 0.55
 static_assert(quarter_forward_bound(0.09 + 0.56) > 0 && quarter_forward_bound(0.09 + 0.56) < fpf::LIM_WIDE, "forward quarter transform of key limbs");
-// products: reduced spectrum (<= p/2) times key (<= p/2): <= 0.55 p each, eight rows stay below the wide limit
-static_assert(k2BkRows * fpf::after_mulmod(0.5001) < fpf::LIM_WIDE, "register sums of eight rows");
 
 // ---- LDS map of blind_rotate_lvl2q_kernel ----
 constexpr int kQLdsR = 0;                                             // 32 KiB: accumulator copy | digit buffer | exchange buffer
@@ -99,8 +103,13 @@ __device__ __forceinline__ void ct_three_stages_w2(double (&x)[kRegs8], const do
 #pragma unroll
         for (int r = 0; r < 2; r++) ct_bfly<true>(x[4 * g + r], x[4 * g + r + 2], w);
     }
+    // last stage: only the addend is reduced (2 operations per butterfly instead of a reduction of both outputs afterwards):
+    // |out| <= 0.5 + (1 + 0.0973 |b|) p
 #pragma unroll
-    for (int g = 0; g < 4; g++) ct_bfly<true>(x[2 * g], x[2 * g + 1], tw[3 + g]);
+    for (int g = 0; g < 4; g++) {
+        x[2 * g] = fpf::reduce(x[2 * g]);
+        ct_bfly<true>(x[2 * g], x[2 * g + 1], tw[3 + g]);
+    }
 }
 
 // per-lane addresses of a quarter wave
@@ -268,6 +277,7 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
     const double sg = (wave & 1) ? -1.0 : 1.0;
     const double c1 = sg * ((wave & 2) ? kZeta3 : fpf::ROOT8);
     const double c3 = sg * ((wave & 2) ? fpf::ROOT8 : kZeta3);
+    const double k1 = c1 - 65536.0, k3 = c3 - 65536.0 * cI, kOff = (double)(1u << (k2Bgbit - 1)) * (1.0 + cI);
 
     // accumulator words of this lane: component j, s (e0 = 128 wave + lane + 64 s), t (position e0 + 512 t)
     const int e_base = 128 * wave + lane;
@@ -365,12 +375,15 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
             for (int j = 0; j < 2; j++)
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
+                    // positions t = 1, 3 (the high 16-bit fields) carry the signed digit (sign mask applied: two's complement),
+                    // positions t = 0, 2 (the low fields) the digit + Bg/2 as the decomposition produces it (no sign mask)
                     uint64_t tmp[4];
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int e = e_base + 64 * s + kQPoints * t;
                         const bool neg = (e < alo) != ahi;
-                        tmp[t] = ((neg ? 0ull - rot[j][s][t] : rot[j][s][t]) - acc[j][s][t] + decomp_offset2()) ^ decomp_signmask2();
+                        tmp[t] = (neg ? 0ull - rot[j][s][t] : rot[j][s][t]) - acc[j][s][t] + decomp_offset2();
+                        if (t & 1) tmp[t] ^= decomp_signmask2();
                     }
 #pragma unroll
                     for (int dd = 0; dd < k2L; dd++) {
@@ -379,12 +392,13 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
                         uint32_t dg[4];
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
-                            if (pos >= 32) dg[t] = (uint32_t)__builtin_amdgcn_sbfe((uint32_t)(tmp[t] >> 32), (uint32_t)(pos - 32), (uint32_t)k2Bgbit);
-                            else dg[t] = (uint32_t)__builtin_amdgcn_sbfe(__builtin_amdgcn_alignbit((uint32_t)(tmp[t] >> 32), (uint32_t)tmp[t], (uint32_t)pos), 0u, (uint32_t)k2Bgbit);
+                            const uint32_t f = pos >= 32 ? (uint32_t)(tmp[t] >> 32) >> (pos - 32)
+                                                         : __builtin_amdgcn_alignbit((uint32_t)(tmp[t] >> 32), (uint32_t)tmp[t], (uint32_t)pos);
+                            dg[t] = (t & 1) ? (uint32_t)__builtin_amdgcn_sbfe(f, 0u, (uint32_t)k2Bgbit) : (f & ((1u << k2Bgbit) - 1));
                         }
                         uint2 w;
-                        w.x = __builtin_amdgcn_perm(dg[1], dg[0], 0x05040100u);      // (d0 & 0xffff) | (d1 << 16)
-                        w.y = __builtin_amdgcn_perm(dg[3], dg[2], 0x05040100u);
+                        w.x = dg[0] | (dg[1] << 16);      // d0 + 256 in [0, 512) | d1 << 16: as a signed word 65536 d1 + d0 + 256
+                        w.y = dg[2] | (dg[3] << 16);
                         *(uint2*)(dig_out + 4096 * (j * k2L + dd) + 512 * s) = w;
                     }
                 }
@@ -409,14 +423,14 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
                     for (int c = 0; c < kRegs8; c++) w[c] = *(const uint2*)(dig_in + 4096 * row + 512 * c);
 #pragma unroll
                     for (int c = 0; c < kRegs8; c++) {
-                        const double d0 = (double)(int)(int16_t)(w[c].x & 0xffffu), d1 = (double)((int)w[c].x >> 16);
-                        const double d2 = (double)(int)(int16_t)(w[c].y & 0xffffu), d3 = (double)((int)w[c].y >> 16);
-                        x[c] = __builtin_fma(c3, d3, __builtin_fma(c1, d1, __builtin_fma(cI, d2, d0)));      // exact: |x| < 2^46
+                        // A = 65536 d1 + d0 + 256, B = 65536 d3 + d2 + 256 (one conversion each), d1, d3 from the high fields:
+                        // d0 + cI d2 + c1 d1 + c3 d3 = A + cI B + (c1 - 65536) d1 + (c3 - 65536 cI) d3 - 256 (1 + cI): ten operations, all exact
+                        const double A = (double)(int)w[c].x, d1 = (double)((int)w[c].x >> 16);
+                        const double B = (double)(int)w[c].y, d3 = (double)((int)w[c].y >> 16);
+                        x[c] = __builtin_fma(k3, d3, __builtin_fma(k1, d1, __builtin_fma(cI, B, A))) - kOff;      // exact: every partial sum < 2^51
                     }
                 }
-                quarter_forward(x, ctx);
-#pragma unroll
-                for (int c = 0; c < kRegs8; c++) x[c] = fpf::reduce(x[c]);
+                quarter_forward(x, ctx);                       // |x| <= 2.2 p: a legal operand of mulmod as it is
                 CUFHE_AMD_PHASEQ(3)
                 const double* krow = key + (size_t)row * (k2Prods * kQKeyPolyDoubles);
 #pragma unroll

@@ -89,7 +89,28 @@ class Backend {
     virtual int event_sync(void* ev) = 0;
     virtual int stream_wait(int s, void* ev) = 0;
     virtual std::string error_text() = 0;
+    // optional device-side timing marks (a timing event recorded on stream s, or nullptr when the backend is not
+    // profiling) and the milliseconds between two of them once both have completed; marks are freed with event_destroy
+    virtual void* mark(int /*s*/) { return nullptr; }
+    virtual float elapsed_ms(void* /*a*/, void* /*b*/) { return 0.0f; }
 };
+
+// What happened to one flushed group, for the timeline of a run (cufhe_amd_sched_get_trace): host times are
+// steady_clock nanoseconds (std::chrono::steady_clock::now().time_since_epoch()), device spans milliseconds from timing
+// events (0 unless the backend was profiling).
+struct GroupTrace {
+    uint64_t id = 0;
+    uint32_t levels = 0, gates = 0, stream = 0, pad = 0;
+    uint64_t in_bytes = 0, out_bytes = 0;
+    int64_t t_queued = 0;          // issuing thread: the group was handed to the launch worker
+    int64_t t_launch_begin = 0;    // worker: picked up
+    int64_t t_gather_end = 0;      // worker: inputs copied out of tlwehost into the pinned block
+    int64_t t_submit_end = 0;      // worker: everything submitted to the stream
+    int64_t t_done_seen = 0;       // issuing thread: completion observed (event synchronised / queried true)
+    int64_t t_delivered = 0;       // issuing thread: results copied into tlwehost, buffers recycled
+    float dev_h2d_ms = 0, dev_body_ms = 0, dev_d2h_ms = 0;     // H2D copy + scatter | gates | gather + D2H copy
+};
+inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace sched
 }  // namespace cufhe_amd
@@ -145,8 +166,6 @@ struct Stats {
     uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
     uint64_t moved_gates = 0;         // gates that left their dependence level for a later one with room (fill_levels)
     std::atomic<uint64_t> worker_cpus{0};   // CPUs the launch worker is pinned to
-    // timeline of the newest flush that carried ciphertext copies, ns from its hand-over to the worker (launch thread)
-    std::atomic<uint64_t> tl_gather_ns{0}, tl_submit_ns{0};
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
     std::atomic<uint64_t> launch_ns{0};
@@ -161,7 +180,7 @@ struct Stats {
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
         worker_cpus.store(o.worker_cpus.load());
-        tl_gather_ns.store(o.tl_gather_ns.load()); tl_submit_ns.store(o.tl_submit_ns.load());
+
         return *this;
     }
 };
@@ -215,6 +234,8 @@ struct Group {                        // consecutive levels flushed together
     std::atomic<int> state{0};        // 0 queued, 1 launched, 2 retired
     int error = 0;
     std::string error_text;
+    GroupTrace trace;
+    void* marks[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 class Scheduler;
@@ -246,6 +267,14 @@ class DeviceSched {
 
     Backend* backend() { return be_; }
     Stats& stats() { return stats_; }
+    // the most recent retired groups, oldest first (at most 64 are kept)
+    size_t get_trace(GroupTrace* out, size_t max, bool clear)
+    {
+        size_t n = std::min(max, trace_.size());
+        for (size_t i = 0; i < n; i++) out[i] = trace_[trace_.size() - n + i];
+        if (clear) trace_.clear();
+        return n;
+    }
     const std::string& error_text() const { return err_; }
     size_t pending_levels() const { return levels_.size(); }
 
@@ -439,6 +468,7 @@ class DeviceSched {
     int nstreams_ = 1;
     int rr_ = 0;
     uint64_t worker_cpus_ = 0;
+    std::deque<GroupTrace> trace_;
     std::string err_;
     Stats stats_;
 
@@ -886,6 +916,13 @@ inline int DeviceSched::flush(size_t max_levels)
             if (ss.open.empty() || ss.open.back() != g->id) ss.open.push_back(g->id);
         }
     g->done = std::make_shared<EventHolder>(be_);
+    g->trace.id = g->id;
+    g->trace.levels = (uint32_t)k;
+    g->trace.gates = (uint32_t)ngates;
+    g->trace.stream = (uint32_t)g->stream;
+    g->trace.in_bytes = g->in_words * 4;
+    g->trace.out_bytes = g->out_words * 4;
+    g->trace.t_queued = now_ns();
     live_.push_back(g);
     stats_.groups++;
     if (threaded_) {
@@ -938,9 +975,11 @@ inline int DeviceSched::launch(Group* g)
         }
         return !rc;
     };
+    g->trace.t_launch_begin = now_ns();
     step(be_->event_create(&g->done->ev));
     for (auto& e : g->deps)
         if (e->ev && rc == 0) step(be_->stream_wait(s, e->ev));
+    g->marks[0] = be_->mark(s);
     if (rc == 0 && g->in_words) {
         const size_t bytes = g->in_words * 4;
         if (step(get_buf(pinned_cache_, bytes, true, &g->pin_in, &g->pin_in_cap)) &&
@@ -958,23 +997,30 @@ inline int DeviceSched::launch(Group* g)
                         c->host_reads.fetch_sub(1, std::memory_order_release);
                     }
             }
+            g->trace.t_gather_end = now_ns();
             step(be_->h2d(s, g->dev_in, g->pin_in, bytes));
         }
     }
+    if (!g->trace.t_gather_end) g->trace.t_gather_end = now_ns();
     if (rc == 0 && g->out_words) {
         const size_t bytes = g->out_words * 4;
         if (step(get_buf(pinned_cache_, bytes, true, &g->pin_out, &g->pin_out_cap)))
             step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_out, &g->dev_out_cap));
     }
+    // the device-side spans of the trace (scatter | gates | gather) are marked for groups of one level; longer groups get one span
+    const bool single = g->plans.size() == 1;
     for (Plan* p : g->plans) {
         if (rc) break;
         if (!p->uploads.empty()) step(be_->copy_ctxts(s, p->uploads.data(), p->uploads.size(), g->dev_in + p->in_base, true));
+        if (single) g->marks[1] = be_->mark(s);
         for (int l = 0; l < kKinds && !rc; l++)
             if (!p->gates[l].empty()) step(be_->run_gates(s, l, p->gates[l].data(), p->gates[l].size()));
+        if (single) g->marks[2] = be_->mark(s);
         if (!rc && !p->downloads.empty())
             step(be_->copy_ctxts(s, p->downloads.data(), p->downloads.size(), g->dev_out + p->out_base, false));
     }
     if (rc == 0 && g->out_words) step(be_->d2h(s, g->pin_out, g->dev_out, g->out_words * 4));
+    g->marks[3] = be_->mark(s);
     if (g->done->ev) {
         const int r = be_->event_record(s, g->done->ev);
         if (r && !rc) {
@@ -983,6 +1029,7 @@ inline int DeviceSched::launch(Group* g)
         }
     }
     g->error = rc;
+    g->trace.t_submit_end = now_ns();
     g->state.store(1, std::memory_order_release);
     return rc;
 }
@@ -992,6 +1039,7 @@ inline int DeviceSched::retire(Group* g)
 {
     if (g->state.load(std::memory_order_acquire) == 2) return 0;
     ScopedNs timer(&stats_.retire_ns);
+    g->trace.t_done_seen = now_ns();
     int rc = g->error;
     if (rc) {
         sticky_error_ = rc;
@@ -1028,6 +1076,20 @@ inline int DeviceSched::retire(Group* g)
         if (g->dev_out) dev_cache_.push_back({g->dev_out, g->dev_out_cap});
     }
     g->deps.clear();
+    if (g->marks[0] && g->marks[3]) {
+        if (g->marks[1] && g->marks[2]) {
+            g->trace.dev_h2d_ms = be_->elapsed_ms(g->marks[0], g->marks[1]);
+            g->trace.dev_body_ms = be_->elapsed_ms(g->marks[1], g->marks[2]);
+            g->trace.dev_d2h_ms = be_->elapsed_ms(g->marks[2], g->marks[3]);
+        } else {
+            g->trace.dev_body_ms = be_->elapsed_ms(g->marks[0], g->marks[3]);
+        }
+    }
+    for (void*& m : g->marks)
+        if (m) { be_->event_destroy(m); m = nullptr; }
+    g->trace.t_delivered = now_ns();
+    trace_.push_back(g->trace);
+    if (trace_.size() > 64) trace_.pop_front();
     g->state.store(2, std::memory_order_release);
     while (!live_.empty() && live_.front()->state.load(std::memory_order_acquire) == 2) {
         delete live_.front();

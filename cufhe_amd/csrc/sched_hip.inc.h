@@ -150,6 +150,23 @@ class HipBackend : public sched::Backend {
         std::lock_guard<std::mutex> lk(mu_);
         return err_;
     }
+    // timing marks of the scheduler's trace: only while the device is profiling (cufhe_amd_profile_enable)
+    void* mark(int s) override
+    {
+        if (!g_dev[device_].profiling) return nullptr;
+        hipStream_t st;
+        if (stream(s, &st)) return nullptr;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        if (hipEventRecord(e, st) != hipSuccess) { (void)hipEventDestroy(e); return nullptr; }
+        return (void*)e;
+    }
+    float elapsed_ms(void* a, void* b) override
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) { (void)hipGetLastError(); return 0.0f; }
+        return ms;
+    }
     // the device must be idle: drop the internal streams (and their workspaces)
     void destroy_streams()
     {
@@ -439,18 +456,23 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->renames = s.renames;
     out->worker_cpus = s.worker_cpus.load();
     out->moved_gates = s.moved_gates;
-    out->tl_gather_ns = s.tl_gather_ns.load(); out->tl_submit_ns = s.tl_submit_ns.load();
-    {
-        DeviceState& ds = g_dev[device];
-        std::lock_guard<std::mutex> lk2(ds.staging_mu);
-        out->tl_h2d_ns = ds.tl_h2d_ns; out->tl_gates_ns = ds.tl_gates_ns; out->tl_d2h_ns = ds.tl_d2h_ns;
-    }
     if (reset) {
         const uint64_t cpus = s.worker_cpus.load();      // a property of the worker thread, not a counter
         s = sched::Stats();
         s.worker_cpus.store(cpus);
     }
     return 0;
+}
+
+/* timeline of the most recent flushes (oldest first): what the PCIe-inclusive rate of the per-gate API is made of */
+int cufhe_amd_sched_get_trace(int device, cufhe_amd_group_trace* out, int max, int clear)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!out || max < 0) return fail(-1, "null / negative");
+    if (!g_scheduler) return 0;
+    static_assert(sizeof(cufhe_amd_group_trace) == sizeof(sched::GroupTrace), "the C struct mirrors sched::GroupTrace");
+    return (int)g_scheduler->dev(device).get_trace(reinterpret_cast<sched::GroupTrace*>(out), (size_t)max, clear != 0);
 }
 
 }  // extern "C"

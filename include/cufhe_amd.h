@@ -157,13 +157,26 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
     uint64_t worker_cpus;           /* CPUs the device's launch worker is pinned to (0: not pinned; "sched_affinity") */
     uint64_t moved_gates;           /* gates that left their dependence level for a later one with room ("sched_fill") */
-    /* timeline of the most recent flush that carried ciphertext copies (ns, relative to its hand-over to the launch
-     * worker): inputs gathered out of tlwehost, everything submitted; and, from HIP events when profiling is enabled
-     * (cufhe_amd_profile_enable), the device-side spans of the H2D copy, the gates and the D2H copy */
-    uint64_t tl_gather_ns, tl_submit_ns;
-    uint64_t tl_h2d_ns, tl_gates_ns, tl_d2h_ns;
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
+/* Timeline of the most recent flushes of a device (oldest first, at most 64 kept): host times are std::chrono::steady_clock
+ * nanoseconds (time_since_epoch), device spans milliseconds between HIP timing events (0 unless cufhe_amd_profile_enable was
+ * on; marked per phase for flushes of one dependence level, as one span otherwise).  This is what the PCIe-inclusive rate of the
+ * per-gate API (enqueue -> Synchronize, test/test_util.h:29-72) is made of; the reference has no counterpart. */
+typedef struct cufhe_amd_group_trace {
+    uint64_t id;
+    uint32_t levels, gates, stream, pad;
+    uint64_t in_bytes, out_bytes;    /* ciphertext words uploaded / downloaded by this flush */
+    int64_t t_queued;                /* issuing thread: handed to the device's launch worker */
+    int64_t t_launch_begin;          /* worker: picked up */
+    int64_t t_gather_end;            /* worker: inputs copied out of tlwehost into the pinned block */
+    int64_t t_submit_end;            /* worker: everything submitted to the stream */
+    int64_t t_done_seen;             /* issuing thread: completion observed */
+    int64_t t_delivered;             /* issuing thread: results copied into tlwehost */
+    float dev_h2d_ms, dev_body_ms, dev_d2h_ms;   /* H2D copy + scatter | gates | gather + D2H copy */
+    float pad2;
+} cufhe_amd_group_trace;
+int cufhe_amd_sched_get_trace(int device, cufhe_amd_group_trace* out, int max, int clear);
 
 /* ---- pieces of the path (TRLWE-level primitives and parity hooks) ----
  * BootstrapTLWE2TRLWE (src/bootstrap_gpu.cu:806-815): tlwe0[count][n+1] -> acc[count][2N]

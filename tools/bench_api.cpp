@@ -107,7 +107,32 @@ int main(int argc, char** argv)
         std::printf("%s{\"device\": %d, \"gpu\": \"%s\", \"gates\": %llu, \"launch_sequences\": %llu, \"worker_launch_ms\": %.3f, "
                     "\"worker_pinned_cpus\": %llu}", dev ? ", " : "", dev, ident[dev].c_str(), (unsigned long long)per_dev[dev].gates,
                     (unsigned long long)per_dev[dev].launch_sequences, per_dev[dev].launch_ns * 1e-6, (unsigned long long)per_dev[dev].worker_cpus);
-    std::printf("]}\n");
+    std::printf("]");
+    {
+        // one more repetition with HIP timing events on (cufhe_amd_profile_enable) for the timeline of the run: where the
+        // milliseconds between the first Nand() and the return of Synchronize() go, flush by flush (device 0)
+        for (int dev = 0; dev < gpus; dev++) CUFHE_AMD_CHECK(cufhe_amd_profile_enable(dev, 1));
+        std::vector<cufhe_amd_group_trace> tr(64);
+        (void)cufhe_amd_sched_get_trace(0, tr.data(), 64, 1);
+        const int64_t t0 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        for (int i = 0; i < kNumTests; i++) Nand(o[i], a[i], b[i], st[i % kNumStreams]);
+        const int64_t t1 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        Synchronize();
+        const int64_t t2 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        for (int dev = 0; dev < gpus; dev++) CUFHE_AMD_CHECK(cufhe_amd_profile_enable(dev, 0));
+        const int n = cufhe_amd_sched_get_trace(0, tr.data(), 64, 1);
+        auto ms = [&](int64_t t) { return (t - t0) * 1e-6; };
+        std::printf(", \"timeline\": {\"what\": \"one repetition with timing events on; host times in ms from the first Nand() call, device 0\", "
+                    "\"enqueue_end_ms\": %.3f, \"synchronize_return_ms\": %.3f, \"flushes\": [", ms(t1), ms(t2));
+        for (int i = 0; i < n; i++)
+            std::printf("%s{\"gates\": %u, \"in_kib\": %llu, \"out_kib\": %llu, \"queued_ms\": %.3f, \"worker_begin_ms\": %.3f, \"inputs_gathered_ms\": %.3f, "
+                        "\"submitted_ms\": %.3f, \"completion_seen_ms\": %.3f, \"delivered_ms\": %.3f, \"dev_h2d_scatter_ms\": %.3f, \"dev_gates_ms\": %.3f, "
+                        "\"dev_gather_d2h_ms\": %.3f}", i ? ", " : "", tr[i].gates, (unsigned long long)(tr[i].in_bytes >> 10),
+                        (unsigned long long)(tr[i].out_bytes >> 10), ms(tr[i].t_queued), ms(tr[i].t_launch_begin), ms(tr[i].t_gather_end),
+                        ms(tr[i].t_submit_end), ms(tr[i].t_done_seen), ms(tr[i].t_delivered), tr[i].dev_h2d_ms, tr[i].dev_body_ms, tr[i].dev_d2h_ms);
+        std::printf("]}");
+    }
+    std::printf("}\n");
     std::fflush(stdout);
     // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
     // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
