@@ -1266,6 +1266,7 @@ int cufhe_amd_set_option(const char* key, long value)
         return 0;
     }
     if (!strcmp(key, "sched_affinity")) { g_sched_affinity = value != 0; return 0; }
+    if (!strcmp(key, "sched_zero_copy")) { g_sched_zero_copy = value != 0; return 0; }
     if (!strcmp(key, "share_devices")) { g_share_devices = value; g_phys_count = cufhe_amd_device_count(); return 0; }
     if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }

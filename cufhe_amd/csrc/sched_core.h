@@ -91,6 +91,9 @@ class Backend {
     virtual std::string error_text() = 0;
     // optional device-side timing marks (a timing event recorded on stream s, or nullptr when the backend is not
     // profiling) and the milliseconds between two of them once both have completed; marks are freed with event_destroy
+    // the address under which the device reads / writes a block from alloc_pinned directly, or nullptr if it cannot: the scheduler
+    // then skips the staging copies (h2d / d2h) and lets copy_ctxts work on the pinned block itself
+    virtual void* device_alias(void* /*pinned*/) { return nullptr; }
     virtual void* mark(int /*s*/) { return nullptr; }
     virtual float elapsed_ms(void* /*a*/, void* /*b*/) { return 0.0f; }
 };
@@ -236,6 +239,7 @@ struct Group {                        // consecutive levels flushed together
     std::string error_text;
     GroupTrace trace;
     void* marks[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool zero_copy_in = false, zero_copy_out = false;     // dev_in / dev_out alias the pinned blocks: nothing to recycle
 };
 
 class Scheduler;
@@ -980,38 +984,67 @@ inline int DeviceSched::launch(Group* g)
     for (auto& e : g->deps)
         if (e->ev && rc == 0) step(be_->stream_wait(s, e->ev));
     g->marks[0] = be_->mark(s);
+    // Staging.  A backend whose pinned memory is visible to the device (device_alias) needs no copy engine at all: the scatter
+    // kernel reads the pinned block over the bus and the gather kernel writes the results straight into it (zero_copy).  The
+    // inputs of the group's FIRST level -- nothing in this group precedes them -- are then scattered chunk by chunk while the
+    // worker is still gathering the next chunk out of the tlwehosts, so that the device starts its first gate one chunk after
+    // the last input was copied instead of after gather + H2D + scatter one behind the other.
+    bool zero_copy = false;
+    size_t first_done = 0;                                    // uploads of plans[0] already scattered
     if (rc == 0 && g->in_words) {
         const size_t bytes = g->in_words * 4;
-        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_in, &g->pin_in_cap)) &&
-            step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_in, &g->dev_in_cap))) {
-            {
-                // the reference's H2D copies, gathered: tlwehost (or the saved words of a ciphertext that was
-                // destroyed meanwhile) -> the pinned staging block
-                std::lock_guard<std::mutex> lk(copy_mu_);
-                for (Plan* p : g->plans)
-                    for (size_t i = 0; i < p->uploads.size(); i++) {
-                        cufhe_amd_ctxt* c = p->upload_ctxts[i];
-                        const uint32_t* shadow = c->shadow.load(std::memory_order_acquire);
-                        memcpy((uint32_t*)g->pin_in + p->in_base + p->uploads[i].slot, shadow ? shadow : c->host,
-                               (size_t)be_->words(c->level) * 4);
-                        c->host_reads.fetch_sub(1, std::memory_order_release);
+        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_in, &g->pin_in_cap))) {
+            uint32_t* alias = (uint32_t*)be_->device_alias(g->pin_in);
+            zero_copy = alias != nullptr;
+            if (zero_copy) g->dev_in = alias;
+            else step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_in, &g->dev_in_cap));
+        }
+        if (rc == 0) {
+            // the reference's H2D copies, gathered: tlwehost (or the saved words of a ciphertext that was
+            // destroyed meanwhile) -> the pinned staging block
+            constexpr size_t kChunk = 512;
+            for (size_t pi = 0; pi < g->plans.size() && !rc; pi++) {
+                Plan* p = g->plans[pi];
+                for (size_t lo = 0; lo < p->uploads.size() && !rc; lo += kChunk) {
+                    const size_t hi = std::min(p->uploads.size(), lo + kChunk);
+                    {
+                        std::lock_guard<std::mutex> lk(copy_mu_);
+                        for (size_t i = lo; i < hi; i++) {
+                            cufhe_amd_ctxt* c = p->upload_ctxts[i];
+                            const uint32_t* shadow = c->shadow.load(std::memory_order_acquire);
+                            memcpy((uint32_t*)g->pin_in + p->in_base + p->uploads[i].slot, shadow ? shadow : c->host,
+                                   (size_t)be_->words(c->level) * 4);
+                            c->host_reads.fetch_sub(1, std::memory_order_release);
+                        }
                     }
+                    if (zero_copy && pi == 0) {
+                        step(be_->copy_ctxts(s, p->uploads.data() + lo, hi - lo, g->dev_in + p->in_base, true));
+                        first_done = hi;
+                    }
+                }
             }
             g->trace.t_gather_end = now_ns();
-            step(be_->h2d(s, g->dev_in, g->pin_in, bytes));
+            if (!zero_copy && rc == 0) step(be_->h2d(s, g->dev_in, g->pin_in, bytes));
         }
     }
     if (!g->trace.t_gather_end) g->trace.t_gather_end = now_ns();
+    bool zero_copy_out = false;
     if (rc == 0 && g->out_words) {
         const size_t bytes = g->out_words * 4;
-        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_out, &g->pin_out_cap)))
-            step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_out, &g->dev_out_cap));
+        if (step(get_buf(pinned_cache_, bytes, true, &g->pin_out, &g->pin_out_cap))) {
+            uint32_t* alias = (uint32_t*)be_->device_alias(g->pin_out);
+            zero_copy_out = alias != nullptr;
+            if (zero_copy_out) g->dev_out = alias;
+            else step(get_buf(dev_cache_, bytes, false, (void**)&g->dev_out, &g->dev_out_cap));
+        }
     }
     // the device-side spans of the trace (scatter | gates | gather) are marked for groups of one level; longer groups get one span
     const bool single = g->plans.size() == 1;
-    for (Plan* p : g->plans) {
+    for (size_t pi = 0; pi < g->plans.size(); pi++) {
+        Plan* p = g->plans[pi];
         if (rc) break;
-        if (!p->uploads.empty()) step(be_->copy_ctxts(s, p->uploads.data(), p->uploads.size(), g->dev_in + p->in_base, true));
+        const size_t from = pi == 0 ? first_done : 0;
+        if (p->uploads.size() > from) step(be_->copy_ctxts(s, p->uploads.data() + from, p->uploads.size() - from, g->dev_in + p->in_base, true));
         if (single) g->marks[1] = be_->mark(s);
         for (int l = 0; l < kKinds && !rc; l++)
             if (!p->gates[l].empty()) step(be_->run_gates(s, l, p->gates[l].data(), p->gates[l].size()));
@@ -1019,7 +1052,9 @@ inline int DeviceSched::launch(Group* g)
         if (!rc && !p->downloads.empty())
             step(be_->copy_ctxts(s, p->downloads.data(), p->downloads.size(), g->dev_out + p->out_base, false));
     }
-    if (rc == 0 && g->out_words) step(be_->d2h(s, g->pin_out, g->dev_out, g->out_words * 4));
+    if (rc == 0 && g->out_words && !zero_copy_out) step(be_->d2h(s, g->pin_out, g->dev_out, g->out_words * 4));
+    g->zero_copy_in = zero_copy;
+    g->zero_copy_out = zero_copy_out;
     g->marks[3] = be_->mark(s);
     if (g->done->ev) {
         const int r = be_->event_record(s, g->done->ev);
@@ -1072,8 +1107,8 @@ inline int DeviceSched::retire(Group* g)
         std::lock_guard<std::mutex> lk(mu_);
         if (g->pin_in) pinned_cache_.push_back({g->pin_in, g->pin_in_cap});
         if (g->pin_out) pinned_cache_.push_back({g->pin_out, g->pin_out_cap});
-        if (g->dev_in) dev_cache_.push_back({g->dev_in, g->dev_in_cap});
-        if (g->dev_out) dev_cache_.push_back({g->dev_out, g->dev_out_cap});
+        if (g->dev_in && !g->zero_copy_in) dev_cache_.push_back({g->dev_in, g->dev_in_cap});
+        if (g->dev_out && !g->zero_copy_out) dev_cache_.push_back({g->dev_out, g->dev_out_cap});
     }
     g->deps.clear();
     if (g->marks[0] && g->marks[3]) {

@@ -15,6 +15,7 @@ long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: lau
 long g_sched_level_gates = 2048; // a dependence level this full is launched at once
 long g_sched_total_gates = 32768;
 long g_sched_rename = 0;          // 1: outputs take fresh device buffers instead of waiting for the old one's users (sched_core.h)
+long g_sched_zero_copy = 1;       // 1: ciphertext staging is read / written by the scatter / gather kernels in pinned host memory (no copy-engine step)
 long g_sched_affinity = 1;        // 1: a device's launch worker runs on the CPUs local to that GPU (NUMA node of its PCI function)
 
 // "0-15,128-143" -> CPU set; returns the number of CPUs parsed
@@ -149,6 +150,14 @@ class HipBackend : public sched::Backend {
     {
         std::lock_guard<std::mutex> lk(mu_);
         return err_;
+    }
+    // hipHostMalloc memory is mapped into the device's address space: the scatter / gather kernels use it in place
+    void* device_alias(void* pinned) override
+    {
+        if (!g_sched_zero_copy) return nullptr;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, pinned, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return d;
     }
     // timing marks of the scheduler's trace: only while the device is profiling (cufhe_amd_profile_enable)
     void* mark(int s) override

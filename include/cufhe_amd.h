@@ -259,6 +259,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * written; results, tlwehost and every API call behave the same.
  * "sched_level_gates" (default 2048) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program.
+ * "sched_zero_copy" (default 1): the batched ciphertext traffic of a flush is read and written by the scatter / gather kernels
+ * directly in pinned host memory, the inputs of a flush's first level chunk by chunk while the rest is still being gathered
+ * from the tlwehosts; 0 = one H2D / D2H copy per flush through device staging buffers (the round-3 path).
  * "sched_affinity" (default 1): the launch worker thread of a device runs on the CPUs local to that GPU
  * (local_cpulist of its PCI function, intersected with the CPUs the process may use); 0 leaves it to the OS. */
 int cufhe_amd_set_option(const char* key, long value);

@@ -44,6 +44,8 @@ static void toy_gate(int op, int level, uint32_t* out, const uint32_t* a, const 
     memcpy(out, r.data(), r.size() * 4);
 }
 
+static bool g_zero_copy = false;   // argv[5]: the stub's pinned memory is "visible to the device" (Backend::device_alias): no staging copies
+
 struct FakeEvent { uint64_t submitted = 0, completed = 0; };
 
 class FakeBackend : public Backend {
@@ -56,6 +58,7 @@ class FakeBackend : public Backend {
     int free_device(void* p) override { free(p); return 0; }
     int alloc_pinned(size_t bytes, void** p) override { *p = malloc(bytes); memset(*p, 0xAB, bytes); return 0; }
     int free_pinned(void* p) override { free(p); return 0; }
+    void* device_alias(void* pinned) override { return g_zero_copy ? pinned : nullptr; }
     int h2d(int s, void* dst, const void* src, size_t bytes) override { push(s, [=] { memcpy(dst, src, bytes); }); return 0; }
     int d2h(int s, void* dst, const void* src, size_t bytes) override { push(s, [=] { memcpy(dst, src, bytes); }); return 0; }
     int copy_ctxts(int s, const CopyRec* recs, size_t n, uint32_t* staging, bool to_ctxt) override
@@ -497,6 +500,7 @@ int main(int argc, char** argv)
     const int gpus = argc > 2 ? atoi(argv[2]) : 2;
     const bool threaded = argc > 3 ? atoi(argv[3]) != 0 : true;
     g_rename = argc > 4 ? atoi(argv[4]) != 0 : false;
+    g_zero_copy = argc > 5 ? atoi(argv[5]) != 0 : false;
     int failures = 0;
     for (int s = 1; s <= seeds; s++) {
         const int f = random_program(1000 + s, 1 + (s % gpus), threaded);

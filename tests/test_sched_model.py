@@ -27,8 +27,8 @@ def harness():
     return EXE
 
 
-def _run(exe, seeds, gpus, threaded, rename=0):
-    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded), str(rename)], capture_output=True, text=True, timeout=900)
+def _run(exe, seeds, gpus, threaded, rename=0, zero_copy=0):
+    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded), str(rename), str(zero_copy)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     return {s["name"]: s for s in (json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("SHAPE "))}
 
@@ -55,6 +55,16 @@ def test_random_programs_with_output_renaming(harness):
     assert shapes["chained"]["launch_sequences"] <= 6 and shapes["intensive"]["launch_sequences"] <= 8
 
 
+def test_random_programs_with_zero_copy_staging(harness):
+    """Backend::device_alias ("sched_zero_copy", the HIP library's default): the scatter / gather kernels work on the pinned
+    staging blocks themselves and the inputs of a flush's first level are scattered chunk by chunk while the launch worker is
+    still gathering the rest.  Same in-order semantics on the random programs, with and without renaming."""
+    shapes = _run(harness, 120, 3, 1, zero_copy=1)
+    assert shapes["chained"]["launch_sequences"] <= 6 and shapes["intensive"]["uploads"] <= 8
+    _run(harness, 60, 3, 1, rename=1, zero_copy=1)
+    _run(harness, 60, 2, 0, zero_copy=1)
+
+
 def test_sanitizers(harness, tmp_path):
     """The same run under AddressSanitizer + UBSan (CPU build only), worker threads on."""
     exe = str(tmp_path / "sched_harness_asan")
@@ -62,13 +72,14 @@ def test_sanitizers(harness, tmp_path):
                            "-fno-sanitize-recover=all", "-o", exe, SRC])
     _run(exe, 25, 3, 1)
     _run(exe, 25, 3, 1, rename=1)
+    _run(exe, 25, 3, 1, zero_copy=1)
 
 
 def test_thread_sanitizer(harness, tmp_path):
     """The issuing thread against the per-device launch workers under ThreadSanitizer (CPU build only)."""
     exe = str(tmp_path / "sched_harness_tsan")
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe, SRC])
-    for rename in ("0", "1"):
-        out = subprocess.run([exe, "12", "3", "1", rename], capture_output=True, text=True, timeout=900)
+    for rename, zero_copy in (("0", "0"), ("1", "0"), ("0", "1")):
+        out = subprocess.run([exe, "12", "3", "1", rename, zero_copy], capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
         assert "ThreadSanitizer" not in out.stderr, out.stderr[:4000]
