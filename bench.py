@@ -501,6 +501,8 @@ def main():
                     res["api_pcie_inclusive"]["depth_first_netlist"] = lines[1]
                 if len(lines) > 2:
                     res["api_pcie_inclusive"]["depth_first_netlist_renamed_outputs"] = lines[2]
+                if len(lines) > 3:
+                    res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = lines[3]
                 res["api_pcie_inclusive"]["what"] = ("4096 cufhe::Nand(out, a, b, st) on host-resident ciphertexts over 256 streams, "
                                                      "then Synchronize(): test/test_util.h:29-72; host_issue = recording + result delivery "
                                                      "on the issuing thread, host_worker = the device's launch thread")

@@ -327,7 +327,7 @@ class DeviceSched {
     int slot_alloc(int level, uint32_t** out);
     void slot_free(int level, uint32_t* p) { free_slots_[level].push_back(p); }
 
-    size_t level_flush_gates = 2048;   // a level this full is launched at once (one round of the blind-rotate grid)
+    size_t level_flush_gates = 4096;   // a level this full is launched at once (two rounds of the blind-rotate grid: 102.5 k gates/s per launch against 100.3 k for one)
     size_t total_flush_gates = 32768;  // bound on the recorded program
     // Renaming: an output whose device buffer still has recorded users (an earlier write not yet superseded, readers of
     // the old value) takes a FRESH buffer instead of waiting for them, so that only true data dependences order the

@@ -12,7 +12,7 @@ namespace {
 
 long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
-long g_sched_level_gates = 2048; // a dependence level this full is launched at once
+long g_sched_level_gates = 4096; // a dependence level this full is launched at once (two rounds of the batch kernel's grid)
 long g_sched_total_gates = 32768;
 long g_sched_rename = 0;          // 1: outputs take fresh device buffers instead of waiting for the old one's users (sched_core.h)
 long g_sched_zero_copy = 1;       // 1: ciphertext staging is read / written by the scatter / gather kernels in pinned host memory (no copy-engine step)
