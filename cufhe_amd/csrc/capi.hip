@@ -1254,6 +1254,7 @@ int cufhe_amd_set_option(const char* key, long value)
         if (g_scheduler)
             for (int d = 0; d < g_scheduler->gpu_num(); d++) {
                 g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
+                g_scheduler->dev(d).idle_flush_gates = (size_t)std::min(g_sched_level_gates, 2048L);
                 g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
             }
         return 0;

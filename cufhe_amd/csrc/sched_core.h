@@ -327,7 +327,11 @@ class DeviceSched {
     int slot_alloc(int level, uint32_t** out);
     void slot_free(int level, uint32_t* p) { free_slots_[level].push_back(p); }
 
-    size_t level_flush_gates = 4096;   // a level this full is launched at once (two rounds of the blind-rotate grid: 102.5 k gates/s per launch against 100.3 k for one)
+    // A front level this full is launched at once: two rounds of the blind-rotate grid while the device still has work (102.5 k
+    // gates/s per launch against 100.3 k for one round; 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s), ONE round when
+    // the device is idle -- nothing to overlap the recording of the second round with (4096 gates: 43.7 ms against 44.5 - 50).
+    size_t level_flush_gates = 4096;
+    size_t idle_flush_gates = 2048;
     size_t total_flush_gates = 32768;  // bound on the recorded program
     // Renaming: an output whose device buffer still has recorded users (an earlier write not yet superseded, readers of
     // the old value) takes a FRESH buffer instead of waiting for them, so that only true data dependences order the
@@ -450,6 +454,16 @@ class DeviceSched {
         StreamState& ss = stream_state(stream);
         ss.max_depth = std::max(ss.max_depth, depth);
         if (p.streams.empty() || p.streams.back() != stream) p.streams.push_back(stream);
+    }
+    // nothing queued, nothing running: every flushed group has completed (whether or not its results were delivered yet)
+    bool device_idle()
+    {
+        for (Group* g : live_) {
+            const int st = g->state.load(std::memory_order_acquire);
+            if (st == 0) return false;
+            if (st == 1 && !g->error && g->done->ev && be_->event_query(g->done->ev) != 1) return false;
+        }
+        return true;
     }
     int resolve_host(cufhe_amd_ctxt* c, bool* need_upload);
     void record_upload(cufhe_amd_ctxt* c, void* stream);
@@ -859,6 +873,8 @@ inline int DeviceSched::after_record()
     // level waits for the caller's Synchronize, up to eight rounds.
     if (!levels_.empty()) {
         const size_t front = levels_.front()->gate_count();
+        if (front >= idle_flush_gates && front < level_flush_gates && (front - idle_flush_gates) % 256 == 0 && levels_.size() == 1 && device_idle())
+            return flush(1);
         if (front >= level_flush_gates &&
             (levels_.size() == 1 || 2 * levels_[1]->gate_count() >= level_flush_gates || front >= 8 * level_flush_gates))
             return flush(1);

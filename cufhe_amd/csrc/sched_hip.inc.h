@@ -255,6 +255,7 @@ sched::Scheduler* scheduler()
         });
         for (int d = 0; d < g_gpu_num; d++) {
             g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
+            g_scheduler->dev(d).idle_flush_gates = (size_t)std::min(g_sched_level_gates, 2048L);
             g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
             g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
         }

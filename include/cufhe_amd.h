@@ -116,7 +116,7 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
  * :160-167, device buffers only).  The gate is RECORDED with its data dependences; the recorded
  * program of a device is launched level by level (all gates whose operands are ready: one
  * blind-rotate + one key-switch launch per level) at Synchronize / StreamQuery / cufhe_amd_flush,
- * or as soon as a level holds 4096 gates.  Stream order, output aliasing, shared inputs and
+ * or as soon as a level holds 4096 gates (2048 when the device is idle).  Stream order, output aliasing, shared inputs and
  * completion semantics are those of the reference (see cufhe_amd/csrc/sched_core.h).
  * cufhe_amd_ctxt_destroy never waits: buffers are recycled when the last recorded gate naming
  * them has retired. */
@@ -257,7 +257,7 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * independent gates of the adders (16-bit adders: 64 dependence levels become 33).  The pointer returned by
  * cufhe_amd_ctxt_device_ptr (Ctxt::tlwedevices in the C++ shim) is then only valid until the ciphertext is next
  * written; results, tlwehost and every API call behave the same.
- * "sched_level_gates" (default 4096; 2048 until round 4: 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s) / "sched_total_gates" (default 32768): a dependence level this
+ * "sched_level_gates" (default 4096 while the device has work -- 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s --, 2048 when it is idle) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program.
  * "sched_zero_copy" (default 1): the batched ciphertext traffic of a flush is read and written by the scatter / gather kernels
  * directly in pinned host memory, the inputs of a flush's first level chunk by chunk while the rest is still being gathered
