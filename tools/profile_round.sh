@@ -31,4 +31,14 @@ echo "tcc pass done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_ACTIVE_INST_VALU \
     --kernel-trace -d $OUT/pmc_mix -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "instruction-mix pass done"
+# the two blind-rotate kernels of the N = 2048 ring side by side (HIP events), their counters in one PMC pass, and -- when a
+# diagnostic build with per-phase cycle counters was shipped (python cufhe_amd/build.py --diagnostic=PHASES) -- the cycles per phase
+python3 tools/lvl2_ab.py 4096 2>&1 | grep -v amdgpu.ids > $OUT/lvl2_ab.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
+    --kernel-trace -d $OUT/pmc_lvl2ab -o pmc --output-format csv -- python3 tools/lvl2_ab.py 4096 > /dev/null 2>&1
+echo "lvl2 A/B pass done"
+if [ -f cufhe_amd/libcufhe_amd_diag.so ]; then
+    CUFHE_AMD_LIBRARY=cufhe_amd/libcufhe_amd_diag.so LVL2_KERNEL=0 python3 tools/lvl2_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/lvl2_phases_half_waves.txt || true
+    CUFHE_AMD_LIBRARY=cufhe_amd/libcufhe_amd_diag.so LVL2_KERNEL=1 python3 tools/lvl2_phases.py 2>&1 | grep -v amdgpu.ids > $OUT/lvl2_phases_quarter_waves.txt || true
+fi
 find $OUT -name "*.csv" | head -40
