@@ -212,6 +212,10 @@ def valu_block(kernel, rotations, launch_ms, clock_hz):
         "frac_of_fp64_issue": FP64_ISSUE_CYCLES_SPEC * insts / slots,
         "frac_of_measured_issue_floor": FP64_ISSUE_CYCLES_MEASURED * insts / slots,
         "clock_hz_this_run": clock_hz,
+        "clock_note": "the clock of THIS run comes from a short FP64 probe kernel (cufhe_amd_probe_clock); a kernel that drives the chip into its power "
+                      "limit runs below it (blind_rotate_lvl2q_kernel: 2.18 GHz under the profiler against 2.43 probed), and its frac_* here are then "
+                      "understated: pipe_busy_under_profiler is measured with the clock the launch really held",
+        "clock_hz_under_profiler": facts.get("clock_hz_under_profiler"),
         "pipe_busy_under_profiler": facts.get("valu_pipe_busy"),
         "lds_bank_conflict_frac": facts.get("lds_bank_conflict_frac"),
         "waves_per_simd": facts.get("waves_per_simd"),
@@ -286,6 +290,10 @@ def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12
 
 def main():
     args = ARGS
+    # stdout carries ONE line, the JSON: whatever else writes to file descriptor 1 below (gloo's "[Gloo] Rank 0 is connected ..."
+    # banner, runtime notices) goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.gpus != WORLD:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={WORLD}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
                  "or plainly (no WORLD_SIZE in the environment) and bench.py starts the ranks itself")
@@ -659,7 +667,7 @@ def main():
                                    "implementation": "oracle/tfhe_oracle_lvl2.c (the checker itself; no optimised CPU path for this ring)",
                                    "sample": f"{n_chk} of the batch's NAND gates, {dt:.1f} s",
                                    "gpu_words_match_oracle": bool(np.array_equal(want.reshape(n_chk, -1), main_out[:n_chk]))}
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=json_out, flush=True)
 
     st.Destroy()
     eng.CleanUp()
