@@ -388,6 +388,13 @@ def sched_stats(device=0, reset=False):
 
 
 # ---- other parameter sets (include/cufhe_amd.h: cufhe_amd_ps_*) ----
+def sched_trace(device=0, clear=True, max_entries=64):
+    """the per-flush timeline of the per-gate API (cufhe_amd_sched_get_trace): list of dicts, oldest first"""
+    buf = (_lib.GroupTrace * max_entries)()
+    n = check(lib.cufhe_amd_sched_get_trace(int(device), buf, max_entries, int(bool(clear))))
+    return [{f: getattr(buf[i], f) for f, _ in _lib.GroupTrace._fields_ if not f.startswith("pad")} for i in range(n)]
+
+
 def ps_count():
     return lib.cufhe_amd_ps_count()
 

@@ -69,6 +69,49 @@ def test_enqueue_gate_words(engine, keys, level):
         s.Destroy()
 
 
+@pytest.mark.parametrize("zero_copy", [1, 0])
+def test_staging_paths_and_flush_timeline(engine, keys, zero_copy):
+    """Both ways a flush moves its ciphertexts -- the scatter / gather kernels working on the pinned block itself ("sched_zero_copy", the
+    default; the first level's inputs go chunk by chunk behind the gather) and the round-3 path through device staging copies -- deliver the
+    oracle's words, and every flush leaves a consistent record in cufhe_amd_sched_get_trace (include/cufhe_amd.h)."""
+    api = engine.api
+    api.set_option("sched_zero_copy", zero_copy)
+    try:
+        count = 1300                   # three chunks of 512 inputs in the first level, a ragged last one
+        rng = np.random.default_rng(901 + zero_copy)
+        bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+        (a, ea), (b, eb) = (_ctxts(api, keys, bits[i], 0, 9100 + i) for i in range(2))
+        outs = [api.Ctxt(0) for _ in range(count)]
+        outs2 = [api.Ctxt(0) for _ in range(count)]
+        sts = [api.Stream() for _ in range(16)]
+        for s in sts:
+            s.Create()
+        api.Synchronize()
+        api.sched_trace(clear=True)
+        api.profile_enable(True)
+        for g in range(count):
+            api.Xor(outs[g], a[g], b[g], sts[g % 16])
+        for g in range(count):         # a second level: reads results still on their way to tlwehost
+            api.Nand(outs2[g], outs[g], b[g], sts[g % 16])
+        api.Synchronize()
+        api.profile_enable(False)
+        api.profile_get(reset=True)
+        w1 = keys.gate_batch(O("XOR"), 0, ea, eb)
+        assert np.array_equal(_host(outs), w1)
+        assert np.array_equal(_host(outs2), keys.gate_batch(O("NAND"), 0, w1, eb))
+        tr = api.sched_trace()
+        assert tr and sum(t["gates"] for t in tr) == 2 * count
+        assert sum(t["in_bytes"] for t in tr) == 2 * count * (ol.n + 1) * 4           # a, b uploaded once; outs never re-uploaded
+        assert sum(t["out_bytes"] for t in tr) == 2 * count * (ol.n + 1) * 4
+        for t in tr:
+            assert t["t_queued"] <= t["t_launch_begin"] <= t["t_gather_end"] <= t["t_submit_end"] <= t["t_done_seen"] <= t["t_delivered"], t
+            assert t["dev_h2d_ms"] >= 0 and t["dev_body_ms"] > 0 and t["dev_d2h_ms"] >= 0, t
+        for s in sts:
+            s.Destroy()
+    finally:
+        api.set_option("sched_zero_copy", 1)
+
+
 def test_chained_program_levels_and_words(engine, keys):
     """test/test_api_gpu.cu:140-159: 64 chains of 5 in-place gates on 8 streams, one Synchronize.
     Must run as 5 dependence levels (<= 6 launch sequences), whole program == oracle word for word."""
