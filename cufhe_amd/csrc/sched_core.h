@@ -167,7 +167,6 @@ struct Stats {
     uint64_t max_level_gates = 0;
     uint64_t cross_stream_waits = 0;
     uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
-    uint64_t moved_gates = 0;         // gates that left their dependence level for a later one with room (fill_levels)
     std::atomic<uint64_t> worker_cpus{0};   // CPUs the launch worker is pinned to
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
@@ -179,7 +178,6 @@ struct Stats {
         gates = o.gates; groups = o.groups; levels = o.levels; launch_sequences = o.launch_sequences;
         uploads = o.uploads; uploads_shared = o.uploads_shared; downloads = o.downloads; forced_syncs = o.forced_syncs;
         max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits; renames = o.renames;
-        moved_gates = o.moved_gates;
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
         worker_cpus.store(o.worker_cpus.load());

@@ -465,7 +465,6 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
     out->renames = s.renames;
     out->worker_cpus = s.worker_cpus.load();
-    out->moved_gates = s.moved_gates;
     if (reset) {
         const uint64_t cpus = s.worker_cpus.load();      // a property of the worker thread, not a counter
         s = sched::Stats();

@@ -156,7 +156,6 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t launch_ns;             /* host time on the device's launch worker */
     uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
     uint64_t worker_cpus;           /* CPUs the device's launch worker is pinned to (0: not pinned; "sched_affinity") */
-    uint64_t moved_gates;           /* gates that left their dependence level for a later one with room ("sched_fill") */
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 /* Timeline of the most recent flushes of a device (oldest first, at most 64 kept): host times are std::chrono::steady_clock
