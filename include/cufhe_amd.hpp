@@ -229,10 +229,10 @@ CUFHE_AMD_GATE3(Mux, CUFHE_AMD_MUX)
 CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
 
 // ---- TRLWE-level primitives, include/cufhe_gpu.cuh:123-146,209-216,282-285 ----
-// Same names and operands as the reference.  GateBootstrappingTLWE2TRLWElvl01NTT, Refresh and
-// SampleExtractAndKeySwitch (and their g-forms) are RECORDED like gates and launched in batches: as in the
-// reference, results are in the host members after Synchronize() or StreamQuery(st) == true.  TRGSW2NTT and
-// CMUXNTT complete before returning.
+// Same names and operands as the reference.  GateBootstrappingTLWE2TRLWElvl01NTT, Refresh,
+// SampleExtractAndKeySwitch and CMUXNTT (and their g-forms) are RECORDED like gates and launched in batches: as in the
+// reference, results are in the host members after Synchronize() or StreamQuery(st) == true.  TRGSW2NTT completes
+// before returning (the reference waits for its D2H copy too).
 
 /// struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134
 struct cuFHETRLWElvl1 {
