@@ -43,6 +43,31 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
 #ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
+// The first TWO stages of half h of the forward transform on one row's gadget digits, exactly (round 4).  q0 / q1 hold, as signed
+// bytes, the digits at e = lane + 64 r (q0) and e + 512 (q1), r = 0..7.  The 1024-point transform's stage 0 gives u_h = a +- I b, its
+// stage 1 pairs u_h[e] with u_h[e + 256] under zeta (h = 0) or zeta^3 (h = 1).  On the four original digits a, a' (e, e + 256) and
+// b, b' (e + 512, e + 768) both are exact linear forms -- zeta^3 I = zeta^5 = -zeta, so zeta^3 (a' - I b') = zeta^3 a' + zeta b' and the
+// 37-bit root only meets a 6-bit digit: five FMAs per pair where the general butterfly took ten operations.  |x| < 2^42.2.
+__device__ __forceinline__ void ll_split_first_stages(double (&x)[kRegs8], const uint2 q0, const uint2 q1, int h)
+{
+    constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double a = (double)(int32_t)__builtin_amdgcn_sbfe(q0.x, 8u * r, 8u), a1 = (double)(int32_t)__builtin_amdgcn_sbfe(q0.y, 8u * r, 8u);
+        const double b = (double)(int32_t)__builtin_amdgcn_sbfe(q1.x, 8u * r, 8u), b1 = (double)(int32_t)__builtin_amdgcn_sbfe(q1.y, 8u * r, 8u);
+        if (h == 0) {
+            const double u = __builtin_fma(b, fpf::ROOT4, a), u1 = __builtin_fma(b1, fpf::ROOT4, a1);
+            x[r] = __builtin_fma(u1, fpf::ROOT8, u);
+            x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
+        } else {
+            const double v = __builtin_fma(-b, fpf::ROOT4, a);
+            const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
+            x[r] = v + t;
+            x[r + 4] = v - t;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump)
@@ -152,13 +177,8 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             // inverse waves (out = wj); then the first stage of the transform
             const uint2 q0 = digL[(row * 2 + 0) * 64 + lane], q1 = digL[(row * 2 + 1) * 64 + lane];
             double x[kRegs8];
-#pragma unroll
-            for (int r = 0; r < kRegs8; r++) {
-                const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(r < 4 ? q0.x : q0.y, 8u * (r & 3), 8u);
-                const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(r < 4 ? q1.x : q1.y, 8u * (r & 3), 8u);
-                x[r] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);       // exact: |I a| < 2^30
-            }
-            ntt512_forward_tu(x, ctx, tu);
+            ll_split_first_stages(x, q0, q1, h);
+            ntt512_forward_tu_from1(x, ctx, tu);
             double* s0 = sumL + h * kH + lane;
 #pragma unroll
             for (int o = 0; o < 2; o++)
@@ -336,13 +356,8 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     auto row_phase = [&](const Rot& r) {
         const uint2 q0 = r.dig[(row * 2 + 0) * 64 + lane], q1 = r.dig[(row * 2 + 1) * 64 + lane];
         double x[kRegs8];
-#pragma unroll
-        for (int k = 0; k < kRegs8; k++) {
-            const double a0 = (double)(int32_t)__builtin_amdgcn_sbfe(k < 4 ? q0.x : q0.y, 8u * (k & 3), 8u);
-            const double a1 = (double)(int32_t)__builtin_amdgcn_sbfe(k < 4 ? q1.x : q1.y, 8u * (k & 3), 8u);
-            x[k] = __builtin_fma(h ? -a1 : a1, fpf::ROOT4, a0);
-        }
-        ntt512_forward_tu(x, ctx, tu);
+        ll_split_first_stages(x, q0, q1, h);
+        ntt512_forward_tu_from1(x, ctx, tu);
         double* s0 = r.sum + h * kH + lane;
 #pragma unroll
         for (int o = 0; o < 2; o++)

@@ -23,15 +23,15 @@
 //
 // Lazy-reduction schedule (bounds in units of p, see fpfield.h; checked on the host by
 // tests/host/host_model.cpp through tests/test_fpfield.py):
-//   forward, gadget digits in (|x| <= 32): stage 0 and the zeta half of stage 1 multiply by
-//            25- and 13-bit roots without reducing (values stay below 2^43); then
-//            after s1..s9: .5 1.05 1.66 2.32 3.04 3.84 4.71 5.67 7.22
-//            (only stage 9 needs mulmod_wide: its input 5.67 exceeds 5.142)
+//   forward, gadget digits in (|x| <= 32): stages 0 and 1 are one exact radix-4 butterfly on the inputs (roots I, zeta and
+//            zeta^3 I = -zeta: values stay below 2^42.2 = 0.006 p, nothing is reduced); then
+//            after s2..s9: .51 1.06 1.66 2.32 3.05 3.85 4.72 6.18
+//            (only stage 9 needs mulmod_wide: kept wide as before, its input is now 4.72)
 //   forward, 32-bit words in (key conversion): every stage reduces; .5 1.05 ... 5.67 7.22 8.92
 //            with stages 8 and 9 wide
 //   inverse  in <= .5         s9 1.0  s8 2.0  s7 4.0  s6 8.0(wide) reduce  s5 1.0  s4 2.0
 //            s3 4.0  s2 8.0(wide) reduce  s1 1.0  s0 2.0
-//   pointwise: digits spectrum <= 7.22 -> each wide product <= 1.702, six of them 10.21 < 10.285
+//   pointwise: digits spectrum <= 6.18 -> each wide product <= 1.601, six of them 9.61 < 10.285
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fpfield.h"
@@ -51,11 +51,10 @@ constexpr int kTileBytes = kTileSlots * 8;   // 8448
 // input would exceed what its multiplication accepts.
 constexpr double forward_digit_spectrum_bound(double digit_max)
 {
-    // stage 0 (I) and the zeta half of stage 1 multiply without reducing: the value must stay an exact double
-    const double s0 = digit_max * (1.0 + fpf::ROOT4);
-    const double s1z = s0 * (1.0 + fpf::ROOT8);
-    if (s1z >= 9007199254740992.0 / 1024.0) return -1.0;      // keep 10 bits of headroom below 2^53
-    double b = s1z / fpf::P + fpf::after_mulmod(s0 / fpf::P); // the reducing half of stage 1 dominates: ~0.5
+    // stages 0 and 1 are one exact radix-4 butterfly on the inputs (ct_four_stages): every partial sum must stay an exact double
+    const double s1 = digit_max * (1.0 + fpf::ROOT4 + fpf::ROOT8 + fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8);
+    if (s1 >= 9007199254740992.0 / 1024.0) return -1.0;       // keep 10 bits of headroom below 2^53
+    double b = s1 / fpf::P;                                   // 2^42.2 / p = 0.006 for Bg = 2^6 (0.5 until the second group of stage 1 was made exact)
     for (int s = 2; s <= 8; s++) {                            // stages 2..8: mulmod
         if (b >= fpf::LIM_NARROW) return -1.0;
         b = b + fpf::after_mulmod(b);
@@ -227,13 +226,25 @@ template <bool SMALL_IN, class TW, bool EXACT0 = false>
 __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
 {
     if (SMALL_IN) {
+        // Stages 0 and 1 as one exact radix-4 butterfly on the four ORIGINAL inputs a, a', b, b' (elements e, e + 256, e + 512, e + 768):
+        //   u = a + I b, u' = a' + I b', v = a - I b                 stage 0 (I = zeta^2, 25 bits)
+        //   x[r] = u + zeta u', x[r + 4] = u - zeta u'                stage 1, first group (zeta, 13 bits)
+        //   x[r + 8], x[r + 12] = v +- zeta^3 (a' - I b')             stage 1, second group: its twiddle zeta^3 has 37 bits, but
+        //                       = v +- (zeta^3 a' + zeta b')          zeta^3 I = zeta^5 = -zeta, so it only ever meets an input, not a product
+        // Nine exact FP64 operations per four elements (round 1-3: fourteen, the second group through a modular product); every
+        // value stays below |x| (1 + I + zeta + zeta^3) = 2^42.2 for gadget digits.
+        constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;          // zeta^3 = 160 989 184 000, exact
 #pragma unroll
-        for (int r = 0; r < 8; r++) ct_bfly_exact(x[r], x[r + 8], fpf::ROOT4);
-#pragma unroll
-        for (int r = 0; r < 4; r++) ct_bfly_exact(x[r], x[r + 4], fpf::ROOT8);
-        const double w = tw(2);
-#pragma unroll
-        for (int r = 0; r < 4; r++) ct_bfly<false>(x[8 + r], x[8 + r + 4], w);
+        for (int r = 0; r < 4; r++) {
+            const double a = x[r], a1 = x[r + 4], b = x[r + 8], b1 = x[r + 12];
+            const double u = __builtin_fma(b, fpf::ROOT4, a), v = __builtin_fma(-b, fpf::ROOT4, a);
+            const double u1 = __builtin_fma(b1, fpf::ROOT4, a1);
+            const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
+            x[r] = __builtin_fma(u1, fpf::ROOT8, u);
+            x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
+            x[r + 8] = v + t;
+            x[r + 12] = v - t;
+        }
     } else {
         const double w0 = tw(0);
 #pragma unroll

@@ -145,6 +145,29 @@ __device__ __forceinline__ void ntt512_forward_tu(double (&x)[kRegs8], const Wav
     CUFHE_AMD_XPOSE8(c.b2, 64, c.c2, 8 * 72)          // B -> C
     ct_three_stages<true>(x, TwArr{twc});
 }
+// The same with stage 0 already applied by the caller (the low-latency kernels fold it, exactly, into the split of the gadget
+// digits: kernels_ll.hip.h, ll_split_first_stages): stages 1 and 2 with tu[1..6], then as above.
+__device__ __forceinline__ void ntt512_forward_tu_from1(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7])
+{
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const double w = tu[1 + g];
+#pragma unroll
+        for (int r = 0; r < 2; r++) ct_bfly<false>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) ct_bfly<false>(x[2 * g], x[2 * g + 1], tu[3 + g]);
+    double twb[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twb[k] = lds_ld(c.tb_fwd, 64 * k);
+    CUFHE_AMD_XPOSE8(c.a1, 8 * 68, c.b1, 64)          // A -> B
+    ct_three_stages<false>(x, TwArr{twb});
+    double twc[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
+    CUFHE_AMD_XPOSE8(c.b2, 64, c.c2, 8 * 72)          // B -> C
+    ct_three_stages<true>(x, TwArr{twc});
+}
 __device__ __forceinline__ void ntt512_inverse_tu(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7])
 {
     double twc[7];

@@ -69,24 +69,49 @@ double mm(double a, double w, bool wide, Track& t)
     return r;
 }
 
-// forward (ntt_wave.h ntt_forward<SMALL_IN>): small_in (gadget digits): stage 0 and group 0
-// of stage 1 multiply exactly by I and zeta without reducing, stages 2..8 mulmod, stage 9
+// forward (ntt_wave.h ntt_forward<SMALL_IN>): small_in (gadget digits): stages 0 and 1 are ONE exact radix-4 butterfly on the
+// original inputs (roots I, zeta and zeta^3 I = -zeta: nothing is reduced), stages 2..8 mulmod, stage 9
 // wide; otherwise (32-bit words) stages 0..7 mulmod, 8 and 9 wide.
 void fwd(double* x, Track& t, double* stage_max, bool small_in)
 {
-    int tt = N >> 1, s = 0;
-    for (int m = 1; m < N; m <<= 1, tt >>= 1, s++) {
+    int tt = N >> 1, s = 0, m = 1;
+    if (small_in) {
+        // ct_four_stages<SMALL_IN>: elements e, e + 256, e + 512, e + 768
+        const double Z3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
+        if (g_fwd[1] != fpf::ROOT4 || g_fwd[2] != fpf::ROOT8 || g_fwd[3] != Z3) t.bad++;      // the table's roots are the small ones the kernel hard-codes
+        double mx = 0;
+        for (int j = 0; j < N / 4; j++) {
+            const double a = x[j], a1 = x[j + N / 4], b = x[j + N / 2], b1 = x[j + 3 * N / 4];
+            const double u = std::fma(b, fpf::ROOT4, a), v = std::fma(-b, fpf::ROOT4, a);
+            const double u1 = std::fma(b1, fpf::ROOT4, a1);
+            const double p0 = b1 * fpf::ROOT8;
+            const double tz = std::fma(a1, Z3, p0);
+            const double q0 = std::fma(u1, fpf::ROOT8, u), q1 = std::fma(-u1, fpf::ROOT8, u), q2 = v + tz, q3 = v - tz;
+            for (double w : {u, v, u1, p0, tz, q0, q1, q2, q3}) t.val(w);
+            // the same values from the two plain stages in exact integer arithmetic (everything is far below 2^63)
+            const long long A = (long long)a, A1 = (long long)a1, B = (long long)b, B1 = (long long)b1, I = (long long)fpf::ROOT4, Z = (long long)fpf::ROOT8;
+            const long long U = A + I * B, V = A - I * B, U1 = A1 + I * B1, V1 = A1 - I * B1;
+            const long long Z3m = (long long)Z3;
+            // zeta^3 V1 = zeta^3 A1 - zeta^3 I B1 and zeta^3 I = zeta^5 = -zeta (mod p): compare modulo p
+            auto modp = [](__int128 z) { long long r = (long long)(z % (__int128)fpf::P_U64); return r < 0 ? r + (long long)fpf::P_U64 : r; };
+            if (modp((__int128)Z3m * V1) != modp((__int128)Z3m * A1 + (__int128)Z * B1)) t.bad++;
+            if ((long long)q0 != U + Z * U1 || (long long)q1 != U - Z * U1) t.bad++;
+            if (modp((__int128)(long long)q2) != modp((__int128)V + (__int128)Z3m * V1) || modp((__int128)(long long)q3) != modp((__int128)V - (__int128)Z3m * V1)) t.bad++;
+            x[j] = q0; x[j + N / 4] = q1; x[j + N / 2] = q2; x[j + 3 * N / 4] = q3;
+            mx = std::fmax(mx, std::fmax(std::fmax(std::fabs(q0), std::fabs(q1)), std::fmax(std::fabs(q2), std::fabs(q3))));
+        }
+        if (stage_max) stage_max[0] = stage_max[1] = mx / fpf::P;
+        m = 4; tt = N >> 3; s = 2;
+    }
+    for (; m < N; m <<= 1, tt >>= 1, s++) {
         const bool wide = small_in ? s >= 9 : s >= 8;
         double mx = 0;
         for (int g = 0; g < m; g++) {
             const double w = g_fwd[m + g];
-            const bool exact = small_in && (s == 0 || (s == 1 && g == 0));
-            if (exact && w != (s == 0 ? fpf::ROOT4 : fpf::ROOT8)) t.bad++;
             double* a = x + 2 * g * tt;
             for (int j = 0; j < tt; j++) {
-                double v, u = a[j];
-                if (exact) { v = a[j + tt] * w; t.val(v); }
-                else v = mm(a[j + tt], w, wide, t);
+                double u = a[j];
+                const double v = mm(a[j + tt], w, wide, t);
                 a[j] = u + v; a[j + tt] = u - v;
                 t.val(a[j]); t.val(a[j + tt]);
                 mx = std::fmax(mx, std::fmax(std::fabs(a[j]), std::fabs(a[j + tt])));
