@@ -101,9 +101,11 @@ template <> struct Poly<10> {
     }
     // natural order in (element lane + 64 r in register r), spectrum order out; any |x| < 2^32
     static __device__ __forceinline__ void forward(double (&x)[R], const Ctx& c) { ntt_forward<false>(x, c); }
-    // |x| <= 32 (gadget digits of Bg <= 2^6): the first two stages multiply exactly (one radix-4 butterfly on the inputs); spectrum bound 6.18 p instead of 8.92 p
+    // gadget digits (|x| <= Bg/2, as long as the exact radix-4 butterfly of the first two stages stays exact: Bg <= 2^10 does): spectrum
+    // bound 6.18 p (Bg = 2^6) .. 6.3 p instead of 8.92 p
     static __device__ __forceinline__ void forward_small(double (&x)[R], const Ctx& c) { ntt_forward<true>(x, c); }
-    static constexpr double spectrum_bound(bool small) { return small ? forward_digit_spectrum_bound(32.0) : forward_words_spectrum_bound(); }
+    static constexpr bool small_ok(double digit_max) { return forward_digit_spectrum_bound(digit_max) > 0; }
+    static constexpr double spectrum_bound(bool small, double digit_max) { return small ? forward_digit_spectrum_bound(digit_max) : forward_words_spectrum_bound(); }
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt_inverse(x, c); }
 };
 template <> struct Poly<9> {
@@ -120,8 +122,10 @@ template <> struct Poly<9> {
         return make_wave512_ctx(lds, tile_off, tables_off, gt, lane);
     }
     static __device__ __forceinline__ void forward(double (&x)[R], const Ctx& c) { ntt512_forward(x, c); }
-    static __device__ __forceinline__ void forward_small(double (&x)[R], const Ctx& c) { ntt512_forward(x, c); }
-    static constexpr double spectrum_bound(bool) { return 7.23; }      // ntt_wave512.h: inputs far below p, |out| <= 7.22 p
+    // |x| <= 32: stages 0 and 1 exact (the stand-alone transform's first roots are I, zeta, zeta^3)
+    static __device__ __forceinline__ void forward_small(double (&x)[R], const Ctx& c) { ntt512_forward_small(x, c); }
+    static constexpr bool small_ok(double digit_max) { return digit_max <= 32.0; }
+    static constexpr double spectrum_bound(bool, double) { return 7.23; }      // ntt_wave512.h: inputs far below p, |out| <= 7.22 p
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt512_inverse(x, c); }
 };
 
@@ -409,8 +413,9 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
     using PO = Poly<PS::Nbit>;
     using L = PsbLds<PS>;
     constexpr int N = D::N, R = D::R, K1 = D::K1;
-    constexpr bool kSmallIn = (1 << (PS::Bgbit - 1)) <= 32;
-    constexpr double kSpec = PO::spectrum_bound(kSmallIn);
+    constexpr double kDigitMax = (double)(1u << (PS::Bgbit - 1));
+    constexpr bool kSmallIn = PO::small_ok(kDigitMax);
+    constexpr double kSpec = PO::spectrum_bound(kSmallIn, kDigitMax);
     constexpr double kRowTerm = fpf::after_mulmod_wide(kSpec);
     constexpr bool kAllRowsFit = D::ROWS * kRowTerm < fpf::LIM_WIDE;
     static_assert(kSpec > 0 && kSpec < fpf::LIM_WIDE, "digit spectrum exceeds what the wide product accepts");

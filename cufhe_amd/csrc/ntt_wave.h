@@ -53,7 +53,7 @@ constexpr double forward_digit_spectrum_bound(double digit_max)
 {
     // stages 0 and 1 are one exact radix-4 butterfly on the inputs (ct_four_stages): every partial sum must stay an exact double
     const double s1 = digit_max * (1.0 + fpf::ROOT4 + fpf::ROOT8 + fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8);
-    if (s1 >= 9007199254740992.0 / 1024.0) return -1.0;       // keep 10 bits of headroom below 2^53
+    if (s1 >= 9007199254740992.0 / 64.0) return -1.0;         // every partial sum of the butterfly is below s1: 6 bits of headroom below 2^53 (Bg = 2^10: 2^46.2)
     double b = s1 / fpf::P;                                   // 2^42.2 / p = 0.006 for Bg = 2^6 (0.5 until the second group of stage 1 was made exact)
     for (int s = 2; s <= 8; s++) {                            // stages 2..8: mulmod
         if (b >= fpf::LIM_NARROW) return -1.0;

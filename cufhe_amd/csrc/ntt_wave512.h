@@ -197,6 +197,38 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[kRegs8], const Wave51
     ct_three_stages<true>(x, TwArr{twc});
 }
 
+// The STAND-ALONE 512-point negacyclic transform (tables512[2]: psi_1024 = psi_2048^2, so its first twiddles are root[1] = I,
+// root[2] = zeta, root[3] = zeta^3) of a gadget-digit polynomial, |x| <= 32: stages 0 and 1 as one exact radix-4 butterfly on the
+// inputs a, a', b, b' = elements e, e + 128, e + 256, e + 384 (ntt_wave.h: ct_four_stages<SMALL_IN>; zeta^3 I = -zeta), nine FP64
+// operations per four elements instead of two general butterfly stages (sixteen); every value stays below 2^42.2.
+__device__ __forceinline__ void ntt512_forward_small(double (&x)[kRegs8], const Wave512Ctx& c)
+{
+    constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const double a = x[r], a1 = x[r + 2], b = x[r + 4], b1 = x[r + 6];
+        const double u = __builtin_fma(b, fpf::ROOT4, a), v = __builtin_fma(-b, fpf::ROOT4, a);
+        const double u1 = __builtin_fma(b1, fpf::ROOT4, a1);
+        const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
+        x[r] = __builtin_fma(u1, fpf::ROOT8, u);
+        x[r + 2] = __builtin_fma(-u1, fpf::ROOT8, u);
+        x[r + 4] = v + t;
+        x[r + 6] = v - t;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) ct_bfly<false>(x[2 * g], x[2 * g + 1], c.gt->tu_fwd[3 + g]);
+    double twb[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twb[k] = lds_ld(c.tb_fwd, 64 * k);
+    CUFHE_AMD_XPOSE8(c.a1, 8 * 68, c.b1, 64)          // A -> B
+    ct_three_stages<false>(x, TwArr{twb});
+    double twc[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
+    CUFHE_AMD_XPOSE8(c.b2, 64, c.c2, 8 * 72)          // B -> C
+    ct_three_stages<true>(x, TwArr{twc});
+}
+
 // inverse half transform: x in layout C with |x| <= p/2, out = u_h in layout A, |out| <= p,
 // not scaled (N^-1 is folded into the bootstrapping key)
 __device__ __forceinline__ void ntt512_inverse(double (&x)[kRegs8], const Wave512Ctx& c)
