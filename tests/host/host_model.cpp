@@ -190,7 +190,7 @@ void hm_polymul(uint32_t* res, const int32_t* a, const uint32_t* b, double* stat
     std::vector<double> x(N), y(N);
     for (int i = 0; i < N; i++) { x[i] = (double)a[i]; y[i] = (double)(int32_t)b[i]; }
     bool small = true;
-    for (int i = 0; i < N; i++) small = small && a[i] >= -32 && a[i] <= 32;
+    for (int i = 0; i < N; i++) small = small && a[i] >= -512 && a[i] <= 512;      // gadget digits up to Bg = 2^10 take the exact first stages (kernels_ps.hip.h: small_ok)
     fwd(x.data(), t, stats ? stats + 4 : nullptr, small);
     fwd(y.data(), t, nullptr, false);
     for (int i = 0; i < N; i++) {

@@ -95,6 +95,31 @@ def test_polymul_schedule_random_and_bounds(hm, oracle):
         assert np.array_equal(res, _school(oracle, a, b))
 
 
+def test_exact_radix4_first_stages_up_to_bg_1024(hm, oracle):
+    """The first two forward stages are one exact radix-4 butterfly on the inputs (ntt_wave.h: ct_four_stages<SMALL_IN>, zeta^3 I = -zeta).
+    It stays exact up to digits of Bg = 2^10 (the cggi16 set, kernels_ps.hip.h: |d| (1 + I + zeta + zeta^3) = 2^46.2): every intermediate an
+    integer below 2^53, the identity checked in integer arithmetic by the host model, products == schoolbook -- including the extreme digits."""
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        a = rng.integers(-512, 512, size=ol.N, dtype=np.int32)
+        if trial == 0:
+            a[:] = -512
+        if trial == 1:
+            a[:] = 511
+            a[::3] = -512
+        # the key operand as that set takes it: balanced 16-bit limbs (a whole 32-bit word against Bg = 2^10 digits leaves the exact range)
+        b = rng.integers(-2**15, 2**15, size=ol.N, dtype=np.int64).astype(np.uint32)
+        if trial < 2:
+            b[:] = np.uint32(2**32 - 2**15)
+        res = np.zeros(ol.N, np.uint32)
+        st = np.zeros(24)
+        hm.hm_polymul(res, a, b, st)
+        assert st[0] == 0, "non-integer or out-of-range intermediate"
+        assert st[1] < 10.285 and st[2] < 5.142 and st[3] < 10.285
+        assert st[4] <= 512 * (1 + 29593600 + 5440 + 5440**3) / P + 1e-12 and st[13] < 6.4      # 0.094 p after the butterfly, spectrum below 6.4 p
+        assert np.array_equal(res, _school(oracle, a, b))
+
+
 def test_external_product_worst_case(hm, oracle):
     """All digits -32 against all BK words 0x80000000: coefficient N-1 of every row reaches
     1024*32*2^31, and the six rows add up to the bound 2^48.585 -- still exact."""
