@@ -212,9 +212,8 @@ def valu_block(kernel, rotations, launch_ms, clock_hz):
         "frac_of_fp64_issue": FP64_ISSUE_CYCLES_SPEC * insts / slots,
         "frac_of_measured_issue_floor": FP64_ISSUE_CYCLES_MEASURED * insts / slots,
         "clock_hz_this_run": clock_hz,
-        "clock_note": "the clock of THIS run comes from a short FP64 probe kernel (cufhe_amd_probe_clock); a kernel that drives the chip into its power "
-                      "limit runs below it (blind_rotate_lvl2q_kernel: 2.18 GHz under the profiler against 2.43 probed), and its frac_* here are then "
-                      "understated: pipe_busy_under_profiler is measured with the clock the launch really held",
+        "clock_note": "clock_hz_this_run is read by a short probe kernel (cufhe_amd_probe_clock) running CONCURRENTLY with this workload's launch: "
+                      "the clock the chip holds under that kernel (an idle-chip probe reads 2.43 GHz; a kernel at the power limit runs below it)",
         "clock_hz_under_profiler": facts.get("clock_hz_under_profiler"),
         "pipe_busy_under_profiler": facts.get("valu_pipe_busy"),
         "lds_bank_conflict_frac": facts.get("lds_bank_conflict_frac"),
@@ -408,6 +407,22 @@ def main():
         api.profile_enable(False)
         return (prof.blind_rotate_ms / max(prof.blind_rotate_launches, 1), prof.keyswitch_ms / max(prof.keyswitch_launches, 1))
 
+    clocks = {}
+
+    def clock_during(key, launch, launch_ms=0.0):
+        """The shader clock the chip holds UNDER THIS WORKLOAD: the probe kernel (cufhe_amd_probe_clock: shader cycles over the constant
+        100 MHz counter, ~1 ms of dependent FMAs, no LDS, a handful of registers) is launched on the null stream while the workload's launch
+        runs on its own non-blocking stream, so its waves sit in the register space the big kernel leaves and count the clock that kernel
+        really gets.  A probe on an otherwise idle chip reads 2.43 GHz; under blind_rotate_kernel the chip holds ~2.35, under
+        blind_rotate_lvl2q_kernel ~2.15-2.18 (power): pricing `valu` with the idle figure understates how busy the pipe is."""
+        if key not in clocks:
+            eng.Synchronize()
+            launch()
+            time.sleep(0.4e-3 * launch_ms)          # sample the middle of the launch: its first milliseconds are a power-management transient (1.8 GHz)
+            clocks[key] = api.probe_clock()
+            eng.Synchronize()
+        return clocks[key]
+
     def roofline(workload, br_ms, ks_ms, n=count):
         l2 = workload == "nand_lvl2"
         rotations = n * (2 if workload == "mux" else 1)
@@ -429,18 +444,18 @@ def main():
         if facts:
             r["traffic"] = facts["hbm_bytes_per_rotation"] * rotations
             r["traffic_replayed_from"] = replayed_from(("fetch", "tcc"))
-        r["valu"] = valu_block(kernel, rotations, br_ms, clock_hz)
+        r["valu"] = valu_block(kernel, rotations, br_ms, clock_during("lvl2" if l2 else "batch", lambda: run_step(workload, n), br_ms))
         # the number that says how close the kernel is to what bounds it, next to the accounting fraction
         r["frac_valu_fp64"] = r["valu"].get("frac_of_fp64_issue")
         r["frac_valu_fp64_is"] = ("VALU instructions of the launch (replayed PMC count per rotation) x 4 cycles / SIMD-cycles of the launch "
-                                  "(launch_ms and shader clock measured in THIS run)")
+                                  "(launch_ms from HIP events and the shader clock under this very launch, both measured in THIS run)")
         return {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_valu_fp64", "traffic")} | r
 
     wl = args.workload
     elapsed = distutil.max_over_ranks(timed(wl, args.steps, args.warmup), dist)
     own_s = own["s"]
     br_ms, ks_ms = kernel_times(wl)
-    clock_hz = api.probe_clock()          # shader clock under an FP64 load, this box, this run (prices `valu`)
+    clock_hz = clock_during("lvl2" if wl == "nand_lvl2" else "batch", lambda: run_step(wl), br_ms)      # shader clock under the workload's own launch
     # every rank's own rate, device and launch times, gathered on all ranks (gloo): rank 0 prints them
     reports = distutil.gather_objects({
         "rank": RANK, "local_rank": LOCAL_RANK, "hip_device": DEV, "gpu": identity, "gates_per_step": count,
@@ -575,7 +590,8 @@ def main():
                     mbr = mp.blind_rotate_ms / max(mp.blind_rotate_launches, 1)
                     extra["nand_512"] = {"ms_per_step": mbr + mp.keyswitch_ms / max(mp.keyswitch_launches, 1),
                                          "blind_rotate_launch_ms": mbr, "kernel": "blind_rotate_ll2_kernel", "bound": "valu_fp64",
-                                         "valu": valu_block("blind_rotate_ll2_kernel", 512, mbr, clock_hz)}
+                                         "valu": valu_block("blind_rotate_ll2_kernel", 512, mbr,
+                                                            clock_during("ll2", lambda: [run_step("nand", 512) for _ in range(4)], 4 * mbr))}
                 except Exception as e:
                     extra["nand_512"] = {"error": repr(e)}
                 try:
@@ -644,7 +660,8 @@ def main():
                                        "bound": "valu_fp64",
                                        "note": "the sweep fraction is an accounting figure (SURVEY.md 8d), not a physical bound: the key is served by "
                                                "the XCD L2s, so it may exceed 1; what the kernel runs into is FP64 issue, `valu`",
-                                       "valu": valu_block("blind_rotate_ps_batch_kernel<%s>" % name, count, pbr_ms, clock_hz),
+                                       "valu": valu_block("blind_rotate_ps_batch_kernel<%s>" % name, count, pbr_ms,
+                                                          clock_during("ps_" + name, ps_step, pbr_ms)),
                                        "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, w), got[idx]))}
                     except Exception as e:
                         psets[name] = {"error": repr(e)}
