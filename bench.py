@@ -152,7 +152,7 @@ SIMDS = 1024                              # 256 CUs x 4
 FP64_ISSUE_CYCLES_SPEC = 4.0              # data sheet: 64 lanes over a 16-lane FP64 pipe (78.6 TFLOP/s)
 FP64_ISSUE_CYCLES_MEASURED = 4.34         # tools/ubench/ubench_ilp.hip on MI355X: two waves per SIMD, v_fma_f64 back to back
 # device code AND the host files that decide launch shapes (units per workgroup are part of what the PMC facts assume)
-DEVICE_SOURCES = ("fpfield.h", "ntt_wave.h", "ntt_wave512.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_ll.hip.h",
+DEVICE_SOURCES = ("fpfield.h", "ntt_r4.h", "ntt_wave.h", "ntt_wave512.h", "kernels_common.hip.h", "kernels.hip.h", "kernels_ll.hip.h",
                   "kernels_lvl2.hip.h", "kernels_lvl2q.hip.h", "kernels_ks2.hip.h", "kernels_ps.hip.h", "capi.hip", "lvl2.inc.h", "paramsets.inc.h")
 
 

@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "csrc", "capi.hip")
 # and the N = 512 parameter-set kernel 4 % slower, so it is not a flag for the whole library
 SRC_LL = os.path.join(HERE, "csrc", "kernels_ll.hip")
 LL_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("capi.hip", "kernels_ll.hip", "kernels_common.hip.h", "kernels.hip.h", "kernels_lvl2.hip.h", "kernels_lvl2q.hip.h", "kernels_ks2.hip.h", "kernels_ll.hip.h", "kernels_ps.hip.h", "paramsets.inc.h", "ntt_wave512.h", "lvl2.inc.h", "sched_hip.inc.h", "sched_core.h", "ntt_wave.h", "fpfield.h")] + \
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("capi.hip", "kernels_ll.hip", "kernels_common.hip.h", "kernels.hip.h", "kernels_lvl2.hip.h", "kernels_lvl2q.hip.h", "kernels_ks2.hip.h", "kernels_ll.hip.h", "kernels_ps.hip.h", "paramsets.inc.h", "ntt_wave512.h", "lvl2.inc.h", "sched_hip.inc.h", "sched_core.h", "ntt_wave.h", "ntt_r4.h", "fpfield.h")] + \
        [os.path.join(os.path.dirname(HERE), "include", "cufhe_amd.h")]
 OUT = os.path.join(HERE, "libcufhe_amd.so")
 # -ffp-contract=off: the field arithmetic spells out every fma; nothing may be re-fused

@@ -61,6 +61,7 @@ struct DeviceState {
     bool ntt_ready = false, keys_ready = false;
     int cus = 0;                         // hipDeviceProp_t::multiProcessorCount (launch-shape rules: one grid round = a workgroup per CU)
     NttTables* tables = nullptr;
+    NttTables* tables_r4 = nullptr;      // the same transform's tables for the radix-4 passes (ntt_r4.h): blind_rotate_kernel
     Ntt512Tables* tables512 = nullptr;   // [3]: the two 512-point halves (low-latency kernel), stand-alone N = 512
     double* bk_ntt = nullptr;
     uint32_t* ksk = nullptr;
@@ -151,7 +152,20 @@ double n_inverse_balanced() { return balanced(powmod_u64(kN, fpf::P_U64 - 2)); }
 
 // Device tables of one 1024-point transform from its root arrays, fwd[m + g] / inv[m + g]
 // being the twiddle of group g at the stage with m groups.
-void fill_tables(NttTables& t, const std::vector<double>& fwd, const std::vector<double>& inv)
+// r4: the tables of the radix-4 passes (ntt_r4.h).  A 16-register block uses the twiddles [w | u, I u | w_0..w_3 | u_0, I u_0, ..];
+// the radix-4 butterfly never multiplies by the second twiddle of a fine pair (root[2m + 1] = I root[2m], -I for the inverse)
+// but by the product of the first with the coarse twiddle: slot 2 = u w, slot 8 + 2g = u_g w_g (tc: slot 5 + 2g = u_g w_g).
+double mul_balanced(double a, double b)
+{
+    const uint64_t ua = a < 0 ? fpf::P_U64 - (uint64_t)(-a) : (uint64_t)a, ub = b < 0 ? fpf::P_U64 - (uint64_t)(-b) : (uint64_t)b;
+    return balanced(mulmod_u64(ua, ub));
+}
+void to_r4_block(double* t, int stride)       // t[k * stride], k < 15: one block of four stages
+{
+    t[2 * stride] = mul_balanced(t[1 * stride], t[0]);
+    for (int g = 0; g < 4; g++) t[(8 + 2 * g) * stride] = mul_balanced(t[(7 + 2 * g) * stride], t[(3 + g) * stride]);
+}
+void fill_tables(NttTables& t, const std::vector<double>& fwd, const std::vector<double>& inv, bool r4 = false)
 {
     memset(&t, 0, sizeof(t));
     for (int k = 0; k < 15; k++) {
@@ -173,10 +187,23 @@ void fill_tables(NttTables& t, const std::vector<double>& fwd, const std::vector
             t.tc_fwd[k * 64 + lane] = fwd[idx];
             t.tc_inv[k * 64 + lane] = inv[idx];
         }
+    if (r4) {
+        to_r4_block(t.tu_fwd, 1);
+        to_r4_block(t.tu_inv, 1);
+        for (int lam = 0; lam < 16; lam++) {
+            to_r4_block(t.tb_fwd + lam, 16);
+            to_r4_block(t.tb_inv + lam, 16);
+        }
+        for (int lane = 0; lane < 64; lane++)
+            for (int g = 0; g < 4; g++) {
+                t.tc_fwd[(5 + 2 * g) * 64 + lane] = mul_balanced(t.tc_fwd[(4 + 2 * g) * 64 + lane], t.tc_fwd[g * 64 + lane]);
+                t.tc_inv[(5 + 2 * g) * 64 + lane] = mul_balanced(t.tc_inv[(4 + 2 * g) * 64 + lane], t.tc_inv[g * 64 + lane]);
+            }
+    }
 }
 
 // root[i] = psi^bitrev(i): the reference's table order, src/ntt_gpu/ntt_gpuntt.cu:88-111
-void build_tables(NttTables& t)
+void build_tables(NttTables& t, bool r4 = false)
 {
     std::vector<double> fwd(kN), inv(kN);
     const uint64_t psi = fpf::PSI_2048, psi_inv = powmod_u64(psi, fpf::P_U64 - 2);
@@ -184,7 +211,7 @@ void build_tables(NttTables& t)
         fwd[i] = balanced(powmod_u64(psi, bitrev(i, 10)));
         inv[i] = balanced(powmod_u64(psi_inv, bitrev(i, 10)));
     }
-    fill_tables(t, fwd, inv);
+    fill_tables(t, fwd, inv, r4);
 }
 
 // Tables of one 512-point transform from accessors rf(idx) / ri(idx) = forward / inverse twiddle of
@@ -275,6 +302,7 @@ int ensure_ntt(int device)
     auto undo = [&]() {
         if (s.fault_host) { (void)hipHostFree(s.fault_host); s.fault_host = nullptr; s.fault = nullptr; }
         if (s.tables) { (void)hipFree(s.tables); s.tables = nullptr; }
+        if (s.tables_r4) { (void)hipFree(s.tables_r4); s.tables_r4 = nullptr; }
         if (s.tables512) { (void)hipFree(s.tables512); s.tables512 = nullptr; }
     };
 #define CUFHE_AMD_TRY_UNDO(expr)                                                               \
@@ -292,6 +320,9 @@ int ensure_ntt(int device)
     build_tables(host);
     CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables, sizeof(NttTables)));
     CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables, &host, sizeof(NttTables), hipMemcpyHostToDevice));
+    build_tables(host, true);
+    CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables_r4, sizeof(NttTables)));
+    CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables_r4, &host, sizeof(NttTables), hipMemcpyHostToDevice));
     static Ntt512Tables host512[3];
     build_tables_512(host512);
     CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables512, sizeof(host512)));
@@ -430,7 +461,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     auto launch_batch = [&](const LinDesc* dd, size_t n, int active, uint32_t* dump) {
         const unsigned blocks = (unsigned)((n + active - 1) / active);
         hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, dd, (int)n,
-                           s.bk_ntt, s.tables, steps, dump, active);
+                           s.bk_ntt, s.tables_r4, steps, dump, active);
     };
     // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
     //   low-latency kernel  3.1 (n <= 64), 3.6 / 6.7 / 10.0 / 13.3 / 16.6 per started round of 256 (key switch included)
@@ -877,7 +908,7 @@ int cufhe_amd_cleanup(void)
         if (s.tables2q) HIP_TRY(hipFree(s.tables2q));
         s.keys2_ready = s.br2_lds_opt_in = s.br2q_lds_opt_in = s.ks2_lds_opt_in = false;
         s.tables2 = nullptr; s.tables2q = nullptr; s.bk2_ntt = nullptr; s.bk2q_ntt = nullptr; s.ksk2 = nullptr;
-        if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables512)); }
+        if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables_r4)); HIP_TRY(hipFree(s.tables512)); }
         if (s.fault_host) { (void)hipHostFree(s.fault_host); s.fault_host = nullptr; s.fault = nullptr; }   // the fault, if any, ends with the keys
         for (auto& b : s.staging) { (void)hipEventDestroy(b.done); (void)hipHostFree(b.host); }
         s.staging.clear();
@@ -885,7 +916,7 @@ int cufhe_amd_cleanup(void)
         s.workspaces.clear();
         s.ntt_ready = s.keys_ready = false;
         s.br_lds_opt_in = s.ks_lds_opt_in = false;
-        s.tables = nullptr; s.tables512 = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
+        s.tables = nullptr; s.tables_r4 = nullptr; s.tables512 = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
         s.prof = cufhe_amd_profile{};
     }
     return 0;

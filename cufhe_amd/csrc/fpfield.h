@@ -51,6 +51,7 @@ constexpr double P = 875781160960001.0;
 constexpr double PINV = 0x1.491cc17c934a8p-50;    // fl(1/p)
 constexpr double ROOT4 = 29593600.0;              // I = zeta^2 = psi^512
 constexpr double ROOT8 = 5440.0;                  // zeta = psi^256
+constexpr double INV_ROOT4 = 0x1.22436485a6c7fp-25;   // fl(1/I)
 constexpr double MAGIC0 = 6755399441055744.0;     // 1.5 * 2^52: adding it rounds to an integer
 constexpr double MAGIC1 = 13510798882111488.0;    // 1.5 * 2^53: rounds to an even integer
 
@@ -72,6 +73,37 @@ FPF_HD double mulmod_wide(double a, double w)
     const double q = __builtin_fma(h, PINV, MAGIC1) - MAGIC1;
     const double r = __builtin_fma(-q, P, h);
     return r + l;
+}
+// a*w + c mod p in one reduction (the last product of a sum reduces the whole sum: 8 operations instead of 7 + 3):
+// |a| < 2^52, |w| <= p/2, c any lazy residue with |c| + (0.5 + 0.146 |a|/p) p < 2^53.  The quotient is estimated from the
+// ROUNDED sum h + c (one more rounding than mulmod: 1.5 instead of 1 unit of growth), the remainder taken exactly:
+// |result| <= (0.5 + 0.146 |a|/p) p.
+FPF_HD double mulmod_add(double a, double w, double c)
+{
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_fma(h + c, PINV, MAGIC0) - MAGIC0;
+    const double r = __builtin_fma(-q, P, h);            // exact: |h - q p| <= |c| + |result| + |l| < 2^53, integer
+    return (r + c) + l;
+}
+// Same for |a| < 2^53: |result| <= (1 + 0.146 |a|/p) p
+FPF_HD double mulmod_add_wide(double a, double w, double c)
+{
+    const double h = a * w;
+    const double l = __builtin_fma(a, w, -h);
+    const double q = __builtin_fma(h + c, PINV, MAGIC1) - MAGIC1;
+    const double r = __builtin_fma(-q, P, h);
+    return (r + c) + l;
+}
+// I*x mod p for any |x| < 2^53, I = zeta^2 the fourth root of unity: p = I^2 + 1, so with x = x1 I + x0 (|x0| <= I/2)
+// I x = x1 I^2 + x0 I = x0 I - x1 -- four operations where a general product takes six, and the result is reduced:
+// |result| <= I^2/2 + 2 I + 2^53 / I < (0.5 + 5e-7) p.  This is what makes a radix-4 butterfly (three general products
+// and one by I) cheaper than four radix-2 butterflies (ntt_r4.h).
+FPF_HD double mul_root4(double x)
+{
+    const double x1 = __builtin_fma(x, INV_ROOT4, MAGIC0) - MAGIC0;    // nearest integer to x / I (|x / I| < 2^28.2)
+    const double x0 = __builtin_fma(-x1, ROOT4, x);                    // exact: small integer
+    return __builtin_fma(x0, ROOT4, -x1);                              // exact: |x0 I| < 2^48.7
 }
 // centred residue of any |a| < 2^53: |result| <= p/2 (+1 at a tie)
 FPF_HD double reduce(double a)
@@ -107,5 +139,9 @@ constexpr double LIM_NARROW = 5.142;             // 2^52 / p, rounded down: larg
 constexpr double LIM_WIDE = 10.285;              // 2^53 / p, rounded down: largest |a| for mulmod_wide / any value
 constexpr double after_mulmod(double a) { return 0.5 + GROW * a; }        // |mulmod(a, w)|
 constexpr double after_mulmod_wide(double a) { return 1.0 + GROW * a; }   // |mulmod_wide(a, w)|
+constexpr double GROW_ADD = 0.14585;             // 1.5 p / 2^53, rounded up (mulmod_add: one more rounding in the quotient estimate)
+constexpr double after_mulmod_add(double a) { return 0.5 + GROW_ADD * a; }        // |mulmod_add(a, w, c)|
+constexpr double after_mulmod_add_wide(double a) { return 1.0 + GROW_ADD * a; }   // |mulmod_add_wide(a, w, c)|
+constexpr double AFTER_MUL_ROOT4 = 0.5000005;    // |mul_root4(x)|
 
 }  // namespace fpf

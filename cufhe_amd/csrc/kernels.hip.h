@@ -109,6 +109,47 @@ __device__ __forceinline__ void rotate_sub(uint32_t (&temp)[kRegs], const uint32
 
 // x (spectrum of one digit polynomial, layout C) times the two polynomials of one TRGSW row,
 // read from the row buffer the workgroup staged in LDS: [out<2][q<8][lane<64][2] doubles
+// One product into its accumulator: wide or narrow by the compile-time bound of the spectrum register (ntt_r4.h); LAST:
+// the product that completes the sum reduces it on the way (fpf::mulmod_add: one operation more than a plain product,
+// three fewer than a separate reduction in front of the inverse transform)
+template <class SPEC, int R, bool LAST>
+__device__ __forceinline__ void product_into(double& acc, double x, double w)
+{
+    constexpr bool wide = r4::needs_wide(SPEC::in().v[R]);
+    if constexpr (LAST) acc = wide ? fpf::mulmod_add_wide(x, w, acc) : fpf::mulmod_add(x, w, acc);
+    else acc += wide ? fpf::mulmod_wide(x, w) : fpf::mulmod(x, w);
+}
+template <class SPEC, bool LAST, int Q>
+__device__ __forceinline__ void pointwise_piece(double (&A0)[kRegs], double (&A1)[kRegs], const double (&x)[kRegs], const double2& b)
+{
+    if constexpr (Q < 8) {
+        product_into<SPEC, 2 * Q, LAST>(A0[2 * Q], x[2 * Q], b.x);
+        product_into<SPEC, 2 * Q + 1, LAST>(A0[2 * Q + 1], x[2 * Q + 1], b.y);
+    } else {
+        product_into<SPEC, 2 * (Q - 8), LAST>(A1[2 * (Q - 8)], x[2 * (Q - 8)], b.x);
+        product_into<SPEC, 2 * (Q - 8) + 1, LAST>(A1[2 * (Q - 8) + 1], x[2 * (Q - 8) + 1], b.y);
+    }
+}
+template <class SPEC, bool LAST, int Q = 0>
+__device__ __forceinline__ void pointwise_pieces(double (&A0)[kRegs], double (&A1)[kRegs], const double (&x)[kRegs],
+                                                 double2 (&b)[16], const char* row_lane)
+{
+    // Software pipeline, pinned: the ds_read_b128 of piece q+D is issued before the products of
+    // piece q (hipcc otherwise sinks every read to its use and waits for it there).  The
+    // sched_barrier lets VALU/SALU instructions float but keeps DS reads on their side.
+#ifndef CUFHE_AMD_BK_DEPTH
+#define CUFHE_AMD_BK_DEPTH 3
+#endif
+    constexpr int D = CUFHE_AMD_BK_DEPTH;
+    if constexpr (Q < 16) {
+        if constexpr (Q + D < 16) b[Q + D] = *(const double2*)(row_lane + (Q + D) * 1024);
+        __builtin_amdgcn_sched_barrier(0x0006);
+        pointwise_piece<SPEC, LAST, Q>(A0, A1, x, b[Q]);
+        __builtin_amdgcn_sched_barrier(0x0006);
+        pointwise_pieces<SPEC, LAST, Q + 1>(A0, A1, x, b, row_lane);
+    }
+}
+template <class SPEC, bool LAST>
 __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double (&A1)[kRegs],
                                                      const double (&x)[kRegs], const char* row_lane)
 {
@@ -123,29 +164,11 @@ __device__ __forceinline__ void pointwise_accumulate(double (&A0)[kRegs], double
     (void)row_lane;
     return;
 #endif
-    // Software pipeline, pinned: the ds_read_b128 of piece q+2 is issued before the products of
-    // piece q (hipcc otherwise sinks every read to its use and waits for it there).  The
-    // sched_barrier lets VALU/SALU instructions float but keeps DS reads on their side.
-#ifndef CUFHE_AMD_BK_DEPTH
-#define CUFHE_AMD_BK_DEPTH 3
-#endif
     constexpr int D = CUFHE_AMD_BK_DEPTH;
     double2 b[16];
 #pragma unroll
     for (int q = 0; q < D; q++) b[q] = *(const double2*)(row_lane + q * 1024);
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        if (q + D < 16) b[q + D] = *(const double2*)(row_lane + (q + D) * 1024);
-        __builtin_amdgcn_sched_barrier(0x0006);
-        if (q < 8) {
-            A0[2 * q] += fpf::mulmod_wide(x[2 * q], b[q].x);
-            A0[2 * q + 1] += fpf::mulmod_wide(x[2 * q + 1], b[q].y);
-        } else {
-            A1[2 * (q - 8)] += fpf::mulmod_wide(x[2 * (q - 8)], b[q].x);
-            A1[2 * (q - 8) + 1] += fpf::mulmod_wide(x[2 * (q - 8) + 1], b[q].y);
-        }
-        __builtin_amdgcn_sched_barrier(0x0006);
-    }
+    pointwise_pieces<SPEC, LAST>(A0, A1, x, b, row_lane);
 }
 
 // The workgroup's row pipeline.  Row R (0 .. 6*steps-1) of the bootstrapping key is the
@@ -201,13 +224,23 @@ struct RowPipe {
     }
 };
 
+// The schedule of the step (ntt_r4.h): spectrum of a digit polynomial, the (k+1) l products per accumulator the last of
+// which reduces the sum, the inverse transform of that
+using BrSpectrum = r4::FwdDigits<(1 << (kBgbit - 1))>::Spectrum;
+using BrSums = r4::PointwiseSum<BrSpectrum, kBkRows, true>;
+using BrInverse = r4::Inverse<BrSums>;
+static_assert(r4::valid(BrSpectrum::in()) && r4::valid(BrSums::in()) && r4::valid(BrInverse::Out::in()),
+              "blind_rotate_kernel: the lazy-reduction schedule of the CMux step exceeds the FP64 mantissa");
+
 // one component j: rotate/subtract/decompose, then l forward NTTs, each multiplied into
-// both accumulators (include/gatebootstrapping_gpu.cuh:153-224)
+// both accumulators (include/gatebootstrapping_gpu.cuh:153-224).  LAST_COMPONENT: its last row completes both sums.
+template <bool LAST_COMPONENT>
 __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)[kRegs],
                                                const uint32_t (&accj)[kRegs], const WaveCtx& ctx,
                                                char* tile, int lane, uint32_t abar,
                                                const RowPipe& pipe, int first_row CUFHE_AMD_DIAG_ARG)
 {
+    constexpr int kDigitMax = 1 << (kBgbit - 1);
     uint32_t temp[kRegs];
     rotate_sub(temp, accj, tile, lane, abar);
 #pragma unroll 1
@@ -217,21 +250,19 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
-        ntt_forward_a<true>(x, ctx);
+        ntt_forward_digits_a_r4<kDigitMax>(x, ctx);
         if (pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
-        ntt_forward_bc<false>(x, ctx);
+        ntt_forward_digits_bc_r4<kDigitMax>(x, ctx);
         if (!pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
-        pointwise_accumulate(A0, A1, x, pipe.row(first_row + d));
+        if (LAST_COMPONENT && d == kL - 1) pointwise_accumulate<BrSpectrum, true>(A0, A1, x, pipe.row(first_row + d));
+        else pointwise_accumulate<BrSpectrum, false>(A0, A1, x, pipe.row(first_row + d));
     }
 }
 
 __device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&accj)[kRegs], const WaveCtx& ctx)
 {
-#pragma unroll
-    for (int r = 0; r < kRegs; r++) A[r] = fpf::reduce(A[r]);
-    ntt_inverse(A, ctx);
-#pragma unroll
-    for (int r = 0; r < kRegs; r++) accj[r] += fpf::lift_u32_small(A[r]);   // centred lift, :258-281 (|A| <= 2 p here)
+    ntt_inverse_r4<BrSums>(A, ctx);
+    lift_add<BrInverse::Out>(accj, A);           // centred lift, :258-281
 }
 
 // descs[count]: in0/in1 are lvl0 TLWEs, out is a lvl1 TLWE (N+1 words, sample extract at
@@ -301,9 +332,9 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
         double A0[kRegs], A1[kRegs];
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
-        // six wide products of at most 1.702 p each: 10.21 p < 2^53, no reduction in between
-        cmux_component(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows CUFHE_AMD_DIAG_PASS);
-        cmux_component(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL CUFHE_AMD_DIAG_PASS);
+        // six products per accumulator, the last one reducing the sum (BrSums)
+        cmux_component<false>(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows CUFHE_AMD_DIAG_PASS);
+        cmux_component<true>(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL CUFHE_AMD_DIAG_PASS);
         inverse_and_add(A0, acc0, ctx);
         inverse_and_add(A1, acc1, ctx);
     }

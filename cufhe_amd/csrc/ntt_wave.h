@@ -35,6 +35,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fpfield.h"
+#include "ntt_r4.h"
 
 namespace cufhe_amd {
 
@@ -218,6 +219,23 @@ __device__ __forceinline__ void ct_bfly_exact(double& a, double& b, double w)
     b = __builtin_fma(-v, w, u);
 }
 
+// Stages 0 and 1 of a polynomial of small integers (gadget digits) as one exact radix-4 butterfly, see ct_four_stages<SMALL_IN>
+__device__ __forceinline__ void ct_exact_first_two(double (&x)[kRegs])
+{
+    constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;          // zeta^3 = 160 989 184 000, exact
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double a = x[r], a1 = x[r + 4], b = x[r + 8], b1 = x[r + 12];
+        const double u = __builtin_fma(b, fpf::ROOT4, a), v = __builtin_fma(-b, fpf::ROOT4, a);
+        const double u1 = __builtin_fma(b1, fpf::ROOT4, a1);
+        const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
+        x[r] = __builtin_fma(u1, fpf::ROOT8, u);
+        x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
+        x[r + 8] = v + t;
+        x[r + 12] = v - t;
+    }
+}
+
 // SMALL_IN: |x| <= 32 on entry and the twiddles are those of stages 0-3 (tw(0) = I,
 // tw(1) = zeta): stage 0 and the first group of stage 1 use ct_bfly_exact.
 // EXACT0 (with SMALL_IN false): stage 0 multiplies by a root so small -- tw(0) = zeta, 13 bits, against inputs below
@@ -233,18 +251,7 @@ __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
         //                       = v +- (zeta^3 a' + zeta b')          zeta^3 I = zeta^5 = -zeta, so it only ever meets an input, not a product
         // Nine exact FP64 operations per four elements (round 1-3: fourteen, the second group through a modular product); every
         // value stays below |x| (1 + I + zeta + zeta^3) = 2^42.2 for gadget digits.
-        constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;          // zeta^3 = 160 989 184 000, exact
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double a = x[r], a1 = x[r + 4], b = x[r + 8], b1 = x[r + 12];
-            const double u = __builtin_fma(b, fpf::ROOT4, a), v = __builtin_fma(-b, fpf::ROOT4, a);
-            const double u1 = __builtin_fma(b1, fpf::ROOT4, a1);
-            const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
-            x[r] = __builtin_fma(u1, fpf::ROOT8, u);
-            x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
-            x[r + 8] = v + t;
-            x[r + 12] = v - t;
-        }
+        ct_exact_first_two(x);
     } else {
         const double w0 = tw(0);
 #pragma unroll
@@ -577,6 +584,74 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c
 #pragma unroll
     for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
     ntt_inverse_twc<HALF_TILE, TU_LDS>(x, c, twc);
+}
+
+
+// ==================================================================================================================
+// Radix-4 transforms (ntt_r4.h) on the r4 twiddle tables (capi.hip: fill_tables(..., r4 = true)): the same layouts,
+// layout changes and twiddle fetch placement as above, 30 instead of 32 operations per four elements and two stages,
+// and reductions only on the registers whose compile-time bound asks for one.
+// ==================================================================================================================
+
+template <int DIGIT_MAX>
+__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c)
+{
+    ct_exact_first_two(x);
+    r4::ct_pass_lo<typename r4::FwdDigits<DIGIT_MAX>::A0, 3, 7>(x, TwUniform{c.gt->tu_fwd});
+}
+template <int DIGIT_MAX, bool HALF_TILE = false>
+__device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], const WaveCtx& c)
+{
+    using F = r4::FwdDigits<DIGIT_MAX>;
+    static_assert(r4::valid(F::Spectrum::in()), "radix-4 forward transform of gadget digits: a value exceeds 2^53");
+    double twb[kTbCount];
+#pragma unroll
+    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_fwd, 128 * k);
+    if (HALF_TILE) xpose_half_tile<true>(x, c.a66, c.b66);
+    else CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
+    r4::ct_pass_hi<typename F::B0>(x, TwArr{twb});
+    r4::ct_pass_lo<typename F::B1, 3, 7>(x, TwArr{twb});
+    double twc[kTcCount];
+#pragma unroll
+    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
+    xpose_bc_permlane(x);                            // B -> C in registers
+    r4::reduce_mask<F::kReduceC>(x);
+    r4::ct_pass_lo<typename F::C1, 0, 4>(x, TwArr{twc});
+}
+
+template <class S0, bool HALF_TILE = false>
+__device__ __forceinline__ void ntt_inverse_r4(double (&x)[kRegs], const WaveCtx& c)
+{
+    using V = r4::Inverse<S0>;
+    static_assert(r4::valid(V::Out::in()), "radix-4 inverse transform: a value exceeds 2^53");
+    double twc[kTcCount];
+#pragma unroll
+    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
+    r4::gs_pass_lo<S0, 0, 4>(x, TwArr{twc});
+    r4::reduce_above<typename V::C1, V::kLimit>(x);
+    double twb[kTbCount];
+#pragma unroll
+    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_inv, 128 * k);
+    xpose_cb_permlane(x);                            // C -> B in registers
+    r4::gs_pass_lo<typename V::B0, 3, 7>(x, TwArr{twb});
+    r4::reduce_above<r4::AfterGs<typename V::B0, false>, V::kLimit>(x);
+    r4::gs_pass_hi<typename V::B1>(x, TwArr{twb});
+    r4::reduce_above<r4::AfterGs<typename V::B1, true>, V::kLimit>(x);
+    if (HALF_TILE) xpose_half_tile<false>(x, c.a65, c.b65);
+    else CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
+    r4::gs_pass_lo<typename V::A0, 3, 7>(x, TwUniform{c.gt->tu_inv});
+    r4::reduce_above<r4::AfterGs<typename V::A0, false>, V::kLimit>(x);
+    r4::gs_pass_hi<typename V::A1>(x, TwUniform{c.gt->tu_inv});
+}
+// acc[r] += torus word of x[r] (the centred lift), the cheaper lift where the register's bound allows it
+template <class OUT, int R = 0>
+__device__ __forceinline__ void lift_add(uint32_t (&acc)[kRegs], const double (&x)[kRegs])
+{
+    if constexpr (R < kRegs) {
+        if constexpr (OUT::in().v[R] < 2.57) acc[R] += fpf::lift_u32_small(x[R]);
+        else acc[R] += fpf::lift_u32(x[R]);
+        lift_add<OUT, R + 1>(acc, x);
+    }
 }
 
 }  // namespace cufhe_amd

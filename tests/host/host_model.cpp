@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../cufhe_amd/csrc/fpfield.h"
+#include "../../cufhe_amd/csrc/ntt_r4.h"
 
 namespace {
 typedef unsigned __int128 u128;
@@ -144,6 +145,155 @@ void inv(double* x, Track& t, double* stage_max)
     }
 }
 }  // namespace
+
+
+// ---- radix-4 schedule (cufhe_amd/csrc/ntt_r4.h, ntt_wave.h: ntt_forward_digits_*_r4 / ntt_inverse_r4) ----------------
+// The pass functions are the device's own (ntt_r4.h is host-callable); what is emulated here are the 64 lanes and the three
+// register layouts of ntt_wave.h, element index e = position in the in-place array:
+//   A: lane = e[5:0], reg = e[9:6]     B: lane = e[9:6] | e[1:0] << 4, reg = e[5:2]     C: lane = e[9:6] | e[5:4] << 4, reg = e[3:0]
+// After every pass each value must be an integer below 2^53 AND below the compile-time bound of its register (Sched::in()).
+namespace r4m {
+using namespace cufhe_amd::r4;
+int elem(char layout, int lane, int reg)
+{
+    const int lam = lane & 15, hi = lane >> 4;
+    if (layout == 'A') return lane | reg << 6;
+    if (layout == 'B') return lam << 6 | reg << 2 | hi;
+    return lam << 6 | hi << 4 | reg;
+}
+// r4 tables, written down from the index formulas of capi.hip (fill_tables) independently of that code
+double mulb(double a, double b)
+{
+    const uint64_t ua = a < 0 ? P - (uint64_t)(-a) : (uint64_t)a, ub = b < 0 ? P - (uint64_t)(-b) : (uint64_t)b;
+    return bal(mulmod_u(ua, ub));
+}
+struct Block { double t[15]; double operator()(int k) const { return t[k]; } };
+Block block_r4(const std::vector<double>& root, int base, int lam)     // radix-2 block: root[base * 2^lvl + lam * 2^lvl + j]
+{
+    Block b;
+    for (int k = 0; k < 15; k++) {
+        int lvl = 0;
+        while ((2 << lvl) <= k + 1) lvl++;
+        b.t[k] = root[(base << lvl) + (lam << lvl) + (k + 1 - (1 << lvl))];
+    }
+    b.t[2] = mulb(b.t[1], b.t[0]);
+    for (int g = 0; g < 4; g++) b.t[8 + 2 * g] = mulb(b.t[7 + 2 * g], b.t[3 + g]);
+    return b;
+}
+struct BlockC { double t[12]; double operator()(int k) const { return t[k]; } };
+BlockC block_c_r4(const std::vector<double>& root, int lane)
+{
+    BlockC b;
+    const int lam = lane & 15, h = lane >> 4;
+    for (int k = 0; k < 12; k++) b.t[k] = k < 4 ? root[256 + ((lam << 4) | (h << 2) | k)] : root[512 + ((lam << 5) | (h << 3) | (k - 4))];
+    for (int g = 0; g < 4; g++) b.t[5 + 2 * g] = mulb(b.t[4 + 2 * g], b.t[g]);
+    return b;
+}
+struct Check {
+    int bad = 0;
+    double worst = 0;       // largest value / (bound of its register)
+    template <class S>
+    void regs(const double (&x)[16])
+    {
+        constexpr RegBounds b = S::in();
+        for (int r = 0; r < 16; r++) {
+            const double a = std::fabs(x[r]);
+            if (a >= 9007199254740992.0 || x[r] != std::nearbyint(x[r])) bad++;
+            if (a > b.v[r] * fpf::P) bad++;
+            if (a / (b.v[r] * fpf::P) > worst) worst = a / (b.v[r] * fpf::P);
+        }
+    }
+};
+template <class F>
+void per_lane(double* X, char layout, F f)
+{
+    for (int lane = 0; lane < 64; lane++) {
+        double x[16];
+        for (int r = 0; r < 16; r++) x[r] = X[elem(layout, lane, r)];
+        f(x, lane);
+        for (int r = 0; r < 16; r++) X[elem(layout, lane, r)] = x[r];
+    }
+}
+template <int DIGIT_MAX>
+void forward_digits(double* X, Check& ck)
+{
+    using F = FwdDigits<DIGIT_MAX>;
+    static_assert(valid(F::Spectrum::in()), "forward schedule");
+    const double Z3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
+    per_lane(X, 'A', [&](double (&x)[16], int) {
+        for (int r = 0; r < 4; r++) {            // ct_exact_first_two
+            const double a = x[r], a1 = x[r + 4], b = x[r + 8], b1 = x[r + 12];
+            const double u = std::fma(b, fpf::ROOT4, a), v = std::fma(-b, fpf::ROOT4, a);
+            const double u1 = std::fma(b1, fpf::ROOT4, a1);
+            const double t = std::fma(a1, Z3, b1 * fpf::ROOT8);
+            x[r] = std::fma(u1, fpf::ROOT8, u); x[r + 4] = std::fma(-u1, fpf::ROOT8, u); x[r + 8] = v + t; x[r + 12] = v - t;
+        }
+        ck.regs<typename F::A0>(x);
+        ct_pass_lo<typename F::A0, 3, 7>(x, block_r4(g_fwd, 1, 0));
+        ck.regs<AfterCt<typename F::A0, false>>(x);
+    });
+    per_lane(X, 'B', [&](double (&x)[16], int lane) {
+        const Block tw = block_r4(g_fwd, 16, lane & 15);
+        ck.regs<typename F::B0>(x);
+        ct_pass_hi<typename F::B0>(x, tw);
+        ck.regs<typename F::B1>(x);
+        ct_pass_lo<typename F::B1, 3, 7>(x, tw);
+        ck.regs<AfterCt<typename F::B1, false>>(x);
+    });
+    per_lane(X, 'C', [&](double (&x)[16], int lane) {
+        ck.regs<typename F::C0>(x);
+        reduce_mask<F::kReduceC>(x);
+        ck.regs<typename F::C1>(x);
+        ct_pass_lo<typename F::C1, 0, 4>(x, block_c_r4(g_fwd, lane));
+        ck.regs<typename F::Spectrum>(x);
+    });
+}
+template <class S0>
+void inverse(double* X, Check& ck)
+{
+    using V = Inverse<S0>;
+    static_assert(valid(V::Out::in()), "inverse schedule");
+    per_lane(X, 'C', [&](double (&x)[16], int lane) {
+        ck.regs<S0>(x);
+        gs_pass_lo<S0, 0, 4>(x, block_c_r4(g_inv, lane));
+        ck.regs<typename V::C1>(x);
+        reduce_above<typename V::C1, V::kLimit>(x);
+    });
+    per_lane(X, 'B', [&](double (&x)[16], int lane) {
+        const Block tw = block_r4(g_inv, 16, lane & 15);
+        ck.regs<typename V::B0>(x);
+        gs_pass_lo<typename V::B0, 3, 7>(x, tw);
+        ck.regs<AfterGs<typename V::B0, false>>(x);
+        reduce_above<AfterGs<typename V::B0, false>, V::kLimit>(x);
+        ck.regs<typename V::B1>(x);
+        gs_pass_hi<typename V::B1>(x, tw);
+        ck.regs<AfterGs<typename V::B1, true>>(x);
+        reduce_above<AfterGs<typename V::B1, true>, V::kLimit>(x);
+        ck.regs<typename V::B2>(x);
+    });
+    per_lane(X, 'A', [&](double (&x)[16], int) {
+        const Block tw = block_r4(g_inv, 1, 0);
+        ck.regs<typename V::A0>(x);
+        gs_pass_lo<typename V::A0, 3, 7>(x, tw);
+        ck.regs<AfterGs<typename V::A0, false>>(x);
+        reduce_above<AfterGs<typename V::A0, false>, V::kLimit>(x);
+        ck.regs<typename V::A1>(x);
+        gs_pass_hi<typename V::A1>(x, tw);
+        ck.regs<typename V::Out>(x);
+    });
+}
+// the lift blind_rotate_kernel's lift_add picks per register (layout A: reg = e >> 6)
+template <class OUT>
+uint32_t lift(double v, int reg, Check& ck)
+{
+    constexpr RegBounds b = OUT::in();
+    if (b.v[reg] < 2.57) {
+        if (std::fabs(v) >= 2251799813685248.0) ck.bad++;
+        return fpf::lift_u32_small(v);
+    }
+    return fpf::lift_u32(v);
+}
+}  // namespace r4m
 
 extern "C" {
 
@@ -311,6 +461,78 @@ void hm_external_product_split(uint32_t* out, const int32_t* dig, const uint32_t
         }
     }
     if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
+}
+
+// One external product with the schedule of blind_rotate_kernel since round 5 (radix-4 passes, per-register bounds, the last
+// product of each sum reducing it): same interface as hm_external_product; stats[4] = largest value / its register's
+// compile-time bound (must stay <= 1), stats[5..20] = the spectrum bound per layout-C register, stats[21..36] = the inverse's
+// output bound per layout-A register.
+void hm_external_product_r4(uint32_t* out, const int32_t* dig, const uint32_t* bk, double* stats)
+{
+    using namespace r4m;
+    tables();
+    Track t;
+    Check ck;
+    constexpr int kDigitMax = 32;
+    using Spec = FwdDigits<kDigitMax>::Spectrum;
+    using Sums = PointwiseSum<Spec, 6, true>;
+    using Out = Inverse<Sums>::Out;
+    constexpr RegBounds sb = Spec::in();
+    std::vector<double> A0(N, 0.0), A1(N, 0.0), x(N), y0(N), y1(N);
+    for (int row = 0; row < 6; row++) {
+        for (int i = 0; i < N; i++) {
+            x[i] = (double)dig[row * N + i];
+            if (std::abs(dig[row * N + i]) > kDigitMax) ck.bad++;
+            y0[i] = (double)(int32_t)bk[(row * 2 + 0) * N + i];
+            y1[i] = (double)(int32_t)bk[(row * 2 + 1) * N + i];
+        }
+        forward_digits<kDigitMax>(x.data(), ck);
+        fwd(y0.data(), t, nullptr, false); fwd(y1.data(), t, nullptr, false);      // the key is still converted by the radix-2 transform
+        for (int i = 0; i < N; i++) {
+            y0[i] = fpf::reduce(mm(y0[i], g_ninv, true, t));
+            y1[i] = fpf::reduce(mm(y1[i], g_ninv, true, t));
+            const bool wide = needs_wide(sb.v[i & 15]);                             // layout C: reg = e[3:0]
+            if (row == 5) {
+                A0[i] = wide ? fpf::mulmod_add_wide(x[i], y0[i], A0[i]) : fpf::mulmod_add(x[i], y0[i], A0[i]);
+                A1[i] = wide ? fpf::mulmod_add_wide(x[i], y1[i], A1[i]) : fpf::mulmod_add(x[i], y1[i], A1[i]);
+            } else {
+                A0[i] += wide ? fpf::mulmod_wide(x[i], y0[i]) : fpf::mulmod(x[i], y0[i]);
+                A1[i] += wide ? fpf::mulmod_wide(x[i], y1[i]) : fpf::mulmod(x[i], y1[i]);
+            }
+            t.val(A0[i]); t.val(A1[i]);
+        }
+    }
+    inverse<Sums>(A0.data(), ck); inverse<Sums>(A1.data(), ck);
+    for (int i = 0; i < N; i++) { out[i] = lift<Out>(A0[i], i >> 6, ck); out[N + i] = lift<Out>(A1[i], i >> 6, ck); }
+    if (stats) {
+        stats[0] = t.bad + ck.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; stats[4] = ck.worst;
+        constexpr RegBounds ob = Out::in();
+        for (int r = 0; r < 16; r++) { stats[5 + r] = sb.v[r]; stats[21 + r] = ob.v[r]; }
+    }
+}
+// scalar checks of the two new field operations against exact arithmetic: returns the number of violations
+int hm_check_mul_root4(const double* a, int count)
+{
+    int bad = 0;
+    for (int i = 0; i < count; i++) {
+        const double r = fpf::mul_root4(a[i]);
+        const __int128 diff = (__int128)(int64_t)a[i] * (int64_t)fpf::ROOT4 - (__int128)(int64_t)r;
+        if (diff % (__int128)P != 0) bad++;
+        if (std::fabs(r) > fpf::AFTER_MUL_ROOT4 * fpf::P || r != std::nearbyint(r)) bad++;
+    }
+    return bad;
+}
+int hm_check_mulmod_add(const double* a, const double* w, const double* c, int count, int wide)
+{
+    int bad = 0;
+    for (int i = 0; i < count; i++) {
+        const double r = wide ? fpf::mulmod_add_wide(a[i], w[i], c[i]) : fpf::mulmod_add(a[i], w[i], c[i]);
+        const __int128 diff = (__int128)(int64_t)a[i] * (int64_t)w[i] + (__int128)(int64_t)c[i] - (__int128)(int64_t)r;
+        if (diff % (__int128)P != 0) bad++;
+        const double bound = (wide ? 1.0 : 0.5) + fpf::GROW_ADD * std::fabs(a[i]) / fpf::P + 1e-9;
+        if (std::fabs(r) > bound * fpf::P || r != std::nearbyint(r)) bad++;
+    }
+    return bad;
 }
 
 double hm_p(void) { return fpf::P; }

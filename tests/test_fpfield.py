@@ -21,9 +21,9 @@ P = 875781160960001
 
 @pytest.fixture(scope="module")
 def hm():
-    deps = [SRC, os.path.join(ol.ROOT, "cufhe_amd", "csrc", "fpfield.h")]
+    deps = [SRC, os.path.join(ol.ROOT, "cufhe_amd", "csrc", "fpfield.h"), os.path.join(ol.ROOT, "cufhe_amd", "csrc", "ntt_r4.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB, SRC])
     L = ctypes.CDLL(LIB)
     f64 = np.ctypeslib.ndpointer(np.float64, flags="C")
     L.hm_check_mulmod.argtypes = [f64, f64, ctypes.c_int, ctypes.c_int]
@@ -33,6 +33,9 @@ def hm():
     L.hm_polymul.argtypes = [u32, i32, u32, f64]
     L.hm_external_product.argtypes = [u32, i32, u32, f64]
     L.hm_external_product_split.argtypes = [u32, i32, u32, f64]
+    L.hm_external_product_r4.argtypes = [u32, i32, u32, f64]
+    L.hm_check_mul_root4.argtypes = [f64, ctypes.c_int]
+    L.hm_check_mulmod_add.argtypes = [f64, f64, f64, ctypes.c_int, ctypes.c_int]
     L.hm_p.restype = ctypes.c_double
     return L
 
@@ -169,6 +172,62 @@ def test_split_transform_schedule(hm, oracle):
         hm.hm_external_product_split(out, dig.ravel(), bk.ravel(), st)
         hm.hm_external_product(ref, dig.ravel(), bk.ravel(), np.zeros(4))
         assert st[0] == 0 and st[1] < 10.285 and st[2] < 5.142 and st[3] < 10.285, st
+        assert np.array_equal(out, ref)
+        want = np.zeros(ol.N, np.uint32)
+        for row in range(6):
+            want += _school(oracle, dig[row], bk[row, 0])
+        assert np.array_equal(out[:ol.N], want)
+
+
+def test_mul_root4_exact_and_bounded(hm):
+    """fpf::mul_root4: I x mod p in four operations (p = I^2 + 1), any |x| < 2^53 in, |result| <= (0.5 + 5e-7) p."""
+    rng = np.random.default_rng(21)
+    a = rng.integers(-(2**53 - 1), 2**53, size=200000).astype(np.float64)
+    I = 29593600
+    a[:12] = [0, 1, -1, I, -I, I // 2, I // 2 + 1, -(I // 2) - 1, 2**53 - 1, -(2**53 - 1), P // 2, -(P // 2)]
+    # ties of the quotient rounding: x = (2k + 1) I / 2
+    a[12:20] = [(2 * k + 1) * I // 2 for k in (0, 1, 5, 1000, 2**27, -1, -6, -2**27)]
+    assert hm.hm_check_mul_root4(a, a.size) == 0
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+def test_mulmod_add_exact_and_bounded(hm, wide):
+    """fpf::mulmod_add(_wide): a w + c reduced in one step; c up to what five earlier products can have left."""
+    rng = np.random.default_rng(23 + wide)
+    count = 200000
+    lim = (2**53 if wide else 2**52) - 1
+    a = rng.integers(-lim, lim + 1, size=count).astype(np.float64)
+    w = rng.integers(-(P // 2), P // 2 + 1, size=count).astype(np.float64)
+    cmax = int((10.285 - (1.0 if wide else 0.5) - 0.14585 * (lim / P) - 0.01) * P)
+    c = rng.integers(-cmax, cmax + 1, size=count).astype(np.float64)
+    a[:8] = [lim, -lim, lim, -lim, 0, 1, -1, lim]
+    w[:8] = [P // 2, P // 2, -(P // 2), -(P // 2), P // 2, P // 2, -(P // 2), 1]
+    c[:8] = [cmax, cmax, -cmax, cmax, cmax, -cmax, 0, cmax]
+    assert hm.hm_check_mulmod_add(a, w, c, count, wide) == 0
+
+
+def test_radix4_schedule_worst_case_and_random(hm, oracle):
+    """The schedule of blind_rotate_kernel (ntt_r4.h: radix-4 passes, per-register compile-time bounds, reductions only on the
+    registers that need one, the last product of a sum reducing it), run by the device's own pass functions on 64 emulated lanes:
+    every value an integer below 2^53 and below the bound of its register, words == the radix-2 schedule == schoolbook --
+    for the worst case (all digits -32 against all key words 0x80000000: the sum reaches the exactness bound) and random inputs."""
+    rng = np.random.default_rng(12)
+    cases = [(np.full((6, ol.N), -32, np.int32), np.full((6, 2, ol.N), 0x80000000, np.uint32)),
+             (np.full((6, ol.N), 31, np.int32), np.full((6, 2, ol.N), 0x7fffffff, np.uint32))]
+    alt = np.full((6, ol.N), -32, np.int32)
+    alt[:, ::2] = 31
+    cases.append((alt, np.full((6, 2, ol.N), 0x80000000, np.uint32)))
+    for _ in range(4):
+        cases.append((rng.integers(-32, 32, size=(6, ol.N), dtype=np.int32),
+                      rng.integers(0, 2**32, size=(6, 2, ol.N), dtype=np.uint64).astype(np.uint32)))
+    for dig, bk in cases:
+        out = np.zeros(2 * ol.N, np.uint32)
+        ref = np.zeros(2 * ol.N, np.uint32)
+        st = np.zeros(40)
+        hm.hm_external_product_r4(out, dig.ravel(), bk.ravel(), st)
+        hm.hm_external_product(ref, dig.ravel(), bk.ravel(), np.zeros(4))
+        assert st[0] == 0 and st[1] < 10.285 and st[4] <= 1.0, st[:5]
+        assert st[5:21].max() < 5.3 and st[21:37].max() < 10.285       # spectrum bound per register; inverse output bound
         assert np.array_equal(out, ref)
         want = np.zeros(ol.N, np.uint32)
         for row in range(6):
