@@ -199,6 +199,17 @@ void fill_tables(NttTables& t, const std::vector<double>& fwd, const std::vector
                 t.tc_fwd[(5 + 2 * g) * 64 + lane] = mul_balanced(t.tc_fwd[(4 + 2 * g) * 64 + lane], t.tc_fwd[g * 64 + lane]);
                 t.tc_inv[(5 + 2 * g) * 64 + lane] = mul_balanced(t.tc_inv[(4 + 2 * g) * 64 + lane], t.tc_inv[g * 64 + lane]);
             }
+        // packed per lane (ntt_wave.h: NttTables::tbp_fwd ..)
+        for (int lam = 0; lam < 16; lam++)
+            for (int k = 0; k < kTbCount; k++) {
+                t.tbp_fwd[lam * kTbpStride + k] = t.tb_fwd[k * 16 + lam];
+                t.tbp_inv[lam * kTbpStride + k] = t.tb_inv[k * 16 + lam];
+            }
+        for (int lane = 0; lane < 64; lane++)
+            for (int k = 0; k < kTcCount; k++) {
+                t.tcp_fwd[lane * kTcpStride + k] = t.tc_fwd[k * 64 + lane];
+                t.tcp_inv[lane * kTcpStride + k] = t.tc_inv[k * 64 + lane];
+            }
     }
 }
 

@@ -32,7 +32,7 @@
 // compute WRONG words.  They are honoured only in a diagnostic build, which cufhe_amd/build.py
 // --diagnostic writes to libcufhe_amd_diag.so so that it can never be mistaken for the product.
 #if (defined(CUFHE_AMD_ABL_NO_TW) || defined(CUFHE_AMD_ABL_NO_XPOSE) || defined(CUFHE_AMD_ABL_NO_BK) || \
-     defined(CUFHE_AMD_ABL_BK0) || defined(CUFHE_AMD_ABL_PHASES) || defined(CUFHE_AMD_ABL_LL2_TIMEOUT) || defined(CUFHE_AMD_ABL_L2_NOATOM)) && !defined(CUFHE_AMD_DIAGNOSTIC_BUILD)
+     defined(CUFHE_AMD_ABL_BK0) || defined(CUFHE_AMD_ABL_NO_SYNC) || defined(CUFHE_AMD_ABL_PHASES) || defined(CUFHE_AMD_ABL_LL2_TIMEOUT) || defined(CUFHE_AMD_ABL_L2_NOATOM)) && !defined(CUFHE_AMD_DIAGNOSTIC_BUILD)
 #error "CUFHE_AMD_ABL_* switches produce wrong results: use `python cufhe_amd/build.py --diagnostic=NAME[,NAME]` (defines CUFHE_AMD_DIAGNOSTIC_BUILD, output libcufhe_amd_diag.so)"
 #endif
 

@@ -209,13 +209,17 @@ struct RowPipe {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const int piece = 2 * wave + c;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+            lds_dma16(src + piece * 1024, dst + piece * 1024);
         }
     }
     __device__ __forceinline__ void sync(int R) const
     {
-        __syncthreads();     // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_SYNC)
+        (void)R;             // timing only: no row barrier, no key traffic -- what the waves do when nothing couples them
+        return;
+#endif
+        lds_dma_wait_all();  // this wave's pieces of row R (issued a row ago) have landed
+        __syncthreads();     // s_waitcnt lgkmcnt(0); s_barrier
         issue(R + 1);
     }
     __device__ __forceinline__ const char* row(int R) const
@@ -278,13 +282,13 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* tabs = (double*)(smem + kBrLdsTables);
-    load_tables_to_lds(tabs, gt);
+    load_packed_tables_to_lds(tabs, gt);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * active + wave;
     char* tile = smem + kBrLdsTiles + wave * kTileBytes;
     uint16_t* abar_lds = (uint16_t*)(smem + kBrLdsAbar + wave * kAbarBytes);
-    const WaveCtx ctx = make_wave_ctx(smem, kBrLdsTiles + wave * kTileBytes, kBrLdsTables, gt, lane);
+    const WaveCtx ctx = make_wave_ctx_packed(smem, kBrLdsTiles + wave * kTileBytes, kBrLdsTables, gt, lane);
     const RowPipe pipe{(const char*)bk_ntt, smem + kBrLdsBk, wave, lane, steps * kBkRows, wave >= kBrWavesPerBlock / 2};
     pipe.issue(0);
     if (wave >= active || g >= count) {

@@ -69,7 +69,7 @@ constexpr int kBkRowBuffers = 3;
 // that "buffer + piece" offsets (< 64 KiB) fold into the DS instructions' offset field.
 constexpr int kBrLdsBk = 0;
 constexpr int kBrLdsTables = kBrLdsBk + kBkRowBuffers * kBkRowBytes;            // 49152
-constexpr int kBrLdsTiles = kBrLdsTables + kLdsTableBytes;
+constexpr int kBrLdsTiles = kBrLdsTables + kLdsTablePackedBytes;                // the packed r4 tables (ntt_wave.h)
 constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
 constexpr int kBrLdsBytes = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;         // 143104
 

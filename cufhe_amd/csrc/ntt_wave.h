@@ -43,6 +43,8 @@ constexpr int kN = 1024;
 constexpr int kRegs = 16;            // coefficients per lane
 constexpr int kTbCount = 15;         // per-lane twiddles of stages 4-7
 constexpr int kTcCount = 12;         // per-lane twiddles of stages 8-9
+constexpr int kTbpStride = 18;       // doubles per lambda in the packed stage 4-7 table (15 used)
+constexpr int kTcpStride = 14;       // doubles per lane in the packed stage 8-9 table (12 used)
 constexpr int kTileSlots = 66 * 16;  // 8-byte slots in a wave's transpose tile
 constexpr int kTileBytes = kTileSlots * 8;   // 8448
 
@@ -117,7 +119,18 @@ struct NttTables {
     double tb_inv[kTbCount * 16];
     double tc_fwd[kTcCount * 64];    // [k][lane]: k<4: root[256 + (lambda<<4|h<<2|k)]; else root[512 + (lambda<<5|h<<3|(k-4))]
     double tc_inv[kTcCount * 64];
+    // The same per-lane twiddles PACKED per lane (filled for the r4 tables only): a lane's fifteen stage 4-7 twiddles and its
+    // twelve stage 8-9 twiddles are contiguous, so a transform fetches them with 8 + 6 ds_read_b128 instead of 27 ds_read_b64
+    // (the compiler pairs those into ds_read2_b64, which moves 128 B per LDS clock where ds_read_b128 moves 256).  The strides
+    // -- 18 doubles = 144 bytes per lambda, 14 doubles = 112 bytes per lane -- put the sixteen lanes of every ds_read_b128 lane
+    // group on sixteen different 4-bank slots.  [tbp_fwd | tbp_inv | tcp_fwd | tcp_inv] is one contiguous block.
+    double tbp_fwd[16 * kTbpStride];
+    double tbp_inv[16 * kTbpStride];
+    double tcp_fwd[64 * kTcpStride];
+    double tcp_inv[64 * kTcpStride];
 };
+constexpr int kLdsTablePackedDoubles = 2 * 16 * kTbpStride + 2 * 64 * kTcpStride;   // 2368
+constexpr int kLdsTablePackedBytes = kLdsTablePackedDoubles * 8;                     // 18944
 constexpr int kLdsTableDoubles = 2 * kTbCount * 16 + 2 * kTcCount * 64;   // 2016
 constexpr int kLdsTableBytes = kLdsTableDoubles * 8;                        // 16128
 
@@ -126,6 +139,13 @@ __device__ __forceinline__ void load_tables_to_lds(double* lds, const NttTables*
 {
     const double* src = g->tb_fwd;   // tb_fwd, tb_inv, tc_fwd, tc_inv are contiguous
     for (int i = threadIdx.x; i < kLdsTableDoubles; i += blockDim.x) lds[i] = src[i];
+}
+
+// the packed tables (NttTables::tbp_fwd ..) instead: kLdsTablePackedBytes at `lds`
+__device__ __forceinline__ void load_packed_tables_to_lds(double* lds, const NttTables* g)
+{
+    const double* src = g->tbp_fwd;
+    for (int i = threadIdx.x; i < kLdsTablePackedDoubles; i += blockDim.x) lds[i] = src[i];
 }
 
 // Per-lane LDS byte addresses, computed once per kernel and kept in VGPRs.
@@ -146,6 +166,24 @@ struct WaveCtx {
     // the wave-per-rotation kernel the partner wave covers the stall (measured: 38.63 ms either way).
     const char* tu_l;
 };
+
+// LDS-DMA of one 1 KiB piece (16 bytes per lane): global `src` (per lane) -> LDS `dst` (wave-uniform base; lane L lands at
+// dst + 16 L).  Written as inline assembly ON PURPOSE: issued through __builtin_amdgcn_global_load_lds the compiler knows that
+// an asynchronous LDS write is in flight, cannot tell which LDS reads it may alias (every per-lane LDS base here is opaque) and
+// puts `s_waitcnt vmcnt(0)` in front of the NEXT ds_read whatever it reads -- the wave then sits out the whole L2 round trip
+// of the piece it has just requested, once per key row (found in the ISA in round 5: in front of the first ds_read_b128 of the
+// pointwise product).  The protocol of the callers never reads a buffer before the barrier that follows the wait below, so no
+// such wait is needed; with the request invisible to the compiler none is emitted.  lds_dma_wait_all() is the wait the
+// callers place in front of that barrier.  M0 carries the LDS base (a reserved register the compiler sets before each of its own uses).
+__device__ __forceinline__ void lds_dma16(const void* src, char* dst_uniform)
+{
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dst_uniform;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // A byte offset the compiler cannot see through: `lds + opaque(off)` keeps the full per-lane
 // address in ONE VGPR, so every access is "VGPR + small immediate".  Without it hipcc folds
@@ -176,6 +214,31 @@ __device__ __forceinline__ WaveCtx make_wave_ctx(char* lds, int tile_off, int ta
     return c;
 }
 
+// WaveCtx whose tb_* / tc_* point into the PACKED tables (load_packed_tables_to_lds): tb_fwd + 16 i is the double2 of
+// twiddles 2i, 2i + 1 of this lane's lambda, tc_fwd + 16 i that of its stage 8-9 twiddles
+__device__ __forceinline__ WaveCtx make_wave_ctx_packed(char* lds, int tile_off, int tables_off, const NttTables* gt, int lane)
+{
+    WaveCtx c = make_wave_ctx(lds, tile_off, tables_off, gt, lane);
+    c.tb_fwd = lds + opaque(tables_off + 8 * kTbpStride * (lane & 15));
+    c.tb_inv = c.tb_fwd + 8 * 16 * kTbpStride;
+    c.tc_fwd = lds + opaque(tables_off + 8 * 2 * 16 * kTbpStride + 8 * kTcpStride * lane);
+    c.tc_inv = c.tc_fwd + 8 * 64 * kTcpStride;
+    return c;
+}
+__device__ __forceinline__ double2 lds_ld2(const char* p, int off) { return *(const double2*)(p + off); }
+// COUNT packed twiddles of this lane into registers (ds_read_b128 each two).  (No CUFHE_AMD_ABL_NO_TW form: with constants in
+// place of these twiddles hipcc folds a fifth of the transform's arithmetic away -- 470 FP64 instructions less in the kernel --
+// so that "ablation" measures a different program; round 5 found its -13 % to be exactly that.)
+template <int COUNT>
+__device__ __forceinline__ void load_packed(double (&tw)[COUNT], const char* base)
+{
+#pragma unroll
+    for (int i = 0; i < (COUNT + 1) / 2; i++) {
+        const double2 v = lds_ld2(base, 16 * i);
+        tw[2 * i] = v.x;
+        if (2 * i + 1 < COUNT) tw[2 * i + 1] = v.y;
+    }
+}
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_NO_TW)
 __device__ __forceinline__ double lds_ld(const char* p, int off) { return 12345678.0 + (double)off + (double)(uintptr_t)p * 1e-30; }
 #else
@@ -588,7 +651,8 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c
 
 
 // ==================================================================================================================
-// Radix-4 transforms (ntt_r4.h) on the r4 twiddle tables (capi.hip: fill_tables(..., r4 = true)): the same layouts,
+// Radix-4 transforms (ntt_r4.h) on the r4 twiddle tables (capi.hip: fill_tables(..., r4 = true)) in their PACKED form
+// (WaveCtx from make_wave_ctx_packed, LDS copy by load_packed_tables_to_lds): the same layouts,
 // layout changes and twiddle fetch placement as above, 30 instead of 32 operations per four elements and two stages,
 // and reductions only on the registers whose compile-time bound asks for one.
 // ==================================================================================================================
@@ -605,15 +669,13 @@ __device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], con
     using F = r4::FwdDigits<DIGIT_MAX>;
     static_assert(r4::valid(F::Spectrum::in()), "radix-4 forward transform of gadget digits: a value exceeds 2^53");
     double twb[kTbCount];
-#pragma unroll
-    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_fwd, 128 * k);
+    load_packed(twb, c.tb_fwd);
     if (HALF_TILE) xpose_half_tile<true>(x, c.a66, c.b66);
     else CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
     r4::ct_pass_hi<typename F::B0>(x, TwArr{twb});
     r4::ct_pass_lo<typename F::B1, 3, 7>(x, TwArr{twb});
     double twc[kTcCount];
-#pragma unroll
-    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_fwd, 512 * k);
+    load_packed(twc, c.tc_fwd);
     xpose_bc_permlane(x);                            // B -> C in registers
     r4::reduce_mask<F::kReduceC>(x);
     r4::ct_pass_lo<typename F::C1, 0, 4>(x, TwArr{twc});
@@ -625,13 +687,11 @@ __device__ __forceinline__ void ntt_inverse_r4(double (&x)[kRegs], const WaveCtx
     using V = r4::Inverse<S0>;
     static_assert(r4::valid(V::Out::in()), "radix-4 inverse transform: a value exceeds 2^53");
     double twc[kTcCount];
-#pragma unroll
-    for (int k = 0; k < kTcCount; k++) twc[k] = lds_ld(c.tc_inv, 512 * k);
+    load_packed(twc, c.tc_inv);
     r4::gs_pass_lo<S0, 0, 4>(x, TwArr{twc});
     r4::reduce_above<typename V::C1, V::kLimit>(x);
     double twb[kTbCount];
-#pragma unroll
-    for (int k = 0; k < kTbCount; k++) twb[k] = lds_ld(c.tb_inv, 128 * k);
+    load_packed(twb, c.tb_inv);
     xpose_cb_permlane(x);                            // C -> B in registers
     r4::gs_pass_lo<typename V::B0, 3, 7>(x, TwArr{twb});
     r4::reduce_above<r4::AfterGs<typename V::B0, false>, V::kLimit>(x);
