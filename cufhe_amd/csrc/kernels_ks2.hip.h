@@ -43,8 +43,7 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_lvl2_shared_kernel(
         for (int c = 0; c < 3; c++) {
             const int piece = wave < k2KsWaves3 ? 3 * wave + c : 3 * k2KsWaves3 + 2 * (wave - k2KsWaves3) + c;
             if (c == 2 && wave >= k2KsWaves3) break;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+            lds_dma16(src + piece * 1024, dst + piece * 1024);
         }
     };
     issue(0);

@@ -364,13 +364,13 @@ struct PsRowPipe {
         for (int c = 0; c < (pieces + WAVES - 1) / WAVES; c++) {
             const int piece = wave + WAVES * c;
             if (piece < pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+                lds_dma16(src + piece * 1024, dst + piece * 1024);
         }
     }
     __device__ __forceinline__ void sync(int R) const
     {
-        __syncthreads();     // s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier: every wave's pieces of row R have landed
+        lds_dma_wait_all();  // this wave's pieces of row R (ntt_wave.h: lds_dma16, invisible to the compiler's own counting)
+        __syncthreads();     // every wave's pieces of row R have landed
         issue(R + 1);        // into the buffer of row R - 2, whose last reader passed its barrier R - 1
     }
     __device__ __forceinline__ const char* row(int R) const
@@ -674,8 +674,7 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_ps_shared_kernel(
         for (int c = 0; c < (K::dma_pieces + kKsWaves - 1) / kKsWaves; c++) {
             const int piece = wave + kKsWaves * c;
             if (piece < K::dma_pieces)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+                lds_dma16(src + piece * 1024, dst + piece * 1024);
         }
     };
     issue(0);
