@@ -242,7 +242,7 @@ template <bool LAST_COMPONENT>
 __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)[kRegs],
                                                const uint32_t (&accj)[kRegs], const WaveCtx& ctx,
                                                char* tile, int lane, uint32_t abar,
-                                               const RowPipe& pipe, int first_row CUFHE_AMD_DIAG_ARG)
+                                               const RowPipe& pipe, int first_row, const TuFwdPinned& tuf CUFHE_AMD_DIAG_ARG)
 {
     constexpr int kDigitMax = 1 << (kBgbit - 1);
     uint32_t temp[kRegs];
@@ -254,18 +254,20 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
-        ntt_forward_digits_a_r4<kDigitMax>(x, ctx);
+        ntt_forward_digits_a_r4<kDigitMax, true>(x, ctx, &tuf);
         if (pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
-        ntt_forward_digits_bc_r4<kDigitMax>(x, ctx);
+        ntt_forward_digits_bc_r4<kDigitMax, false, true>(x, ctx);
         if (!pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
         if (LAST_COMPONENT && d == kL - 1) pointwise_accumulate<BrSpectrum, true>(A0, A1, x, pipe.row(first_row + d));
         else pointwise_accumulate<BrSpectrum, false>(A0, A1, x, pipe.row(first_row + d));
     }
 }
 
-__device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&accj)[kRegs], const WaveCtx& ctx)
+template <bool TWB_LOADED>
+__device__ __forceinline__ void inverse_and_add(double (&A)[kRegs], uint32_t (&accj)[kRegs], const WaveCtx& ctx,
+                                                const double (&twc)[kTcCount], double (&twb)[kTbCount])
 {
-    ntt_inverse_r4<BrSums>(A, ctx);
+    ntt_inverse_r4_tw<BrSums, false, TWB_LOADED>(A, ctx, twc, twb);
     lift_add<BrInverse::Out>(accj, A);           // centred lift, :258-281
 }
 
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
         acc1[r] = neg ? 0u - kMu : kMu;
     }
     __syncthreads();          // tables staged; abar list visible (own wave only, but cheap)
+    TuFwdPinned tuf;
+    tuf.load(gt);
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     unsigned long long diag_wait = 0;
     const unsigned long long diag_t0 = __builtin_readcyclecounter();
@@ -333,14 +337,16 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
     for (int i = 0; i < steps; i++) {
         // abar = 0 needs no special case: all digits are zero and the step adds nothing
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
-        double A0[kRegs], A1[kRegs];
+        double A0[kRegs], A1[kRegs], inv_twc[kTcCount], inv_twb[kTbCount];
 #pragma unroll
         for (int r = 0; r < kRegs; r++) { A0[r] = 0.0; A1[r] = 0.0; }
         // six products per accumulator, the last one reducing the sum (BrSums)
-        cmux_component<false>(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows CUFHE_AMD_DIAG_PASS);
-        cmux_component<true>(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL CUFHE_AMD_DIAG_PASS);
-        inverse_and_add(A0, acc0, ctx);
-        inverse_and_add(A1, acc1, ctx);
+        cmux_component<false>(A0, A1, acc0, ctx, tile, lane, abar, pipe, i * kBkRows, tuf CUFHE_AMD_DIAG_PASS);
+        cmux_component<true>(A0, A1, acc1, ctx, tile, lane, abar, pipe, i * kBkRows + kL, tuf CUFHE_AMD_DIAG_PASS);
+        // the two inverse transforms share their per-lane twiddles: fetched once
+        load_packed(inv_twc, ctx.tc_inv);
+        inverse_and_add<false>(A0, acc0, ctx, inv_twc, inv_twb);     // fetches the stage 7-4 twiddles ...
+        inverse_and_add<true>(A1, acc1, ctx, inv_twc, inv_twb);      // ... which the second transform re-uses
     }
 
     if (acc_dump) {

@@ -332,6 +332,15 @@ R4_HD void reduce_above(double (&x)[16])
     }
 }
 
+// the same for the four registers of HI group G (registers G, G + 4, G + 8, G + 12)
+template <class S, int LIMIT_MILLI, int G>
+R4_HD void reduce_above_group(double (&x)[16])
+{
+    if constexpr (S::in().v[G] > LIMIT_MILLI * 0.001) x[G] = fpf::reduce(x[G]);
+    if constexpr (S::in().v[G + 4] > LIMIT_MILLI * 0.001) x[G + 4] = fpf::reduce(x[G + 4]);
+    if constexpr (S::in().v[G + 8] > LIMIT_MILLI * 0.001) x[G + 8] = fpf::reduce(x[G + 8]);
+    if constexpr (S::in().v[G + 12] > LIMIT_MILLI * 0.001) x[G + 12] = fpf::reduce(x[G + 12]);
+}
 template <unsigned MASK, int R = 0>
 R4_HD void reduce_mask(double (&x)[16])
 {

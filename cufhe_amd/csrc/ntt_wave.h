@@ -657,20 +657,65 @@ __device__ __forceinline__ void ntt_inverse(double (&x)[kRegs], const WaveCtx& c
 // and reductions only on the registers whose compile-time bound asks for one.
 // ==================================================================================================================
 
-template <int DIGIT_MAX>
-__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c)
+// STORE: every group of the last pass is written to the transpose tile (A side, pitch 66) as soon as it is computed, so the
+// LDS writes of the layout change run beside the rest of the pass instead of after it; ntt_forward_digits_bc_r4<.., STORED = true>
+// then only reads.  (The tile's earlier readers -- rotate_sub, the previous transform -- produced the data these values are
+// computed from, so the data dependence orders the stores behind them; the compiler fence in front keeps them behind any
+// independent tile access of an earlier transform, as CUFHE_AMD_XPOSE does.)
+// The twelve wave-uniform twiddles of stages 2-3 (r4 table slots 3..14), loaded ONCE per kernel and pinned in scalar registers:
+// read through the scalar cache in every transform they cost an s_load followed by s_waitcnt lgkmcnt(0), which also drains
+// the wave's LDS queue -- with the tile stores of STORE below in flight that wait sits in the middle of the pass.
+struct TuFwdPinned {
+    double t[12];
+    __device__ __forceinline__ void load(const NttTables* gt)
+    {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            double v = gt->tu_fwd[3 + k];
+            asm volatile("" : "+s"(v));       // opaque: kept in an SGPR pair, never re-loaded
+            t[k] = v;
+        }
+    }
+    __device__ __forceinline__ double operator()(int k) const { return t[k - 3]; }
+};
+template <int DIGIT_MAX, bool STORE = false, class TW = TwUniform>
+__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c, const TW* pinned = nullptr)
 {
+    using A0 = typename r4::FwdDigits<DIGIT_MAX>::A0;
     ct_exact_first_two(x);
-    r4::ct_pass_lo<typename r4::FwdDigits<DIGIT_MAX>::A0, 3, 7>(x, TwUniform{c.gt->tu_fwd});
+    if (!STORE) {
+        r4::ct_pass_lo<A0, 3, 7>(x, TwUniform{c.gt->tu_fwd});
+    } else {
+        const TW& tw = *pinned;
+        asm volatile("" ::: "memory");
+        r4::Group<A0, false, 0>::ct(x, tw(3), tw(7), tw(8));
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds_st(c.a66, 8 * 66 * r, x[r]);
+        r4::Group<A0, false, 1>::ct(x, tw(4), tw(9), tw(10));
+#pragma unroll
+        for (int r = 4; r < 8; r++) lds_st(c.a66, 8 * 66 * r, x[r]);
+        r4::Group<A0, false, 2>::ct(x, tw(5), tw(11), tw(12));
+#pragma unroll
+        for (int r = 8; r < 12; r++) lds_st(c.a66, 8 * 66 * r, x[r]);
+        r4::Group<A0, false, 3>::ct(x, tw(6), tw(13), tw(14));
+#pragma unroll
+        for (int r = 12; r < 16; r++) lds_st(c.a66, 8 * 66 * r, x[r]);
+    }
 }
-template <int DIGIT_MAX, bool HALF_TILE = false>
+template <int DIGIT_MAX, bool HALF_TILE = false, bool STORED = false>
 __device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], const WaveCtx& c)
 {
     using F = r4::FwdDigits<DIGIT_MAX>;
     static_assert(r4::valid(F::Spectrum::in()), "radix-4 forward transform of gadget digits: a value exceeds 2^53");
+    static_assert(!(HALF_TILE && STORED), "the half-size tile takes the layout change in two passes");
     double twb[kTbCount];
     load_packed(twb, c.tb_fwd);
     if (HALF_TILE) xpose_half_tile<true>(x, c.a66, c.b66);
+    else if (STORED) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) x[r] = lds_ld(c.b66, 32 * r);
+    }
     else CUFHE_AMD_XPOSE(c.a66, 8 * 66, c.b66, 32)        // A -> B
     r4::ct_pass_hi<typename F::B0>(x, TwArr{twb});
     r4::ct_pass_lo<typename F::B1, 3, 7>(x, TwArr{twb});
@@ -681,24 +726,58 @@ __device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], con
     r4::ct_pass_lo<typename F::C1, 0, 4>(x, TwArr{twc});
 }
 
+template <class S0, bool HALF_TILE, bool TWB_LOADED>
+__device__ __forceinline__ void ntt_inverse_r4_tw(double (&x)[kRegs], const WaveCtx& c, const double (&twc)[kTcCount], double (&twb)[kTbCount]);
 template <class S0, bool HALF_TILE = false>
 __device__ __forceinline__ void ntt_inverse_r4(double (&x)[kRegs], const WaveCtx& c)
 {
+    double twc[kTcCount], twb[kTbCount];
+    load_packed(twc, c.tc_inv);
+    ntt_inverse_r4_tw<S0, HALF_TILE, false>(x, c, twc, twb);
+}
+// The same with the twelve stage 9-8 twiddles already in registers (a caller with several inverse transforms in a row loads
+// them once, ahead of the work in front of the first); TWB_LOADED: the fifteen stage 7-4 twiddles as well, else they are
+// fetched here (into twb, which a following transform may then re-use)
+template <class S0, bool HALF_TILE, bool TWB_LOADED>
+__device__ __forceinline__ void ntt_inverse_r4_tw(double (&x)[kRegs], const WaveCtx& c, const double (&twc)[kTcCount], double (&twb)[kTbCount])
+{
     using V = r4::Inverse<S0>;
     static_assert(r4::valid(V::Out::in()), "radix-4 inverse transform: a value exceeds 2^53");
-    double twc[kTcCount];
-    load_packed(twc, c.tc_inv);
     r4::gs_pass_lo<S0, 0, 4>(x, TwArr{twc});
     r4::reduce_above<typename V::C1, V::kLimit>(x);
-    double twb[kTbCount];
-    load_packed(twb, c.tb_inv);
+    if (!TWB_LOADED) load_packed(twb, c.tb_inv);
     xpose_cb_permlane(x);                            // C -> B in registers
     r4::gs_pass_lo<typename V::B0, 3, 7>(x, TwArr{twb});
     r4::reduce_above<r4::AfterGs<typename V::B0, false>, V::kLimit>(x);
-    r4::gs_pass_hi<typename V::B1>(x, TwArr{twb});
-    r4::reduce_above<r4::AfterGs<typename V::B1, true>, V::kLimit>(x);
-    if (HALF_TILE) xpose_half_tile<false>(x, c.a65, c.b65);
-    else CUFHE_AMD_XPOSE(c.b65, 32, c.a65, 8 * 65)        // B -> A
+    if (HALF_TILE) {
+        r4::gs_pass_hi<typename V::B1>(x, TwArr{twb});
+        r4::reduce_above<r4::AfterGs<typename V::B1, true>, V::kLimit>(x);
+        xpose_half_tile<false>(x, c.a65, c.b65);
+    } else {
+        // B -> A with every group of the last pass stored as soon as it is computed (cf. ntt_forward_digits_a_r4<.., STORE>)
+        using B1o = r4::AfterGs<typename V::B1, true>;
+        const double w = twb[0], v = twb[1], vw = twb[2];
+        asm volatile("" ::: "memory");
+        r4::Group<typename V::B1, true, 0>::gs(x, w, v, vw);
+        r4::reduce_above_group<B1o, V::kLimit, 0>(x);
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) lds_st(c.b65, 32 * k, x[k]);
+        r4::Group<typename V::B1, true, 1>::gs(x, w, v, vw);
+        r4::reduce_above_group<B1o, V::kLimit, 1>(x);
+#pragma unroll
+        for (int k = 1; k < 16; k += 4) lds_st(c.b65, 32 * k, x[k]);
+        r4::Group<typename V::B1, true, 2>::gs(x, w, v, vw);
+        r4::reduce_above_group<B1o, V::kLimit, 2>(x);
+#pragma unroll
+        for (int k = 2; k < 16; k += 4) lds_st(c.b65, 32 * k, x[k]);
+        r4::Group<typename V::B1, true, 3>::gs(x, w, v, vw);
+        r4::reduce_above_group<B1o, V::kLimit, 3>(x);
+#pragma unroll
+        for (int k = 3; k < 16; k += 4) lds_st(c.b65, 32 * k, x[k]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < kRegs; r++) x[r] = lds_ld(c.a65, 8 * 65 * r);
+    }
     r4::gs_pass_lo<typename V::A0, 3, 7>(x, TwUniform{c.gt->tu_inv});
     r4::reduce_above<r4::AfterGs<typename V::A0, false>, V::kLimit>(x);
     r4::gs_pass_hi<typename V::A1>(x, TwUniform{c.gt->tu_inv});
