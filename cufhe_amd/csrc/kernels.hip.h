@@ -254,9 +254,10 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
 #pragma unroll
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
-        ntt_forward_digits_a_r4<kDigitMax, true>(x, ctx, &tuf);
+        double twb[kTbCount];
+        ntt_forward_digits_a_r4<kDigitMax, true>(x, ctx, &tuf, twb);
         if (pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
-        ntt_forward_digits_bc_r4<kDigitMax, false, true>(x, ctx);
+        ntt_forward_digits_bc_r4<kDigitMax, false, true>(x, ctx, twb);
         if (!pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
         if (LAST_COMPONENT && d == kL - 1) pointwise_accumulate<BrSpectrum, true>(A0, A1, x, pipe.row(first_row + d));
         else pointwise_accumulate<BrSpectrum, false>(A0, A1, x, pipe.row(first_row + d));

@@ -679,7 +679,7 @@ struct TuFwdPinned {
     __device__ __forceinline__ double operator()(int k) const { return t[k - 3]; }
 };
 template <int DIGIT_MAX, bool STORE = false, class TW = TwUniform>
-__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c, const TW* pinned = nullptr)
+__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c, const TW* pinned = nullptr, double* twb_ahead = nullptr)
 {
     using A0 = typename r4::FwdDigits<DIGIT_MAX>::A0;
     ct_exact_first_two(x);
@@ -687,6 +687,10 @@ __device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], cons
         r4::ct_pass_lo<A0, 3, 7>(x, TwUniform{c.gt->tu_fwd});
     } else {
         const TW& tw = *pinned;
+        if (twb_ahead) {          // the stage 4-7 twiddles of ntt_forward_digits_bc_r4, requested a pass ahead of their use
+            double (&t)[kTbCount] = *reinterpret_cast<double (*)[kTbCount]>(twb_ahead);
+            load_packed(t, c.tb_fwd);
+        }
         asm volatile("" ::: "memory");
         r4::Group<A0, false, 0>::ct(x, tw(3), tw(7), tw(8));
 #pragma unroll
@@ -703,13 +707,18 @@ __device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], cons
     }
 }
 template <int DIGIT_MAX, bool HALF_TILE = false, bool STORED = false>
-__device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], const WaveCtx& c)
+__device__ __forceinline__ void ntt_forward_digits_bc_r4(double (&x)[kRegs], const WaveCtx& c, const double* twb_loaded = nullptr)
 {
     using F = r4::FwdDigits<DIGIT_MAX>;
     static_assert(r4::valid(F::Spectrum::in()), "radix-4 forward transform of gadget digits: a value exceeds 2^53");
     static_assert(!(HALF_TILE && STORED), "the half-size tile takes the layout change in two passes");
     double twb[kTbCount];
-    load_packed(twb, c.tb_fwd);
+    if (twb_loaded) {
+#pragma unroll
+        for (int k = 0; k < kTbCount; k++) twb[k] = twb_loaded[k];
+    } else {
+        load_packed(twb, c.tb_fwd);
+    }
     if (HALF_TILE) xpose_half_tile<true>(x, c.a66, c.b66);
     else if (STORED) {
         asm volatile("" ::: "memory");
