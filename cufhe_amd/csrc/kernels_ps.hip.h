@@ -28,6 +28,7 @@
 // NTT-domain key: [step][limb][row][out][q < R/2][lane][2] doubles: a TRGSW row of one limb is one contiguous
 // block of (k+1) polynomials, each in the spectrum order of the wave transform (registers 2q, 2q+1 of a lane).
 #pragma once
+#include <type_traits>
 #include "kernels.hip.h"
 #include "ntt_wave512.h"
 
@@ -127,6 +128,51 @@ template <> struct Poly<9> {
     static constexpr bool small_ok(double digit_max) { return digit_max <= 32.0; }
     static constexpr double spectrum_bound(bool, double) { return 7.23; }      // ntt_wave512.h: inputs far below p, |out| <= 7.22 p
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt512_inverse(x, c); }
+};
+
+// The transforms of the wave-per-rotation kernel (blind_rotate_ps_batch_kernel): for the 1024-point ring the radix-4 passes of
+// ntt_r4.h on the r4 tables in their packed form (round 4; the workgroup-per-rotation kernel and the key conversion keep the
+// radix-2 transform and tables above), for the 512-point ring Poly<9> as it is.  DIGIT_MAX = Bg/2.
+template <int NBIT, int DIGIT_MAX> struct PsbPoly;
+template <int DIGIT_MAX> struct PsbPoly<9, DIGIT_MAX> : Poly<9> {
+    static constexpr bool kR4Tables = false;
+    static constexpr bool kSmall = Poly<9>::small_ok((double)DIGIT_MAX);
+    static constexpr double kSpectrum = Poly<9>::spectrum_bound(kSmall, (double)DIGIT_MAX);
+    struct State {};                 // per-kernel transform state (nothing for this ring)
+    static __device__ __forceinline__ void init(State&, const Tables*) {}
+    static __device__ __forceinline__ void forward_digits(double (&x)[R], const Ctx& c, const State&)
+    {
+        if (kSmall) Poly<9>::forward_small(x, c);
+        else Poly<9>::forward(x, c);
+    }
+};
+template <class PS>
+using PsbPolyOf = PsbPoly<PS::Nbit, (1 << (PS::Bgbit - 1))>;
+template <int DIGIT_MAX> struct PsbPoly<10, DIGIT_MAX> {
+    static constexpr bool kR4Tables = true;
+    static constexpr int R = 16, tile_bytes = kTileBytes, table_bytes = kLdsTablePackedBytes;
+    using Tables = NttTables;         // the r4 instance (capi.hip: DeviceState::tables_r4)
+    using Ctx = WaveCtx;
+    using Fwd = r4::FwdDigits<DIGIT_MAX>;
+    using Inv = r4::Inverse<r4::Uniform<501>>;
+    static_assert(r4::valid(Fwd::Spectrum::in()), "radix-4 forward transform of this set's gadget digits: a value exceeds 2^53");
+    static constexpr double kSpectrum = r4::max_of(Fwd::Spectrum::in());
+    static __device__ __forceinline__ void load_tables(char* lds, const Tables* gt) { load_packed_tables_to_lds((double*)lds, gt); }
+    static __device__ __forceinline__ Ctx ctx(char* lds, int tile_off, int tables_off, const Tables* gt, int lane)
+    {
+        return make_wave_ctx_packed(lds, tile_off, tables_off, gt, lane);
+    }
+    struct State {};
+    static __device__ __forceinline__ void init(State&, const Tables*) {}
+    static __device__ __forceinline__ void forward_digits(double (&x)[R], const Ctx& c, const State&)
+    {
+        // (blind_rotate_kernel's store-inside-the-pass form with pinned scalar twiddles measured slower here: 38.4 against 37.5 ms
+        // for `default`, 45.6 against 45.0 for `cggi16` -- 105 SGPRs)
+        ntt_forward_digits_a_r4<DIGIT_MAX>(x, c);
+        ntt_forward_digits_bc_r4<DIGIT_MAX>(x, c);
+    }
+    // x reduced (|x| <= p/2) in, any |out| < 2^53
+    static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt_inverse_r4<r4::Uniform<501>>(x, c); }
 };
 
 // waves of the workgroup-per-rotation kernel: one per TRGSW row where that takes more than 8 (k2n512: 9 rows would
@@ -333,7 +379,7 @@ constexpr int kPsbRowBuffers = 3;
 template <class PS>
 struct PsbLds {
     using D = PsDims<PS>;
-    using PO = Poly<PS::Nbit>;
+    using PO = PsbPolyOf<PS>;
     static constexpr int waves = kPsbWavesOf<PS>;
     static constexpr int threads = 64 * waves;
     static constexpr int row_bytes = D::K1 * D::N * 8;
@@ -410,12 +456,10 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
     const typename Poly<PS::Nbit>::Tables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {
     using D = PsDims<PS>;
-    using PO = Poly<PS::Nbit>;
+    using PO = PsbPolyOf<PS>;
     using L = PsbLds<PS>;
     constexpr int N = D::N, R = D::R, K1 = D::K1;
-    constexpr double kDigitMax = (double)(1u << (PS::Bgbit - 1));
-    constexpr bool kSmallIn = PO::small_ok(kDigitMax);
-    constexpr double kSpec = PO::spectrum_bound(kSmallIn, kDigitMax);
+    constexpr double kSpec = PO::kSpectrum;
     constexpr double kRowTerm = fpf::after_mulmod_wide(kSpec);
     constexpr bool kAllRowsFit = D::ROWS * kRowTerm < fpf::LIM_WIDE;
     static_assert(kSpec > 0 && kSpec < fpf::LIM_WIDE, "digit spectrum exceeds what the wide product accepts");
@@ -457,6 +501,8 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
         acc[PS::k][r] = neg ? 0u - kMu : kMu;
     }
     __syncthreads();          // tables staged; abar list visible
+    typename PO::State po_state;
+    PO::init(po_state, gt);
 
     int row_id = 0;
 #pragma unroll 1
@@ -487,8 +533,7 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
 #pragma unroll
                     for (int r = 0; r < R; r++) x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)PS::Bgbit);
                     if (pipe.late) pipe.sync(row_id);
-                    if (kSmallIn) PO::forward_small(x, ctx);
-                    else PO::forward(x, ctx);
+                    PO::forward_digits(x, ctx, po_state);
                     if (!pipe.late) pipe.sync(row_id);
                     // :206-221.  The spectrum (<= kSpec p) goes into wide products unreduced: each is <= kRowTerm p, the l
                     // rows of a component add up below 2^53 on top of a reduced sum (static_assert above), and a set whose

@@ -78,6 +78,14 @@ const typename Poly<PS::Nbit>::Tables* ps_tables(DeviceState& s)
     else return s.tables512 + 2;            // the stand-alone 512-point negacyclic transform
 }
 
+// the wave-per-rotation kernel of a 1024-point set runs the radix-4 transform: its tables
+template <class PS>
+const typename Poly<PS::Nbit>::Tables* ps_tables_batch(DeviceState& s)
+{
+    if constexpr (PS::Nbit == 10) return PsbPolyOf<PS>::kR4Tables ? s.tables_r4 : s.tables;
+    else return s.tables512 + 2;
+}
+
 template <class PS>
 int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count, int steps, uint32_t* dump)
 {
@@ -93,7 +101,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
         // one wave per rotation, 8 rotations per workgroup share the key rows (throughput shape)
         const unsigned blocks = (unsigned)((count + PsbLds<PS>::waves - 1) / PsbLds<PS>::waves);
         hipLaunchKernelGGL(blind_rotate_ps_batch_kernel<PS>, dim3(blocks), dim3(PsbLds<PS>::threads), PsbLds<PS>::bytes, st, d, (int)count,
-                           ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+                           ps.bk_ntt, ps_tables_batch<PS>(s), steps, dump);
     } else {
         // one workgroup per rotation (latency shape)
         hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(PsLds<PS>::threads), PsLds<PS>::bytes, st, d, (int)count,
