@@ -255,7 +255,7 @@ __device__ __forceinline__ void cmux_component(double (&A0)[kRegs], double (&A1)
         for (int r = 0; r < kRegs; r++)
             x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[r], pos, (uint32_t)kBgbit);
         double twb[kTbCount];
-        ntt_forward_digits_a_r4<kDigitMax, true>(x, ctx, &tuf, twb);
+        ntt_forward_digits_a_r4<kDigitMax, true>(x, ctx, &tuf, &twb);
         if (pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)
         ntt_forward_digits_bc_r4<kDigitMax, false, true>(x, ctx, twb);
         if (!pipe.late) CUFHE_AMD_ROW_SYNC(first_row + d)

@@ -145,12 +145,6 @@ constexpr RegBounds reduce_mask_bounds(const RegBounds& in, unsigned mask)
         if ((mask >> r) & 1u) out.v[r] = kReduced;
     return out;
 }
-constexpr int count_above(const RegBounds& in, double limit)
-{
-    int n = 0;
-    for (int r = 0; r < 16; r++) n += in.v[r] > limit ? 1 : 0;
-    return n;
-}
 
 // ---- schedules as types: S::in() is the bound of every register on entry ----
 template <class S, bool HI>

@@ -679,7 +679,7 @@ struct TuFwdPinned {
     __device__ __forceinline__ double operator()(int k) const { return t[k - 3]; }
 };
 template <int DIGIT_MAX, bool STORE = false, class TW = TwUniform>
-__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c, const TW* pinned = nullptr, double* twb_ahead = nullptr)
+__device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], const WaveCtx& c, const TW* pinned = nullptr, double (*twb_ahead)[kTbCount] = nullptr)
 {
     using A0 = typename r4::FwdDigits<DIGIT_MAX>::A0;
     ct_exact_first_two(x);
@@ -687,10 +687,7 @@ __device__ __forceinline__ void ntt_forward_digits_a_r4(double (&x)[kRegs], cons
         r4::ct_pass_lo<A0, 3, 7>(x, TwUniform{c.gt->tu_fwd});
     } else {
         const TW& tw = *pinned;
-        if (twb_ahead) {          // the stage 4-7 twiddles of ntt_forward_digits_bc_r4, requested a pass ahead of their use
-            double (&t)[kTbCount] = *reinterpret_cast<double (*)[kTbCount]>(twb_ahead);
-            load_packed(t, c.tb_fwd);
-        }
+        if (twb_ahead) load_packed(*twb_ahead, c.tb_fwd);      // the stage 4-7 twiddles of ntt_forward_digits_bc_r4, requested a pass ahead of their use
         asm volatile("" ::: "memory");
         r4::Group<A0, false, 0>::ct(x, tw(3), tw(7), tw(8));
 #pragma unroll
