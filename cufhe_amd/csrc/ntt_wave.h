@@ -21,7 +21,11 @@
 //   B <-> C only exchanges lane bits 5:4 with two register bits: 32 v_permlane32/16_swap
 //   instructions, no LDS (measured 1.4 % faster than a second LDS round trip).
 //
-// Lazy-reduction schedule (bounds in units of p, see fpfield.h; checked on the host by
+// Two forms of the butterflies live here: the radix-2 stages below (key conversion, the workgroup-per-rotation kernels, the
+// N = 2048 half transforms) and, at the end of the file, the radix-4 passes of ntt_r4.h that blind_rotate_kernel and the
+// wave-per-rotation kernel of the parameter sets run (same layouts and layout changes; bounds per register at compile time).
+//
+// Lazy-reduction schedule of the radix-2 form (bounds in units of p, see fpfield.h; checked on the host by
 // tests/host/host_model.cpp through tests/test_fpfield.py):
 //   forward, gadget digits in (|x| <= 32): stages 0 and 1 are one exact radix-4 butterfly on the inputs (roots I, zeta and
 //            zeta^3 I = -zeta: values stay below 2^42.2 = 0.006 p, nothing is reduced); then
