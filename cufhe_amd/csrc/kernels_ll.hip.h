@@ -17,7 +17,8 @@
 //                the gadget decomposition of the NEXT step, all l digits as signed bytes (each row wave
 //                used to recompute the decomposed word of its coefficients: six times the same arithmetic,
 //                on the waves that set the length of the step)
-// Four workgroup barriers per step.  The NTT-domain key is read in its ordinary layout.
+// Four workgroup barriers per step; every wave keeps the twiddles of its role in registers for the whole kernel.  The NTT-domain
+// key is read in its ordinary layout.
 // The kernels of this file are compiled in their own translation unit (kernels_ll.hip, with
 // -mllvm -amdgpu-sched-strategy=max-ilp: 3.5 % faster here, while the same strategy costs the N = 512 parameter-set
 // kernel 4 %); capi.hip includes it with CUFHE_AMD_LL_DECLARATIONS_ONLY for the constants and the prototypes.
@@ -132,14 +133,19 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     double tu[7];                                             // this wave's stage 0-2 twiddles: forward for a row wave, inverse otherwise
 #pragma unroll
     for (int k = 0; k < 7; k++) tu[k] = row_wave ? gt2[h].tu_fwd[k] : gt2[h].tu_inv[k];
+    double twb[7], twc[7];                                    // ... and its per-lam / per-lane twiddles, fetched once (ntt_wave512.h)
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        twb[k] = lds_ld(row_wave ? ctx.tb_fwd : ctx.tb_inv, 64 * k);
+        twc[k] = lds_ld(row_wave ? ctx.tc_fwd : ctx.tc_inv, 512 * k);
+    }
     // The coefficient-wise tail of a step is spread over all 16 waves: wave k owns the slices (out, hh, rr) =
     // (m, k >> 3, k & 7), m = 0, 1, i.e. coefficients lane + 64 rr + 512 hh of accumulator component m.
     const int hh = wave >> 3, rr = wave & 7;
     const int ecoef = lane + 64 * rr + kH * hh;               // this lane's coefficient, both components
     // digits of (X^abar - 1) acc_m at ecoef for the CMux step `step`, w[m] = acc_m[ecoef]
     // (include/gatebootstrapping_gpu.cuh:157-181); byte (row, hh, lane, rr) of the digit table
-    auto decompose = [&](int step, const uint32_t (&w)[2]) {
-        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[step]);
+    auto decompose = [&](uint32_t abar, const uint32_t (&w)[2]) {
         const int alo = (int)(abar & (kN - 1));
         const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
         const int ridx = (ecoef - alo) & (kN - 1);
@@ -159,8 +165,11 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         uint32_t w[2];
 #pragma unroll
         for (int m = 0; m < 2; m++) w[m] = accL[m * 2 * kN + ecoef];
-        decompose(0, w);
+        decompose(__builtin_amdgcn_readfirstlane((uint32_t)abar_lds[0]), w);
     }
+    // abar of the coming steps in one VGPR per wave, 64 steps to a window, read with v_readlane: no LDS round trip (and no
+    // readfirstlane behind it) between the barrier after the accumulator update and the rotated read of the decomposition
+    uint32_t abar_win = abar_lds[lane];
     __syncthreads();
 
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
@@ -172,13 +181,15 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 #endif
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
+        if (((i + 1) & 63) == 0) abar_win = abar_lds[i + 1 + lane];       // entries 630..639 are padding, never used
+        const uint32_t abar_next = __builtin_amdgcn_readlane(abar_win, (i + 1) & 63);
         if (row_wave) {
             // digits of this row at e = lane + 64 r (word 0) and e + 512 (word 1), a signed byte each, left by the
             // inverse waves (out = wj); then the first stage of the transform
             const uint2 q0 = digL[(row * 2 + 0) * 64 + lane], q1 = digL[(row * 2 + 1) * 64 + lane];
             double x[kRegs8];
             ll_split_first_stages(x, q0, q1, h);
-            ntt512_forward_tu_from1(x, ctx, tu);
+            ntt512_forward_pinned_from1(x, ctx, tu, twb, twc);
             double* s0 = sumL + h * kH + lane;
 #pragma unroll
             for (int o = 0; o < 2; o++)
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             double* s = sumL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) { u[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-            ntt512_inverse_tu(u, ctx, tu);                    // u_h[e], e = lane + 64 r, |u| <= p
+            ntt512_inverse_pinned(u, ctx, tu, twb, twc);      // u_h[e], e = lane + 64 r, |u| <= p
             double* hd = handL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) hd[r * 64] = u[r];
@@ -230,10 +241,15 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         CUFHE_AMD_PHASE(4)
         __syncthreads();
         CUFHE_AMD_PHASE(5)
-        if (i + 1 < steps) decompose(i + 1, wnew);            // reads other waves' new words: after the barrier
+        if (i + 1 < steps) decompose(abar_next, wnew);        // reads other waves' new words: after the barrier
         CUFHE_AMD_PHASE(6)
         __syncthreads();
         CUFHE_AMD_PHASE(7)
+    }
+
+    if (acc_dump) {
+        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
+        for (int e = tid; e < kN; e += kLlThreads) { o[e] = accL[e]; o[kN + e] = accL[2 * kN + e]; }
     }
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
     if (acc_dump && lane == 0 && g == 0) {
@@ -242,11 +258,6 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         for (int k = 0; k < 8; k++) o[k] = ph[k];
     }
 #endif
-
-    if (acc_dump) {
-        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
-        for (int e = tid; e < kN; e += kLlThreads) { o[e] = accL[e]; o[kN + e] = accL[2 * kN + e]; }
-    }
     if (d.out) {
         uint32_t* o = d.out;      // __SampleExtractIndex__<P,0>
         for (int e = tid; e < kN; e += kLlThreads) {
@@ -349,6 +360,12 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     double tu[7];                                             // this wave's stage 0-2 twiddles: forward for a row wave, inverse otherwise
 #pragma unroll
     for (int k = 0; k < 7; k++) tu[k] = row_wave ? gt2[h].tu_fwd[k] : gt2[h].tu_inv[k];
+    double twb[7], twc[7];                                    // ... and its per-lam / per-lane twiddles, fetched once
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        twb[k] = lds_ld(row_wave ? ctx.tb_fwd : ctx.tb_inv, 64 * k);
+        twc[k] = lds_ld(row_wave ? ctx.tc_fwd : ctx.tc_inv, 512 * k);
+    }
     const int hh = wave >> 3, rr = wave & 7;
     const int ecoef = lane + 64 * rr + kH * hh;
 
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         const uint2 q0 = r.dig[(row * 2 + 0) * 64 + lane], q1 = r.dig[(row * 2 + 1) * 64 + lane];
         double x[kRegs8];
         ll_split_first_stages(x, q0, q1, h);
-        ntt512_forward_tu_from1(x, ctx, tu);
+        ntt512_forward_pinned_from1(x, ctx, tu, twb, twc);
         double* s0 = r.sum + h * kH + lane;
 #pragma unroll
         for (int o = 0; o < 2; o++)
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         double u[kRegs8];
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) u[k] = fpf::reduce(s[k * 64]);
-        ntt512_inverse_tu(u, ctx, tu);
+        ntt512_inverse_pinned(u, ctx, tu, twb, twc);
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) s[k * 64] = u[k];
         inv_sync();
@@ -483,20 +500,27 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     }
     __syncthreads();
 
+    // One loop per role (the role of a wave never changes): the registers of a row wave -- key row, twiddles, spectrum -- and
+    // those of an inverse wave are allocated separately instead of as the union of both over one loop.
+    //   slot 1: rows of A (step i) beside the tail of B's step i - 1 (inverse transforms, accumulator, digits of step i)
+    //   slot 2: rows of B (step i) beside the tail of A's step i
+    if (row_wave) {
 #pragma unroll 1
-    for (int i = 0; i < steps; i++) {
-        // slot 1: rows of A (step i) beside the tail of B's step i - 1 (inverse transforms, accumulator, digits of step i)
-        if (row_wave) row_phase(rot[0]);
-        else if (i > 0) inverse_chain(rot[1], i, true);
-        __syncthreads();
-        // slot 2: rows of B (step i) beside the tail of A's step i
-        if (row_wave) {
+        for (int i = 0; i < steps; i++) {
+            row_phase(rot[0]);
+            __syncthreads();
             row_phase(rot[1]);
             if (i + 1 < steps) load_row(i + 1);               // b is free
-        } else {
-            inverse_chain(rot[0], i + 1, i + 1 < steps);
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < steps; i++) {
+            if (i > 0) inverse_chain(rot[1], i, true);
+            __syncthreads();
+            inverse_chain(rot[0], i + 1, i + 1 < steps);
+            __syncthreads();
+        }
     }
     if (steps > 0) {      // B's last step
         if (!row_wave) inverse_chain(rot[1], steps, false);

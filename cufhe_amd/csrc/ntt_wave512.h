@@ -182,6 +182,34 @@ __device__ __forceinline__ void ntt512_inverse_tu(double (&x)[kRegs8], const Wav
     CUFHE_AMD_XPOSE8(c.b1, 64, c.a1, 8 * 68)          // B -> A
     gs_three_stages<1>(x, TwArr{tu});                 // s2 s1 (wide, reduce) s0: -> 1
 }
+// The same two transforms with ALL of the wave's twiddles held by the caller: a wave of the low-latency kernels keeps one role (row
+// or inverse) for the whole kernel, so the seven per-lam and seven per-lane twiddles of its direction are fetched once, not once per
+// CMux step (an inverse wave is alone on its SIMD: the fetch sat at the head of its dependent chain).
+__device__ __forceinline__ void ntt512_forward_pinned_from1(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7],
+                                                            const double (&twb)[7], const double (&twc)[7])
+{
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const double w = tu[1 + g];
+#pragma unroll
+        for (int r = 0; r < 2; r++) ct_bfly<false>(x[4 * g + r], x[4 * g + r + 2], w);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) ct_bfly<false>(x[2 * g], x[2 * g + 1], tu[3 + g]);
+    CUFHE_AMD_XPOSE8(c.a1, 8 * 68, c.b1, 64)          // A -> B
+    ct_three_stages<false>(x, TwArr{twb});
+    CUFHE_AMD_XPOSE8(c.b2, 64, c.c2, 8 * 72)          // B -> C
+    ct_three_stages<true>(x, TwArr{twc});
+}
+__device__ __forceinline__ void ntt512_inverse_pinned(double (&x)[kRegs8], const Wave512Ctx& c, const double (&tu)[7],
+                                                      const double (&twb)[7], const double (&twc)[7])
+{
+    gs_three_stages<-1>(x, TwArr{twc});               // s8 s7 s6: .5 -> 4
+    CUFHE_AMD_XPOSE8(c.c2, 8 * 72, c.b2, 64)          // C -> B
+    gs_three_stages<0>(x, TwArr{twb});                // s5 (wide, reduce) s4 s3: -> 2
+    CUFHE_AMD_XPOSE8(c.b1, 64, c.a1, 8 * 68)          // B -> A
+    gs_three_stages<1>(x, TwArr{tu});                 // s2 s1 (wide, reduce) s0: -> 1
+}
 __device__ __forceinline__ void ntt512_forward(double (&x)[kRegs8], const Wave512Ctx& c)
 {
     ct_three_stages<false>(x, TwUniform{c.gt->tu_fwd});

@@ -24,7 +24,7 @@ for count in (1, 256):
     w = acc.download()[: 2 * N].view(np.uint64)
     names = ["row work", "barrier 1", "inverse work", "barrier 2", "final stage", "barrier 3", "decompose", "barrier 4"]
     print(f"--- {count} rotation(s): cycles per step (630 steps), by wave")
-    for wave in (0, 1, 5, 11, 12, 13, 15):
+    for wave in (0, 3, 4, 7, 8, 11, 12, 15):
         c = w[16 + wave * 8: 16 + wave * 8 + 8] / 630.0
         print(f"wave {wave:2d}: " + "  ".join(f"{nm} {v:7.0f}" for nm, v in zip(names, c)) + f"   total {c.sum():7.0f}")
 eng.CleanUp()
