@@ -523,7 +523,7 @@ def main():
                 if len(lines) > 1:
                     res["api_pcie_inclusive"]["depth_first_netlist"] = lines[1]
                 if len(lines) > 2:
-                    res["api_pcie_inclusive"]["depth_first_netlist_renamed_outputs"] = lines[2]
+                    res["api_pcie_inclusive"]["depth_first_netlist_without_renaming"] = lines[2]
                 if len(lines) > 3:
                     res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = lines[3]
                 res["api_pcie_inclusive"]["what"] = ("4096 cufhe::Nand(out, a, b, st) on host-resident ciphertexts over 256 streams, "

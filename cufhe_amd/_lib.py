@@ -51,7 +51,7 @@ class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
                                                "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames",
-                                               "worker_cpus")]
+                                               "worker_cpus", "home_copies")]
 
 
 class GroupTrace(ctypes.Structure):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "cufhe_amd_enqueue_trlwe_op": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void]),
     "cufhe_amd_enqueue_cmux": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_int, c_void, c_void, c_void, c_void]),
     "cufhe_amd_trgsw_to_ntt_host": (ctypes.c_int, [ctypes.c_int, c_void, c_void, c_void]),
+    "cufhe_amd_trgsw_to_ntt": (ctypes.c_int, [ctypes.c_int, c_void, c_void, c_void]),
     "cufhe_amd_enqueue_copy": (ctypes.c_int, [ctypes.c_int, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_flush": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_sched_stream_query": (ctypes.c_int, [ctypes.c_int, c_void]),

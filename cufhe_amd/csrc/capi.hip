@@ -50,7 +50,10 @@ struct EventPair { hipEvent_t a, b; uint64_t units; };
 // Pinned host staging for descriptor uploads.  hipMemcpyAsync from pageable memory may
 // return before the bytes have been read, so descriptors are staged in pinned blocks that
 // are recycled only once the event recorded behind their copy has completed.
-struct PinnedBlock { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false; };
+// A block is free again when its owner has RECORDED `done` behind the last device access, that event has completed, and the owner
+// is not itself still reading the block on the host (`held`, cufhe_amd_trgsw_to_ntt_host): completion of a never-recorded or stale
+// event says nothing about the current owner.
+struct PinnedBlock { void* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; bool busy = false, recorded = false, held = false; };
 
 // Per-stream device workspace (temporaries + descriptor arrays of one launch sequence).
 // Work on one stream is ordered, so the next sequence on the same stream may overwrite the
@@ -400,8 +403,8 @@ int acquire_staging(DeviceState& s, size_t bytes, PinnedBlock** out)
 {
     std::lock_guard<std::mutex> lk(s.staging_mu);
     for (auto& b : s.staging) {
-        if (b.busy && hipEventQuery(b.done) == hipSuccess) b.busy = false;
-        if (!b.busy && b.bytes >= bytes) { b.busy = true; *out = &b; return 0; }
+        if (b.busy && b.recorded && !b.held && hipEventQuery(b.done) == hipSuccess) b.busy = false;
+        if (!b.busy && b.bytes >= bytes) { b.busy = true; b.recorded = false; b.held = false; *out = &b; return 0; }
     }
     PinnedBlock nb;
     nb.bytes = bytes < 65536 ? 65536 : bytes;
@@ -411,6 +414,19 @@ int acquire_staging(DeviceState& s, size_t bytes, PinnedBlock** out)
     s.staging.push_back(nb);
     *out = &s.staging.back();
     return 0;
+}
+// the owner's last device access to the block is on `st`: from its completion on the block may be handed out again
+int staging_done_after(DeviceState& s, PinnedBlock* blk, hipStream_t st)
+{
+    HIP_TRY(hipEventRecord(blk->done, st));
+    std::lock_guard<std::mutex> lk(s.staging_mu);
+    blk->recorded = true;
+    return 0;
+}
+void staging_hold(DeviceState& s, PinnedBlock* blk, bool held)
+{
+    std::lock_guard<std::mutex> lk(s.staging_mu);
+    blk->held = held;
 }
 
 template <class Desc>
@@ -424,8 +440,7 @@ int upload_descs(DeviceState& s, Scratch& sc, const std::vector<Desc>& h, Desc**
     if (int rc = acquire_staging(s, bytes, &blk)) return rc;
     memcpy(blk->host, h.data(), bytes);
     HIP_TRY(hipMemcpyAsync(*d, blk->host, bytes, hipMemcpyHostToDevice, sc.st));
-    HIP_TRY(hipEventRecord(blk->done, sc.st));
-    return 0;
+    return staging_done_after(s, blk, sc.st);
 }
 
 // HIP events around a launch sequence on its own stream (cufhe_amd_profile_enable): begin before, end after
@@ -1156,6 +1171,8 @@ int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_
     if (int rc = sc.alloc((void**)&d_out, out_bytes)) return rc;
     PinnedBlock* blk = nullptr;
     if (int rc = acquire_staging(s, in_bytes + out_bytes, &blk)) return rc;
+    staging_hold(s, blk, true);          // the host reads the result out of the block after the stream has finished with it
+    struct Release { DeviceState& s; PinnedBlock* b; ~Release() { staging_hold(s, b, false); } } release{s, blk};
     memcpy(blk->host, trgsw_host, in_bytes);
     HIP_TRY(hipMemcpyAsync(d_in, blk->host, in_bytes, hipMemcpyHostToDevice, st));
     const unsigned blocks = (unsigned)((kBkPolysPerStep + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
@@ -1164,7 +1181,7 @@ int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_
     HIP_TRY(hipGetLastError());
     char* pin_out = (char*)blk->host + in_bytes;
     HIP_TRY(hipMemcpyAsync(pin_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(blk->done, st));
+    if (int rc = staging_done_after(s, blk, st)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     memcpy(trgsw_ntt_host, pin_out, out_bytes);
     return device_fault(device);

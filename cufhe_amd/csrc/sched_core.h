@@ -122,7 +122,16 @@ inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanosec
 // `tlwehost` plus one device buffer per GPU, and the bookkeeping that orders recorded accesses.
 struct cufhe_amd_ctxt {
     struct PerDev {
-        uint32_t* dev = nullptr;
+        uint32_t* dev = nullptr;    // the buffer that holds (or will hold) the current value
+        // Renaming (DeviceSched::rename_outputs): `home` is the buffer the ciphertext was created with -- the pointer the
+        // reference publishes as Ctxt::tlwedevices[i] (include/cufhe_gpu.cuh:80-84).  While dev != home the value lives in a
+        // renamed buffer; it is copied back before the host can observe completion (restore_homes), so that `home` holds
+        // the value whenever the caller may look.  home_deps: the recorded levels that still name `home` (the write and the
+        // reads of the value it held when the ciphertext was renamed away from it).
+        uint32_t* home = nullptr;
+        std::vector<uint32_t> home_deps;
+        void* wstream = nullptr;    // caller stream of the newest recorded gate write (completion of that stream must cover the copy back)
+        int renamed_idx = -1;       // position in DeviceSched::renamed_
         uint32_t ready = 0;         // depth from which a gate may read `dev` (0: resident since long)
         uint32_t wdepth = 0;        // depth of the newest recorded write of `dev` (0: none on record)
         bool w_upload = false;      // ... which was an upload (runs before the gates of its level)
@@ -167,6 +176,7 @@ struct Stats {
     uint64_t max_level_gates = 0;
     uint64_t cross_stream_waits = 0;
     uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
+    uint64_t home_copies = 0;         // renamed values copied back to the ciphertext's own buffer before the host could look
     std::atomic<uint64_t> worker_cpus{0};   // CPUs the launch worker is pinned to
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
@@ -177,7 +187,7 @@ struct Stats {
     {
         gates = o.gates; groups = o.groups; levels = o.levels; launch_sequences = o.launch_sequences;
         uploads = o.uploads; uploads_shared = o.uploads_shared; downloads = o.downloads; forced_syncs = o.forced_syncs;
-        max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits; renames = o.renames;
+        max_level_gates = o.max_level_gates; cross_stream_waits = o.cross_stream_waits; renames = o.renames; home_copies = o.home_copies;
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
         worker_cpus.store(o.worker_cpus.load());
@@ -284,6 +294,11 @@ class DeviceSched {
     int record_gate(void* stream, int op, bool copying, cufhe_amd_ctxt* out, cufhe_amd_ctxt* const (&ins)[3], int kind = -1);
     int record_copy(void* stream, cufhe_amd_ctxt* c, bool to_device);
     int flush(size_t max_levels = (size_t)-1);
+    int flush_for_completion()                 // the caller is about to wait for everything: renamed values go home in the same flush
+    {
+        restore_homes(nullptr);
+        return flush();
+    }
     int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
     int synchronize();
     void forget_stream(void* stream)
@@ -334,20 +349,52 @@ class DeviceSched {
     // Renaming: an output whose device buffer still has recorded users (an earlier write not yet superseded, readers of
     // the old value) takes a FRESH buffer instead of waiting for them, so that only true data dependences order the
     // program (a temporary re-used down a ripple-carry chain no longer serialises the adders' independent gates).  The
-    // old buffer is recycled once the last level naming it has retired.  The device pointer of a ciphertext
-    // (cufhe_amd_ctxt_device_ptr, Ctxt::tlwedevices) is then no longer constant: off unless asked for.
-    bool rename_outputs = false;
+    // old buffer is recycled once every level up to the last one naming it has retired.  The buffer a ciphertext was
+    // created with (Ctxt::tlwedevices[i], include/cufhe_gpu.cuh:80-84) stays its HOME: it is never recycled while the
+    // ciphertext lives, a later write returns to it when nothing recorded names it any more, and a value still living in a
+    // renamed buffer when the caller asks for completion (Synchronize, StreamQuery of the stream that wrote it) is copied
+    // home first -- one Copy gate per such ciphertext in the flush that the request triggers -- so that the published
+    // pointer holds the value whenever the host is entitled to look, exactly as without renaming.  TLWE ciphertexts only
+    // (the copy back is an ordinary Copy gate of the ciphertext's level).
+    bool rename_outputs = true;
+    int copy_op = 13;                  // the op code of Copy (CUFHE_AMD_COPY) in GateRef::op
+    void forget_renamed(cufhe_amd_ctxt* c)        // the ciphertext goes away: nothing to copy home any more
+    {
+        cufhe_amd_ctxt::PerDev& pd = c->d[device_];
+        if (pd.renamed_idx < 0) return;
+        cufhe_amd_ctxt* last = renamed_.back();
+        renamed_[(size_t)pd.renamed_idx] = last;
+        last->d[device_].renamed_idx = pd.renamed_idx;
+        renamed_.pop_back();
+        pd.renamed_idx = -1;
+    }
+    // every level up to `depth` has completed and been retired (groups retire out of order and run on different internal
+    // streams: the newest level naming a buffer being done does not mean that an older reader in another group is)
+    bool all_done_through(uint32_t depth)
+    {
+        if (depth == 0) return true;
+        if (depth >= base_depth_) return false;
+        return live_.empty() || live_.front()->first_depth > depth;
+    }
 
    private:
     struct StreamState { uint32_t max_depth = 0; std::vector<uint64_t> open; };
     struct Buf { void* p; size_t cap; };
     struct RetiredBuf { uint32_t* p; int level; uint32_t last_use; };      // renamed-away buffers still named by recorded levels
     std::vector<RetiredBuf> retired_;
+    std::vector<cufhe_amd_ctxt*> renamed_;        // live ciphertexts whose value is in a renamed buffer on this device
+    int restore_homes(void* only_stream);         // record the copies back (all, or those last written on one caller stream)
+    static uint32_t max_depth_of(const std::vector<uint32_t>& v)
+    {
+        uint32_t m = 0;
+        for (uint32_t d : v) m = std::max(m, d);
+        return m;
+    }
     void collect_retired()
     {
         size_t k = 0;
         for (const RetiredBuf& r : retired_) {
-            if (done(r.last_use)) slot_free(r.level, r.p);
+            if (all_done_through(r.last_use)) slot_free(r.level, r.p);
             else retired_[k++] = r;
         }
         retired_.resize(k);
@@ -553,6 +600,7 @@ class Scheduler {
                 delete c;
                 return rc;
             }
+        for (size_t d = 0; d < devs_.size(); d++) c->d[d].home = c->d[d].dev;
         live_ctxts_++;
         c->owner = this;
         *out = c;
@@ -574,6 +622,7 @@ class Scheduler {
         }
         c->destroyed = true;
         c->host = nullptr;
+        for (size_t d = 0; d < devs_.size(); d++) devs_[d]->forget_renamed(c);
         if (!collect(c)) zombies_.push_back(c);
     }
     // called when levels retire: release destroyed ciphertexts that nothing recorded names any more
@@ -603,12 +652,29 @@ class Scheduler {
         }
         return 0;
     }
+    // The CALLER is about to overwrite c's tlwehost itself, now (TRGSW2NTT fills trgswhost synchronously,
+    // src/bootstrap_gpu.cu:75-94) -- not through a recorded delivery.  A result still on its way to that memory must land
+    // first, recorded uploads that have not read it yet must read the old words first, and no device may go on taking
+    // what it holds for "the current tlwehost".
+    int before_direct_host_write(cufhe_amd_ctxt* c)
+    {
+        if (c->host_dev >= 0)
+            if (int rc = devs_[c->host_dev]->synchronize()) return rc;
+        for (size_t e = 0; e < devs_.size(); e++) {
+            cufhe_amd_ctxt::PerDev& pe = c->d[e];
+            pe.snap_plan = nullptr;
+            pe.snap_owned = false;
+            if (pe.last_upload && !devs_[e]->uploads_copied(pe.last_upload))
+                if (int rc = devs_[e]->flush_and_copy()) return rc;
+        }
+        return 0;
+    }
     int synchronize_all()
     {
         // hand every device its recorded work first, then wait: the devices run concurrently
         int rc = 0;
         for (auto& d : devs_)
-            if (int r = d->flush()) rc = rc ? rc : r;
+            if (int r = d->flush_for_completion()) rc = rc ? rc : r;
         for (auto& d : devs_)
             if (int r = d->synchronize()) rc = rc ? rc : r;
         return rc;
@@ -618,8 +684,10 @@ class Scheduler {
     bool collect(cufhe_amd_ctxt* c);            // release c if no recorded or in-flight level names it
     void ctxt_release(cufhe_amd_ctxt* c)
     {
-        for (size_t d = 0; d < c->d.size() && d < devs_.size(); d++)
+        for (size_t d = 0; d < c->d.size() && d < devs_.size(); d++) {
             if (c->d[d].dev) devs_[d]->slot_free(c->level, c->d[d].dev);
+            if (c->d[d].home && c->d[d].home != c->d[d].dev) devs_[d]->slot_free(c->level, c->d[d].home);
+        }
         delete[] c->shadow.load();
         delete c;
         live_ctxts_--;
@@ -633,8 +701,11 @@ class Scheduler {
 
 inline bool Scheduler::collect(cufhe_amd_ctxt* c)
 {
-    for (size_t d = 0; d < devs_.size(); d++)
-        if (!devs_[d]->level_done(c->d[d].last_use)) return false;
+    for (size_t d = 0; d < devs_.size(); d++) {
+        if (!devs_[d]->all_done_through(c->d[d].last_use)) return false;
+        for (uint32_t dd : c->d[d].home_deps)
+            if (!devs_[d]->all_done_through(dd)) return false;
+    }
     ctxt_release(c);
     return true;
 }
@@ -781,8 +852,15 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     const uint32_t* const in_dev[3] = {ins[0]->d[device_].dev, ins[1] ? ins[1]->d[device_].dev : nullptr,
                                        ins[2] ? ins[2]->d[device_].dev : nullptr};
     uint32_t* fresh = nullptr;
-    if (rename_outputs && D > Din && slot_alloc(out->level, &fresh) == 0) D = Din;
-    else fresh = nullptr;
+    bool back_home = false;
+    if (rename_outputs && D > Din && out->level <= 1) {
+        if (po.dev != po.home && all_done_through(max_depth_of(po.home_deps))) {
+            fresh = po.home;                                          // nothing recorded names the home buffer any more
+            back_home = true;
+            D = Din;
+        } else if (slot_alloc(out->level, &fresh) == 0) D = Din;
+        else fresh = nullptr;
+    }
 
     Plan& p = plan_at(D);
     for (int i = 0; i < 3; i++) {
@@ -799,7 +877,23 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
         if (ins[i]) add_reader(ins[i]->d[device_], D);
     if (fresh) {
         // the old buffer keeps serving the levels that name it (this gate included, if it is in place)
-        retired_.push_back({po.dev, out->level, po.last_use});
+        if (po.dev == po.home) {
+            // leaving home: remember who still names it -- the write and the reads of the value it holds, and this gate
+            po.home_deps.clear();
+            if (po.wdepth) po.home_deps.push_back(po.wdepth);
+            for_readers(po, [&](uint32_t r) { po.home_deps.push_back(r); });
+            if (po.last_use) po.home_deps.push_back(po.last_use);
+            for (int i = 0; i < 3; i++)
+                if (ins[i] == out) po.home_deps.push_back(D);
+            po.renamed_idx = (int)renamed_.size();
+            renamed_.push_back(out);
+        } else {
+            retired_.push_back({po.dev, out->level, std::max(po.last_use, D)});
+            if (back_home) {
+                po.home_deps.clear();
+                forget_renamed(out);
+            }
+        }
         po.dev = fresh;
         po.last_use = 0;
         stats_.renames++;
@@ -812,6 +906,7 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     clear_readers(po);
     po.snap_plan = nullptr;
     po.snap_owned = false;
+    po.wstream = stream;
     use(po, D);
     p.gates[kind].push_back(GateRef{op, po.dev, in_dev[0], in_dev[1], in_dev[2]});
     if (copying) {
@@ -858,6 +953,37 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
     c->host_token = token;
     stats_.downloads++;
     note_stream(p, stream, D);
+    return 0;
+}
+
+// The caller is about to observe completion (Synchronize, or StreamQuery of `only_stream`): every value that lives in a
+// renamed buffer goes back to the buffer its ciphertext was created with, as one Copy gate per ciphertext at the first level
+// that follows the value's producer and the last recorded users of the home buffer.
+inline int DeviceSched::restore_homes(void* only_stream)
+{
+    for (size_t k = 0; k < renamed_.size();) {
+        cufhe_amd_ctxt* c = renamed_[k];
+        cufhe_amd_ctxt::PerDev& pd = c->d[device_];
+        if (only_stream && pd.wstream != only_stream) { k++; continue; }
+        uint32_t D = std::max(base_depth_, pd.ready);
+        D = std::max(D, max_depth_of(pd.home_deps) + 1);
+        Plan& p = plan_at(D);
+        add_dep(p, pd.wdepth);
+        for (uint32_t dd : pd.home_deps) add_dep(p, dd);
+        p.gates[c->level].push_back(GateRef{copy_op, pd.home, pd.dev, nullptr, nullptr});
+        retired_.push_back({pd.dev, c->level, std::max(pd.last_use, D)});
+        pd.dev = pd.home;
+        pd.home_deps.clear();
+        pd.wdepth = D;                 // same value, same version: a result on its way to tlwehost still matches
+        pd.w_upload = false;
+        pd.ready = D + 1;
+        clear_readers(pd);
+        pd.last_use = D;
+        note_stream(p, pd.wstream, D);
+        pending_gates_++;
+        stats_.home_copies++;
+        forget_renamed(c);             // swaps the last entry into k
+    }
     return 0;
 }
 
@@ -1151,6 +1277,7 @@ inline int DeviceSched::retire(Group* g)
 
 inline int DeviceSched::synchronize()
 {
+    restore_homes(nullptr);
     if (int rc = flush()) return rc;
     wait_worker_idle();
     be_->bind_thread();
@@ -1179,7 +1306,8 @@ inline int DeviceSched::stream_query(void* stream)
 {
     auto it = streams_.find(stream);
     if (it == streams_.end()) return 1;
-    StreamState& ss = it->second;                 // references survive a rehash, iterators do not
+    restore_homes(stream);
+    StreamState& ss = streams_[stream];           // references survive a rehash, iterators do not
     if (ss.max_depth >= base_depth_)
         if (int rc = flush()) return rc;          // it can only complete once it has been launched
     be_->bind_thread();

@@ -14,7 +14,7 @@ long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
 long g_sched_level_gates = 4096; // a dependence level this full is launched at once (two rounds of the batch kernel's grid)
 long g_sched_total_gates = 32768;
-long g_sched_rename = 0;          // 1: outputs take fresh device buffers instead of waiting for the old one's users (sched_core.h)
+long g_sched_rename = 1;          // outputs take fresh device buffers instead of waiting for the old one's users, values return to the ciphertext's own buffer before the host may look (sched_core.h); 0: never
 long g_sched_zero_copy = 1;       // 1: ciphertext staging is read / written by the scatter / gather kernels in pinned host memory (no copy-engine step)
 long g_sched_affinity = 1;        // 1: a device's launch worker runs on the CPUs local to that GPU (NUMA node of its PCI function)
 
@@ -258,6 +258,7 @@ sched::Scheduler* scheduler()
             g_scheduler->dev(d).idle_flush_gates = (size_t)std::min(g_sched_level_gates, 2048L);
             g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
             g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
+            g_scheduler->dev(d).copy_op = CUFHE_AMD_COPY;
         }
     }
     return g_scheduler;
@@ -334,7 +335,7 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
 uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)
 {
     if (!c || device < 0 || device >= (int)c->d.size()) return nullptr;
-    return c->d[device].dev;
+    return c->d[device].home;       // the ciphertext's own buffer: holds its value whenever completion has been observed (sched_core.h)
 }
 
 static int sched_check_ctxt(sched::Scheduler* S, cufhe_amd_ctxt* c)
@@ -392,6 +393,25 @@ int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cu
     if (!g_dev[device].keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
     cufhe_amd_ctxt* ins[3] = {in, nullptr, nullptr};
     if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins, 2)) return sched_error(S->dev(device), rc);
+    return 0;
+}
+
+/* TRGSW2NTT (src/bootstrap_gpu.cu:75-94) on a TRGSW holder (ciphertext handle of level 3): the reference leaves the NTT-domain words
+ * in trgswhost AND in trgswdevices[st.device_id()].  The holder's host words are rewritten here, synchronously, so the scheduler is
+ * told first (recorded uploads of the old words read them before they change; snapshots of "the current trgswhost" are dropped), and
+ * the upload of the new words to the stream's device is recorded like a CtxtCopyH2D: a following gCMUXNTT finds them in the device
+ * buffer, a following CMUXNTT does not take an older upload for current. */
+int cufhe_amd_trgsw_to_ntt(int device, void* stream, const uint32_t* trgsw_host, cufhe_amd_ctxt* out)
+{
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (int rc = check_device(device)) return rc;
+    if (!trgsw_host || !out) return fail(-1, "null pointer");
+    sched::Scheduler* S = scheduler();
+    if (int rc = sched_check_ctxt(S, out)) return rc;
+    if (out->level != 3) return fail(-1, "TRGSW2NTT needs a TRGSW holder (ciphertext handle of level 3)");
+    if (int rc = S->before_direct_host_write(out)) return fail(rc, "scheduler: flushing a device ahead of TRGSW2NTT failed");
+    if (int rc = cufhe_amd_trgsw_to_ntt_host(device, stream, trgsw_host, reinterpret_cast<double*>(out->host))) return rc;
+    if (int rc = S->dev(device).record_copy(stream, out, true)) return sched_error(S->dev(device), rc);
     return 0;
 }
 
@@ -464,6 +484,7 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->forced_syncs = s.forced_syncs; out->max_level_gates = s.max_level_gates; out->cross_stream_waits = s.cross_stream_waits;
     out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
     out->renames = s.renames;
+    out->home_copies = s.home_copies;
     out->worker_cpus = s.worker_cpus.load();
     if (reset) {
         const uint64_t cpus = s.worker_cpus.load();      // a property of the worker thread, not a counter

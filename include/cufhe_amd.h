@@ -110,7 +110,7 @@ int cufhe_amd_gate_list(int device, void* stream, int level, size_t count, const
 typedef struct cufhe_amd_ctxt cufhe_amd_ctxt;
 int cufhe_amd_ctxt_create(int level, uint32_t* host_words, cufhe_amd_ctxt** out);
 int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c);
-uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);
+uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);   /* constant for the life of the ciphertext */
 /* Nand(out, in0, in1, st) ... NMux, Not, Copy (copying != 0: src/cufhe_gates_gpu.cu:148-158,
  * inputs taken from tlwehost, result delivered to out's tlwehost) and gNand ... (copying == 0:
  * :160-167, device buffers only).  The gate is RECORDED with its data dependences; the recorded
@@ -156,6 +156,7 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t launch_ns;             /* host time on the device's launch worker */
     uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
     uint64_t worker_cpus;           /* CPUs the device's launch worker is pinned to (0: not pinned; "sched_affinity") */
+    uint64_t home_copies;           /* renamed values copied back to the ciphertext's own buffer before the host could look */
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 /* Timeline of the most recent flushes of a device (oldest first, at most 64 kept): host times are std::chrono::steady_clock
@@ -204,6 +205,10 @@ int cufhe_amd_trgsw_to_ntt_batch(int device, void* stream, size_t count, const u
  * comes from the stream's workspace and recycled pinned blocks -- no allocation per call.  trgsw_host: (k+1)l (k+1) N
  * torus words; trgsw_ntt_host: as many doubles. */
 int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_host, double* trgsw_ntt_host);
+/* TRGSW2NTT on a TRGSW holder (ciphertext handle of level 3, struct cuFHETRGSWNTTlvl1): fills the holder's host words (complete
+ * on return) and records their upload to the stream's device, so that both CMUXNTT forms see them -- the reference leaves the
+ * result in trgswhost and trgswdevices[st.device_id()] (src/bootstrap_gpu.cu:75-94).  Ordered against recorded uses of the holder. */
+int cufhe_amd_trgsw_to_ntt(int device, void* stream, const uint32_t* trgsw_host, cufhe_amd_ctxt* trgswntt);
 /* CMUXNTT (src/bootstrap_gpu.cu:197-285): res = c0 + trgsw [x] (c1 - c0), TRLWEs [count][2N]; res may be c0 or c1 */
 int cufhe_amd_cmux_batch(int device, void* stream, size_t count, const double* trgsw_ntt,
                          const uint32_t* c1, const uint32_t* c0, uint32_t* res);
@@ -250,12 +255,14 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * "sched_streams" (default 4): internal HIP streams per device over which independent flushes of the
  * per-gate API overlap; "sched_threads" (default 1): one launch worker thread per device (0: launches
  * happen on the issuing thread).  Both before the first ciphertext is created.
- * "sched_rename" (default 0): 1 = an output whose device buffer still has recorded users (an earlier write,
+ * "sched_rename" (default 1): an output whose device buffer still has recorded users (an earlier write,
  * readers of the old value) takes a fresh buffer instead of being ordered after them, so that only true data
  * dependences order a recorded program: a temporary re-used down a ripple-carry chain no longer serialises the
- * independent gates of the adders (16-bit adders: 64 dependence levels become 33).  The pointer returned by
- * cufhe_amd_ctxt_device_ptr (Ctxt::tlwedevices in the C++ shim) is then only valid until the ciphertext is next
- * written; results, tlwehost and every API call behave the same.
+ * independent gates of the adders (16-bit adders: 64 dependence levels become 33).  The buffer a ciphertext was created
+ * with (cufhe_amd_ctxt_device_ptr at construction = Ctxt::tlwedevices[i], include/cufhe_gpu.cuh:80-84) stays its home: a
+ * value still in a renamed buffer when the caller asks for completion (Synchronize, StreamQuery of the stream that wrote
+ * it) is copied home by one Copy gate in the flush that request triggers, so the published pointer holds the value
+ * whenever the host may look -- results, tlwehost, tlwedevices and every API call behave as with 0 (never rename).
  * "sched_level_gates" (default 4096 while the device has work -- 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s --, 2048 when it is idle) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program.
  * "sched_zero_copy" (default 1): the batched ciphertext traffic of a flush is read and written by the scatter / gather kernels

@@ -189,7 +189,7 @@ struct Ctxt {
     Ctxt& operator=(const Ctxt&) = delete;
 
     alignas(64) TFHEpp::TLWE<P> tlwehost;
-    std::vector<typename P::T*> tlwedevices;   // as of construction; with "sched_rename" on ask cufhe_amd_ctxt_device_ptr(handle, i)
+    std::vector<typename P::T*> tlwedevices;   // the ciphertext's own device buffers: they hold its value whenever completion has been observed
     cufhe_amd_ctxt* handle = nullptr;
 };
 
@@ -271,10 +271,12 @@ struct cuFHETRGSWNTTlvl1 {
 };
 
 /// TRGSW2NTT, src/bootstrap_gpu.cu:75-94: torus-domain TRGSW -> trgswntt.trgswhost, complete on return (the reference
-/// waits for its D2H as well).  Staging is pooled inside the library: nothing is allocated per call.
+/// waits for its D2H as well), and -- as in the reference -- trgswntt.trgswdevices[st.device_id()]: the upload is recorded on
+/// the holder's handle, so gCMUXNTT finds the words on the device and a holder refilled between two CMUXNTT calls is
+/// re-uploaded for the second.  Staging is pooled inside the library: nothing is allocated per call.
 inline void TRGSW2NTT(cuFHETRGSWNTTlvl1& trgswntt, const TFHEpp::TRGSW<TFHEpp::lvl1param>& trgsw, Stream& st)
 {
-    CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt_host(st.device_id(), st.st(), reinterpret_cast<const uint32_t*>(trgsw.data()), trgswntt.trgswhost.data()));
+    CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt(st.device_id(), st.st(), reinterpret_cast<const uint32_t*>(trgsw.data()), trgswntt.handle));
 }
 /// gGateBootstrappingTLWE2TRLWElvl01NTT / GateBootstrappingTLWE2TRLWElvl01NTT, src/cufhe_gates_gpu.cu:86-104
 inline void gGateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)

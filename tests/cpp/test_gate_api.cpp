@@ -30,6 +30,7 @@ static cufhe_amd_sched_stats all_stats()
         cufhe_amd_sched_stats s;
         CUFHE_AMD_CHECK(cufhe_amd_sched_get_stats(d, &s, 1));
         sum.gates += s.gates; sum.launch_sequences += s.launch_sequences; sum.levels += s.levels; sum.groups += s.groups;
+        sum.renames += s.renames; sum.home_copies += s.home_copies;
     }
     return sum;
 }
@@ -205,9 +206,24 @@ void RippleAdders(std::mt19937& eng)
         bad += got != va[i] + vb[i];
     }
     cufhe_amd_sched_stats stats = all_stats();
-    if (stats.launch_sequences > 40 * (uint64_t)GetGPUNum()) bad++;
-    std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums, %llu launch sequences)\n",
-                bad ? "FAIL" : "PASS", bad, kAdders, (unsigned long long)stats.launch_sequences);
+    // renaming (the default): the re-used temporaries no longer order the program, two levels per bit + the level of copies home
+    const bool renaming = !getenv("CUFHE_AMD_NO_SCHED_RENAME");
+    if (stats.launch_sequences > (renaming ? 2 * kBits + 2 : 40) * (uint64_t)GetGPUNum()) bad++;
+    if ((stats.renames > 0) != renaming) bad++;
+    // Ctxt::tlwedevices (include/cufhe_gpu.cuh:80-84) is a public member: after Synchronize() the buffer it names holds the
+    // ciphertext, whether or not the scheduler kept the value somewhere else on the way
+    int stale = 0;
+    for (int i = 0; i < kAdders; i++)
+        for (Ctxt<P>* c : {&t1[i], &t2[i], &carry[i]}) {
+            TFHEpp::TLWE<P> dev{};
+            const int d = st[i].device_id();
+            CUFHE_AMD_CHECK(cufhe_amd_memcpy_d2h(d, nullptr, dev.data(), c->tlwedevices[d], sizeof(dev)));
+            CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(d, nullptr));
+            stale += dev != c->tlwehost;
+        }
+    bad += stale;
+    std::printf("16 x 8-bit ripple-carry adders (640 dependent gates): %s (%d/%d wrong sums, %llu launch sequences, %llu renames, %d stale tlwedevices)\n",
+                bad ? "FAIL" : "PASS", bad, kAdders, (unsigned long long)stats.launch_sequences, (unsigned long long)stats.renames, stale);
     g_failures += bad;
     for (int i = 0; i < kAdders; i++) st[i].Destroy();
     delete[] st;
@@ -287,6 +303,23 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         Synchronize();
         bad += coeff0(res) != (g_s0[i] ? bit : 1 - bit); total++;
         bad += coeff0(res2) != 1 - bit; total++;   // either branch holds 1 - bit
+        // TRGSW2NTT leaves the words on the stream's device as well (src/bootstrap_gpu.cu:75-94): the device-resident form
+        // must find them there (t, t_other are on the device since the operations above)
+        cuFHETRLWElvl1 res3;
+        gCMUXNTT(res3, cs, t, t_other, st);
+        CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), res3.handle, 0));
+        // the holder refilled between two unsynchronised CMUXNTT calls: the first must use the old selector, the second the new
+        const int i2 = (i + 1 + (int)(eng() % 600)) % 630;
+        TRGSW<lvl1param> trgsw2;
+        std::memcpy(trgsw2.data(), bk.data() + (size_t)i2 * ORC_BK_ROWS * 2 * ORC_N, sizeof(trgsw2));
+        cuFHETRLWElvl1 res4, res5;
+        CMUXNTT(res4, cs, t, t_other, st);         // s0[i]  ? t : t_other
+        TRGSW2NTT(cs, trgsw2, st);
+        CMUXNTT(res5, cs, t, t_other, st);         // s0[i2] ? t : t_other
+        Synchronize();
+        bad += coeff0(res3) != (g_s0[i] ? bit : 1 - bit); total++;
+        bad += coeff0(res4) != (g_s0[i] ? bit : 1 - bit); total++;
+        bad += coeff0(res5) != (g_s0[i2] ? bit : 1 - bit); total++;
     }
     std::printf("TRLWE-level primitives: %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, total);
     g_failures += bad;
@@ -397,8 +430,8 @@ int main(int argc, char** argv)
     // more logical GPUs than the box has (test/test_gate_gpu_multi.cc hard-codes gpuNum = 2): every logical device
     // keeps its own keys, scheduler, launch thread and streams, several of them on one physical GPU
     if (getenv("CUFHE_AMD_SHARE_DEVICES")) CUFHE_AMD_CHECK(cufhe_amd_set_option("share_devices", 1));
-    // the whole program again with outputs taking fresh device buffers (include/cufhe_amd.h, "sched_rename")
-    if (getenv("CUFHE_AMD_SCHED_RENAME")) CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 1));
+    // the whole program again with every output waiting for the users of its buffer (include/cufhe_amd.h, "sched_rename" 0)
+    if (getenv("CUFHE_AMD_NO_SCHED_RENAME")) CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 0));
     SetGPUNum(gpus);
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     ReferenceGlobals(gpus);

@@ -20,7 +20,8 @@
 using namespace cufhe_amd::sched;
 
 static const int kWords[3] = {37, 53, 71};  // toy ciphertext sizes (odd on purpose): lvl0, lvl1, TRLWE
-enum { OP_NOT = 12, OP_COPY = 13, OP_MUX = 10, OP_NMUX = 11, TL_BOOT = 100, TL_REFRESH = 101, TL_SEIKS = 102 };
+enum { OP_NOT = 12, OP_COPY = 13, OP_MUX = 10, OP_NMUX = 11, TL_BOOT = 100, TL_REFRESH = 101, TL_SEIKS = 102,
+       OP_HOME_COPY = 99 };     // DeviceSched::copy_op here: the scheduler's own copy of a renamed value back to the ciphertext's buffer (the user-visible ops, Copy included, are word mixers)
 static int tl_in_level(int op) { return op == TL_BOOT ? 0 : 2; }
 static int tl_out_level(int op) { return op == TL_SEIKS ? 0 : 2; }
 
@@ -32,6 +33,7 @@ static uint32_t mix(int op, uint32_t a, uint32_t b, uint32_t c, uint32_t w)
 }
 static void toy_gate(int op, int level, uint32_t* out, const uint32_t* a, const uint32_t* b, const uint32_t* c)
 {
+    if (op == OP_HOME_COPY) { memmove(out, a, kWords[level] * 4); return; }
     if (op >= TL_BOOT) {      // TRLWE-level operations map between ciphertext kinds
         const int wi = kWords[tl_in_level(op)], wo = kWords[tl_out_level(op)];
         std::vector<uint32_t> r(wo);
@@ -165,7 +167,11 @@ struct Test {
     Scheduler* S;
     std::vector<FakeBackend*> be;
     std::mt19937_64 rng;
-    struct C { cufhe_amd_ctxt* h; std::vector<uint32_t> host; ModelCtxt m; void* last_host_writer_stream = nullptr; bool alive = true; };
+    struct C {
+        cufhe_amd_ctxt* h; std::vector<uint32_t> host; ModelCtxt m; void* last_host_writer_stream = nullptr; bool alive = true;
+        std::vector<uint32_t*> home;                   // the device pointers as of creation: what the reference publishes as tlwedevices
+        std::vector<void*> last_dev_writer_stream;     // per device: the caller stream of the newest gate that wrote the device value
+    };
     std::vector<C*> ct;
     int failures = 0;
 
@@ -176,7 +182,7 @@ struct Test {
             be.push_back(b);
             return b;
         });
-        for (int d = 0; d < gpus; d++) S->dev(d).rename_outputs = g_rename;
+        for (int d = 0; d < gpus; d++) { S->dev(d).rename_outputs = g_rename; S->dev(d).copy_op = OP_HOME_COPY; }
     }
     ~Test()
     {
@@ -195,6 +201,8 @@ struct Test {
         c->m.host = c->host;
         c->m.dev.assign(G, std::vector<uint32_t>(kWords[level], 0));
         c->m.dev_defined.assign(G, false);
+        for (int d = 0; d < G; d++) c->home.push_back(c->h->d[d].dev);
+        c->last_dev_writer_stream.assign(G, nullptr);
         ct.push_back(c);
         return c;
     }
@@ -211,6 +219,7 @@ struct Test {
         toy_gate(op, out->m.level, r.data(), a->m.dev[dev].data(), b ? b->m.dev[dev].data() : nullptr, c3 ? c3->m.dev[dev].data() : nullptr);
         out->m.dev[dev] = r;
         out->m.dev_defined[dev] = true;
+        out->last_dev_writer_stream[dev] = st;
         if (copying) { out->m.host = r; out->last_host_writer_stream = st; }
     }
     void copy(int dev, void* st, C* c, bool to_device)
@@ -226,6 +235,17 @@ struct Test {
             printf("FAIL host mismatch (%s) ctxt %p level %d\n", when, (void*)c, c->m.level);
         }
     }
+    // StreamQuery(st) returned true: what gates on st wrote must be in the ciphertexts' OWN device buffers (the pointers
+    // published at creation), renaming or not.  Uploads do not count: copy() / copying gates write the device value too,
+    // but only a gate's write can have been renamed away.
+    void check_home_after_query(int dev, void* st)
+    {
+        for (auto* b : be) b->drain();
+        for (C* c : ct) {
+            if (!c->alive || c->last_dev_writer_stream[dev] != st || !c->m.dev_defined[dev]) continue;
+            if (c->h->d[dev].dev != c->home[dev]) { failures++; printf("FAIL ctxt %p still renamed after StreamQuery\n", (void*)c); }
+        }
+    }
     void sync_and_check(bool check_dev)
     {
         if (int rc = S->synchronize_all()) { fprintf(stderr, "synchronize rc %d\n", rc); abort(); }
@@ -235,9 +255,9 @@ struct Test {
             check_host(c, "after Synchronize");
             if (check_dev)
                 for (int d = 0; d < G; d++)
-                    if (c->m.dev_defined[d] && memcmp(c->h->d[d].dev, c->m.dev[d].data(), kWords[c->m.level] * 4)) {
+                    if (c->m.dev_defined[d] && (c->h->d[d].dev != c->home[d] || memcmp(c->home[d], c->m.dev[d].data(), kWords[c->m.level] * 4))) {
                         failures++;
-                        printf("FAIL device mismatch ctxt %p dev %d\n", (void*)c, d);
+                        printf("FAIL device mismatch ctxt %p dev %d%s\n", (void*)c, d, c->h->d[d].dev != c->home[d] ? " (value not in the ciphertext's own buffer)" : "");
                     }
         }
     }
@@ -303,9 +323,11 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
         } else if (r < 92) {                        // StreamQuery poll
             const int q = t.S->dev(dev).stream_query(st);
             if (q < 0) { fprintf(stderr, "stream_query rc %d\n", q); abort(); }
-            if (q == 1)
+            if (q == 1) {
                 for (Test::C* c : t.ct)
                     if (c->alive && c->last_host_writer_stream == st) t.check_host(c, "after StreamQuery");
+                t.check_home_after_query(dev, st);
+            }
         } else if (r < 95) {                        // Synchronize, then the host may edit ciphertexts
             t.sync_and_check(true);
             for (int k = 0; k < 3; k++) {
@@ -314,6 +336,14 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
                 for (auto& w : c->host) w = (uint32_t)prng();
                 c->m.host = c->host;
             }
+        } else if (r < 96) {                        // the caller rewrites a tlwehost itself, without Synchronize (TRGSW2NTT on a holder)
+            Test::C* c = t.ct[prng() % t.ct.size()];
+            if (!c->alive) continue;
+            if (int rc = t.S->before_direct_host_write(c->h)) { fprintf(stderr, "before_direct_host_write rc %d\n", rc); abort(); }
+            for (auto* b : t.be) b->drain();
+            t.check_host(c, "before a direct host write");      // a result that was on its way has landed
+            for (auto& w : c->host) w = (uint32_t)prng();
+            c->m.host = c->host;
         } else if (r < 98) {                        // a ciphertext goes out of scope while work on it is recorded
             Test::C* c = t.ct[prng() % t.ct.size()];
             if (!c->alive) continue;

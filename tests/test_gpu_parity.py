@@ -323,10 +323,11 @@ def test_cpp_gate_api_three_logical_gpus(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
-def test_cpp_gate_api_with_output_renaming(engine):
-    """The same program, two logical devices, with "sched_rename": every check of the reference's test programs (truth
-    tables, chained in-place gates, polling, device-resident g-gates, TRLWE-level primitives, launch-count bounds) holds
-    when outputs take fresh device buffers."""
+def test_cpp_gate_api_without_output_renaming(engine):
+    """The same program, two logical devices, with "sched_rename" 0 (the default is 1 since round 5: every other run of this
+    program renames): every check of the reference's test programs (truth tables, chained in-place gates, polling,
+    device-resident g-gates, TRLWE-level primitives, launch-count bounds, tlwedevices after Synchronize) holds when every
+    output waits for the users of its buffer instead."""
     import os
     import subprocess
     exe = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api")
@@ -334,7 +335,7 @@ def test_cpp_gate_api_with_output_renaming(engine):
     engine.CleanUp()
     try:
         out = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=900,
-                             env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1", CUFHE_AMD_SCHED_RENAME="1"))
+                             env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1", CUFHE_AMD_NO_SCHED_RENAME="1"))
         print(out.stdout[-3000:])
         assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     finally:

@@ -6,6 +6,7 @@ Reference programs: test/test_api_gpu.cu:140-159 (chained in-place gates), test/
 and test/test_util.h:29-94 (every gate over many streams), test/test_intensive.cc:21-128 (polling),
 include/cufhe_gpu.cuh:282-313 (g-gates).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -148,15 +149,17 @@ def test_chained_program_levels_and_words(engine, keys):
 @pytest.mark.parametrize("rename", [0, 1])
 def test_ripple_adders_levels_and_words(engine, keys, rename):
     """16 8-bit ripple-carry adders issued bit by bit, one stream each (640 dependent gates,
-    tests/cpp/test_gate_api.cpp RippleAdders): <= 40 launch sequences, sums == oracle words.  With "sched_rename" the
-    re-used temporaries stop ordering the program (t1 is overwritten while its readers are still on record: it takes a
-    fresh device buffer) and only the carry chain is left: two levels per bit."""
+    tests/cpp/test_gate_api.cpp RippleAdders): <= 40 launch sequences, sums == oracle words.  With "sched_rename" (the
+    default) the re-used temporaries stop ordering the program (t1 is overwritten while its readers are still on record: it
+    takes a fresh device buffer) and only the carry chain is left: two levels per bit, plus the one level of Copy gates that
+    brings the renamed values back to the ciphertexts' own device buffers (`tlwedevices`, include/cufhe_gpu.cuh:80-84)
+    before Synchronize returns -- read back here from those very pointers."""
     api = engine.api
     api.set_option("sched_rename", rename)
     try:
         _ripple_adders(engine, keys, rename)
     finally:
-        api.set_option("sched_rename", 0)
+        api.set_option("sched_rename", 1)
 
 
 def _ripple_adders(engine, keys, rename):
@@ -188,7 +191,15 @@ def _ripple_adders(engine, keys, rename):
     stats = api.sched_stats()
     assert stats.gates == 5 * A * B
     assert stats.launch_sequences <= (2 * B + 2 if rename else 40), f"{stats.launch_sequences} launch sequences"
-    assert (stats.renames > 0) == bool(rename)
+    assert (stats.renames > 0) == bool(rename) and (stats.home_copies > 0) == bool(rename)
+    # the pointers published at construction hold the values, renamed on the way or not (every gate here is a copying one:
+    # tlwehost has the same words)
+    for c in t1 + t2 + carry:
+        dev = np.empty(ol.n + 1, np.uint32)
+        L = engine._lib
+        L.check(L.lib.cufhe_amd_memcpy_d2h(0, None, dev.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(c.tlwedevices[0]), dev.size * 4))
+        L.check(L.lib.cufhe_amd_stream_synchronize(0, None))
+        assert np.array_equal(dev, c.tlwehost), "tlwedevices[0] does not hold the ciphertext's value after Synchronize"
     # the same program on the oracle, bit by bit (batched over the adders)
     ex, ey = ex.reshape(A, B, -1), ey.reshape(A, B, -1)
     wc = ecarry
@@ -508,7 +519,7 @@ def test_random_program_matches_in_order_oracle(engine, keys, oracle, rename, se
         else:
             api.Flush(0)
     api.Synchronize()
-    api.set_option("sched_rename", 0)
+    api.set_option("sched_rename", 1)
     for lvl, lst in cts.items():
         for i, c in enumerate(lst):
             assert np.array_equal(c.tlwehost, host[id(c)]), f"level {lvl} ciphertext {i}"

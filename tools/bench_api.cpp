@@ -136,10 +136,11 @@ int main(int argc, char** argv)
     std::fflush(stdout);
     // A depth-first netlist through the same API: 256 independent 16-bit ripple-carry adders, issued ADDER BY ADDER
     // (every gate depends on the previous ones of its adder; test/test_api_gpu.cu:140-159 is the pattern in small).
-    // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders; once as the reference's
-    // buffers dictate (the temporaries t1, t2 re-used bit after bit order the program) and once with "sched_rename"
-    // (outputs take fresh device buffers: only the carry chain is left).
-    for (int rename = 0; rename < 2 && netlist; rename++) {
+    // The scheduler cuts the 20 480 recorded gates into dependence levels across the adders; once with the defaults
+    // ("sched_rename" 1: outputs take fresh device buffers, only the carry chain is left, the values return to the
+    // ciphertexts' own buffers in the flush of Synchronize) and once as the reference's buffers dictate ("sched_rename" 0:
+    // the temporaries t1, t2 re-used bit after bit order the program).
+    for (int rename = 1; rename >= 0 && netlist; rename--) {
         CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", rename));
         const int kAdders = 256, kBits = 16;
         std::vector<Ctxt<P>> x(kAdders * kBits), y(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);
@@ -174,7 +175,7 @@ int main(int argc, char** argv)
                     rename, (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
                     (unsigned long long)ns.launch_sequences, (unsigned long long)ns.max_level_gates);
     }
-    CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 0));
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 1));
     // What a smarter level assignment could reach at best, emulated by the program itself: the same adders in single-assignment
     // form (no buffer is written twice, so only data dependences order it), the sum bits -- the only gates nothing else reads --
     // withheld until the carry chains are launched and issued as ONE level at the end.  If this is not faster than the
