@@ -9,7 +9,12 @@ scaling, no data-path collective.  `python bench.py --gpus N` run
 the N ranks itself (before torch or the HIP library are imported); under
 `torch.distributed.run` it is one of the ranks.  `--workload mixed --total-gates 32768` is
 BASELINE configs[2] instead: the 32 768 mixed gates of SURVEY.md 8(d) config 3 split
-contiguously over the ranks (strong scaling).
+contiguously over the ranks (strong scaling); a plain `--gpus N` run with N > 1 times that
+workload as well, in the same processes, after the NAND timing (extra_workloads.mixed_32768_strong).
+
+The line starts with the numbers (first 2 KB: value, value_pcie_inclusive, single-gate latency, the
+extra workloads' rates in `summary`, roofline, cpu_baseline); what the fields mean and how each is
+measured is prose that does not change from run to run: profiles/bench_line_notes.md.
 
 Prints ONE JSON line (rank 0):
   value / ms_per_step      the timed region: K steps, no profiling hooks inside
@@ -212,8 +217,6 @@ def valu_block(kernel, rotations, launch_ms, clock_hz):
         "frac_of_fp64_issue": FP64_ISSUE_CYCLES_SPEC * insts / slots,
         "frac_of_measured_issue_floor": FP64_ISSUE_CYCLES_MEASURED * insts / slots,
         "clock_hz_this_run": clock_hz,
-        "clock_note": "clock_hz_this_run is read by a short probe kernel (cufhe_amd_probe_clock) running CONCURRENTLY with this workload's launch: "
-                      "the clock the chip holds under that kernel (an idle-chip probe reads 2.43 GHz; a kernel at the power limit runs below it)",
         "clock_hz_under_profiler": facts.get("clock_hz_under_profiler"),
         "pipe_busy_under_profiler": facts.get("valu_pipe_busy"),
         "lds_bank_conflict_frac": facts.get("lds_bank_conflict_frac"),
@@ -235,10 +238,27 @@ def oracle_check(ol, L, ek, ops, in0, in1, in2, gpu_out, idx):
     return bool(np.array_equal(out.reshape(idx.size, -1), gpu_out[idx]))
 
 
-def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12.0):
-    """Time the optimised CPU gate (oracle/cpu_fast.c) on a bounded sample of the same workload."""
+def cgroup_cpu_quota():
+    """CPUs this container may use according to its cgroup (v2 cpu.max, v1 cfs quota), or None when unlimited / unreadable."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
+def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=10.0):
+    """Time the optimised CPU gate (oracle/cpu_fast.c) on a bounded sample of the same workload: on every core this process may
+    use (all visible cores unless the cgroup quota says fewer) and, measured separately, on ONE thread."""
     fek = L.fast_evalkey_create(bk, ksk)
     visible = L.orc_max_threads()
+    quota = cgroup_cpu_quota()
     nand = np.array([0], np.int32)
     words = ol.n + 1
 
@@ -250,14 +270,18 @@ def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12
         L.fast_gate_batch(fek, nand, 0, count, out, a, b, threads)
         return time.perf_counter() - t, out.reshape(count, words)
 
-    # the container's CPU share can be far below the visible core count: calibrate the thread
-    # count on one round each (16 gates per thread: one block) and keep the fastest
-    best = None
-    for cand in sorted({min(16, visible), min(32, visible), min(64, visible), visible}):
+    threads = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    # one thread, measured (not derived from the parallel run): 12 gates after one to warm the tables
+    run(1, 1)
+    dt1, _ = run(12, 1)
+    single_ms = 1e3 * dt1 / 12
+    # one round per candidate thread count (16 gates per thread: one block), for context: the share of the box a container really
+    # gets can be below what it is shown, and then fewer threads are faster
+    calib = []
+    for cand in sorted({min(16, visible), min(32, visible), min(64, visible), visible, threads}):
         dt, _ = run(16 * cand, cand)
-        if best is None or 16 * cand / dt > best[0]:
-            best = (16 * cand / dt, cand, dt)
-    rate, threads, _ = best
+        calib.append({"threads": int(cand), "gates_per_s": round(16 * cand / dt, 1)})
+    rate = next(c["gates_per_s"] for c in calib if c["threads"] == threads)
     # about target_seconds of CPU work: whole passes over the batch (the same gates the GPU ran)
     count = in0.shape[0]
     passes = max(1, int(round(target_seconds * rate / count)))
@@ -275,16 +299,79 @@ def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=12
     count_total = count * passes
     return {
         "value": count_total / dt, "unit": "gate-bootstraps/s", "cores": int(threads), "kind": "port",
+        "sample": f"{passes} pass(es) over the batch's {count} NAND gates on {threads} threads, {dt:.1f} s; 12 gates on one thread, {dt1:.2f} s",
+        "single_thread_ms_per_gate": single_ms,
+        "visible_cores": int(visible), "cgroup_cpu_quota": quota,
         "implementation": "oracle/cpu_fast.c: exact FP64-field NTT, constant-geometry radix-2, "
                           + {4: "AVX-512", 3: "AVX2+FMA", 0: "scalar"}[int(L.fast_isa_level())] + ", OpenMP over gates",
-        "visible_cores": int(visible),
-        "sample": f"{passes} pass(es) over the batch's {count} NAND gates, {dt:.1f} s",
-        "ms_per_gate_per_core": 1e3 * dt * threads / count_total,
+        "ms_per_gate_per_core_in_the_parallel_run": 1e3 * dt * threads / count_total,
+        "thread_count_rounds": calib,
         "cpu_words_match_oracle": bool(np.array_equal(out[idx], want)),
         "gpu_words_match_cpu": bool(np.array_equal(out, gpu_out[:count])),        # all 4096 gates
         "gpu_words_match_oracle": bool(np.array_equal(gpu_out[idx], want)),
         "reference_readme_context": "TFHE library on CPU: 10 ms per gate; cuFHE: 13 ms per gate per A100 SM (README.md:29-31)",
     }
+
+
+def ordered_line(res):
+    """The numbers first: the driver keeps the head of the line (stdout_tail), so everything a reader needs to judge the run sits in
+    the first 2 KB -- the contract fields, the PCIe-inclusive rate, the single-gate latency, one figure per extra workload
+    (`summary`), the roofline and cpu_baseline objects cut to their numbers -- and the detail blocks follow."""
+    ex = res.get("extra_workloads") or {}
+    api_blk = res.get("api_pcie_inclusive") or {}
+
+    def val(d, k="value"):
+        return d.get(k) if isinstance(d, dict) else None
+    summary = {
+        "mux_gates_per_s": val(ex.get("mux")), "mixed_gates_per_s": val(ex.get("mixed")),
+        "nand_lvl2_per_s": val(ex.get("nand_lvl2")), "nand_level1_per_s": val(ex.get("nand_level1")),
+        "nand_512_ms": val(ex.get("nand_512"), "ms_per_step"),
+        "mixed_32768_strong_gates_per_s": val(ex.get("mixed_32768_strong")),
+        "adder_netlist_gates_per_s": val(api_blk.get("depth_first_netlist"), "gates_per_s"),
+        "adder_netlist_without_renaming_gates_per_s": val(api_blk.get("depth_first_netlist_without_renaming"), "gates_per_s"),
+        "api_reference_style_latency_ms_per_gate": val(api_blk.get("reference_style"), "latency_ms_per_gate"),
+        "param_sets_per_s": {k: val(v) for k, v in (ex.get("param_sets") or {}).items()} or None,
+        "all_word_checks_pass": None,
+    }
+    checks = []
+
+    def walk(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k.endswith("_match_oracle") or k.endswith("_match_cpu"):
+                    if v is not None:
+                        checks.append(bool(v))
+                else:
+                    walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+    walk(res)
+    summary["all_word_checks_pass"] = all(checks) if checks else None
+    summary = {k: v for k, v in summary.items() if v is not None}
+    head_keys = ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "value_pcie_inclusive", "ms_per_gate_latency_single_gate", "ms_per_gate_throughput")
+    out = {k: res[k] for k in head_keys if k in res}
+    out["summary"] = summary
+    rf = res.get("roofline")
+    if rf:
+        first = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_valu_fp64", "launch_ms", "rotations_per_launch",
+                 "algorithmic_bytes_per_rotation")
+        out["roofline"] = {k: rf[k] for k in first if k in rf}
+    cb = res.get("cpu_baseline")
+    if cb:
+        first = ("value", "unit", "cores", "kind", "sample", "single_thread_ms_per_gate", "visible_cores", "cgroup_cpu_quota")
+        out["cpu_baseline"] = {k: cb[k] for k in first if k in cb}
+    if "config" in res:
+        out["config"] = res["config"]
+    if rf:
+        out["roofline_detail"] = {k: v for k, v in rf.items() if k not in out["roofline"]}
+    if cb:
+        out["cpu_baseline_detail"] = {k: v for k, v in cb.items() if k not in out["cpu_baseline"]}
+    for k, v in res.items():
+        if k not in out:
+            out[k] = v
+    return out
 
 
 def main():
@@ -433,10 +520,6 @@ def main():
         r = {
             "bound": "valu_fp64", "kernel": kernel,
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "accounting": "achieved/peak/frac price the launch with the BK sweep SURVEY.md 8(d) prescribes (the bytes a cache-less "
-                          "sweep of the bootstrapping key would read) against the HBM peak; the sweep is served by the XCD L2s "
-                          "(`traffic` = measured fabric/HBM bytes), so `bound` names what the kernel actually runs into: FP64 "
-                          "vector issue, priced in `valu`",
             "traffic": None, "traffic_unit": "bytes per launch",
             "launch_ms": br_ms, "rotations_per_launch": rotations, "algorithmic_bytes_per_rotation": bk_bytes,
             "keyswitch_launch_ms": ks_ms, "pmc_source": note,
@@ -447,8 +530,6 @@ def main():
         r["valu"] = valu_block(kernel, rotations, br_ms, clock_during("lvl2" if l2 else "batch", lambda: run_step(workload, n), br_ms))
         # the number that says how close the kernel is to what bounds it, next to the accounting fraction
         r["frac_valu_fp64"] = r["valu"].get("frac_of_fp64_issue")
-        r["frac_valu_fp64_is"] = ("VALU instructions of the launch (replayed PMC count per rotation) x 4 cycles / SIMD-cycles of the launch "
-                                  "(launch_ms from HIP events and the shader clock under this very launch, both measured in THIS run)")
         return {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_valu_fp64", "traffic")} | r
 
     wl = args.workload
@@ -461,6 +542,54 @@ def main():
         "rank": RANK, "local_rank": LOCAL_RANK, "hip_device": DEV, "gpu": identity, "gates_per_step": count,
         "value": count * args.steps / own_s if own_s > 0 else None, "ms_per_step": 1e3 * own_s / args.steps,
         "blind_rotate_launch_ms": br_ms, "keyswitch_launch_ms": ks_ms, "clock_hz": clock_hz}, dist)
+
+    def mixed_strong_extra(total=32768, steps=2, warmup=1):
+        """BASELINE configs[2] inside a plain multi-rank run: `total` mixed And/Or/Xor/Nand gates per step, gate i on rank
+        floor(i / ceil(total / W)) (test/test_gate_gpu_multi.cc:36-93 splits its gates over the GPUs the same way), same processes,
+        same key replicas, no collective in the data path.  Every rank takes part (barriers)."""
+        lo, hi = distutil.shard(total, RANK, WORLD)
+        cnt = hi - lo
+        r = np.random.default_rng(4300 + RANK)
+        xin = [r.integers(0, 2**32, size=(max(cnt, 1), ol.n + 1), dtype=np.uint64).astype(np.uint32) for _ in range(3)]
+        xd = [api.DeviceBuffer(x.size).upload(x) for x in xin]
+        xout = api.DeviceBuffer(max(cnt, 1) * (ol.n + 1))
+        xops = np.array([[api.AND, api.OR, api.XOR, api.NAND][(lo + g) % 4] for g in range(max(cnt, 1))], np.int32)
+
+        def step():
+            if cnt:
+                api.gate_batch(xops, 0, xout, xd[0], xd[1], xd[2], count=cnt, device=0, stream=st.st())
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        eng.Synchronize()
+        torch.cuda.synchronize()
+        own_t = time.perf_counter() - t0
+        barrier()
+        el = distutil.max_over_ranks(time.perf_counter() - t0, dist)
+        per = distutil.gather_objects({"rank": RANK, "first_gate": lo, "gates_per_step": cnt, "ms_per_step": 1e3 * own_t / steps,
+                                       "value": cnt * steps / own_t if cnt and own_t > 0 else None}, dist)
+        match = None
+        if RANK == 0 and cnt and not args.no_cpu_baseline:
+            import oracle_lib                 # the checker, on a sample of rank 0's gates
+            L = oracle_lib.load()
+            oek = L.orc_evalkey_create(bk, ksk)
+            got = xout.download().reshape(max(cnt, 1), ol.n + 1)
+            idx = np.arange(1, cnt, max(1, cnt // 16))[:16]
+            match = oracle_check(ol, L, oek, xops, xin[0], xin[1], xin[2], got, idx)
+            L.orc_evalkey_destroy(oek)
+        for b in xd + [xout]:
+            b.free()
+        return {"value": total * steps / el, "unit": "gates/s", "scaling": "strong", "ms_per_step": 1e3 * el / steps, "steps": steps,
+                "warmup": warmup, "total_gates_per_step": total, "baseline_config": "configs[2]", "per_rank": per,
+                "gpu_words_match_oracle": match,
+                "sharding": "gate i -> rank floor(i / ceil(total / W)), op = (And, Or, Xor, Nand)[i mod 4], per-GPU BK/KSK replica, no collective"}
+
+    mixed_strong = None
+    if WORLD > 1 and not strong and wl == "nand" and not args.no_extra:
+        mixed_strong = mixed_strong_extra()
 
     extras_on = RANK == 0 and WORLD == 1 and not args.no_extra and not strong
     latency_ms = None
@@ -505,7 +634,10 @@ def main():
             **distutil.rank_summary(reports, args.allow_shared_gpu),
             "ms_per_gate_latency_single_gate": latency_ms,
             "roofline": roofline(wl, br_ms, ks_ms),
+            "notes": "profiles/bench_line_notes.md",
         }
+        if mixed_strong is not None:
+            res["extra_workloads"] = {"mixed_32768_strong": mixed_strong}
         main_out = dout.download().reshape(max(count, 1), ol.n + 1)[:count]
 
         if extras_on and not args.no_api:
@@ -526,9 +658,6 @@ def main():
                     res["api_pcie_inclusive"]["depth_first_netlist_without_renaming"] = lines[2]
                 if len(lines) > 3:
                     res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = lines[3]
-                res["api_pcie_inclusive"]["what"] = ("4096 cufhe::Nand(out, a, b, st) on host-resident ciphertexts over 256 streams, "
-                                                     "then Synchronize(): test/test_util.h:29-72; host_issue = recording + result delivery "
-                                                     "on the issuing thread, host_worker = the device's launch thread")
             except Exception as e:      # the figure is auxiliary: never lose the headline line to it
                 res["api_pcie_inclusive"] = {"error": repr(e)}
 
@@ -576,6 +705,36 @@ def main():
                                           "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, -1), out2[idx]))}
                 except Exception as e:
                     extra["nand_lvl2"] = {"error": repr(e)}
+                # the reference's primary tested ciphertext level (test/test_gate_gpu.cc:36-91): NAND on lvl1 ciphertexts, key switch
+                # first, then the blind rotation (src/bootstrap_gpu.cu:383-400)
+                try:
+                    w1 = ol.N + 1
+                    r1 = np.random.default_rng(4711)
+                    x1 = [r1.integers(0, 2**32, size=(count, w1), dtype=np.uint64).astype(np.uint32) for _ in range(2)]
+                    xd1 = [api.DeviceBuffer(x.size).upload(x) for x in x1]
+                    xo1 = api.DeviceBuffer(count * w1)
+
+                    def step1():
+                        api.gate_batch(api.NAND, 1, xo1, xd1[0], xd1[1], None, count=count, device=0, stream=st.st())
+                    step1()
+                    eng.Synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        step1()
+                    eng.Synchronize()
+                    dt = (time.perf_counter() - t0) / 2
+                    got1 = xo1.download().reshape(count, w1)
+                    idx = np.arange(1, count, max(1, count // 8))[:8]
+                    want1 = np.zeros(idx.size * w1, np.uint32)
+                    a_s, b_s = np.ascontiguousarray(x1[0][idx]).ravel(), np.ascontiguousarray(x1[1][idx]).ravel()
+                    L.orc_gate_batch(oek, np.array([0], np.int32), 0, 1, idx.size, want1, a_s, b_s.ctypes.data, None, min(L.orc_max_threads(), 32))
+                    extra["nand_level1"] = {"value": count / dt, "unit": "gate-bootstraps/s", "ms_per_step": 1e3 * dt,
+                                            "what": f"{count} NAND on lvl1 ciphertexts (N + 1 = {w1} words): IdentityKeySwitch, blind rotation, sample extract",
+                                            "gpu_words_match_oracle": bool(np.array_equal(want1.reshape(idx.size, w1), got1[idx]))}
+                    for b in xd1 + [xo1]:
+                        b.free()
+                except Exception as e:
+                    extra["nand_level1"] = {"error": repr(e)}
                 # a mid-sized launch (512 gates: one round of the paired low-latency kernel) and the key switch of the main batch
                 try:
                     run_step("nand", 512)
@@ -658,8 +817,6 @@ def main():
                                        "blind_rotate_launch_ms": pbr_ms,
                                        "bk_sweep_frac_of_hbm_peak": count * bk_bytes / dt / 8e12,
                                        "bound": "valu_fp64",
-                                       "note": "the sweep fraction is an accounting figure (SURVEY.md 8d), not a physical bound: the key is served by "
-                                               "the XCD L2s, so it may exceed 1; what the kernel runs into is FP64 issue, `valu`",
                                        "valu": valu_block("blind_rotate_ps_batch_kernel<%s>" % name, count, pbr_ms,
                                                           clock_during("ps_" + name, ps_step, pbr_ms)),
                                        "gpu_words_match_oracle": bool(np.array_equal(want.reshape(idx.size, w), got[idx]))}
@@ -684,7 +841,7 @@ def main():
                                    "implementation": "oracle/tfhe_oracle_lvl2.c (the checker itself; no optimised CPU path for this ring)",
                                    "sample": f"{n_chk} of the batch's NAND gates, {dt:.1f} s",
                                    "gpu_words_match_oracle": bool(np.array_equal(want.reshape(n_chk, -1), main_out[:n_chk]))}
-        print(json.dumps(res), file=json_out, flush=True)
+        print(json.dumps(ordered_line(res)), file=json_out, flush=True)
 
     st.Destroy()
     eng.CleanUp()

@@ -39,6 +39,21 @@ dist.barrier(); el = d.max_over_ranks(time.perf_counter() - t0 + rank, dist)
 assert el >= world - 1                      # MAX over ranks, not this rank's own time
 np.save(os.path.join(OUT, f"shard{rank}.npy"), out)
 np.save(os.path.join(OUT, f"range{rank}.npy"), np.array([lo, hi]))
+# the second timed workload of a plain multi-rank bench run (extra_workloads.mixed_32768_strong): a strong split of ANOTHER gate list
+# in the same processes, every rank's share gathered on all ranks
+total2 = 13
+lo2, hi2 = d.shard(total2, rank, world)
+ins2 = [keys.encrypt(np.random.default_rng(6 + i).integers(0, 2, size=total2).astype(np.uint8), 0, seed=400 + i) for i in range(2)]
+ops2 = np.array([[3, 4, 5, 0][g % 4] for g in range(total2)], np.int32)
+dist.barrier(); t0 = time.perf_counter()
+out2 = keys.gate_batch(ops2[lo2:hi2], 0, ins2[0][lo2:hi2], ins2[1][lo2:hi2])
+own = time.perf_counter() - t0
+dist.barrier(); el2 = d.max_over_ranks(time.perf_counter() - t0, dist)
+per = d.gather_objects({"rank": rank, "first_gate": lo2, "gates_per_step": hi2 - lo2, "ms_per_step": 1e3 * own}, dist)
+assert [p["rank"] for p in per] == list(range(world)) and sum(p["gates_per_step"] for p in per) == total2
+assert all(per[i]["first_gate"] + per[i]["gates_per_step"] == per[i + 1]["first_gate"] for i in range(world - 1))
+assert el2 >= max(p["ms_per_step"] for p in per) * 1e-3 * 0.999
+np.save(os.path.join(OUT, f"second{rank}.npy"), out2)
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -78,6 +93,15 @@ def test_two_ranks_gloo(tmp_path, keys):
         lo, hi = np.load(tmp_path / f"range{rank}.npy")
         got[lo:hi] = np.load(tmp_path / f"shard{rank}.npy")
     assert np.array_equal(got, want)
+    # the strong split of the second workload: union of the ranks' shares == the single-rank words
+    total2 = 13
+    ins2 = [keys.encrypt(np.random.default_rng(6 + i).integers(0, 2, size=total2).astype(np.uint8), 0, seed=400 + i) for i in range(2)]
+    ops2 = np.array([[3, 4, 5, 0][g % 4] for g in range(total2)], np.int32)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"second{r}.npy") for r in range(2)]), keys.gate_batch(ops2, 0, ins2[0], ins2[1]))
+    # bench.py wires it in: a plain multi-rank NAND run times configs[2] in the same processes, on every rank (barriers inside)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "if WORLD > 1 and not strong and wl == \"nand\" and not args.no_extra:\n        mixed_strong = mixed_strong_extra()" in src
+    assert src.index("mixed_strong = mixed_strong_extra()") < src.index("if RANK == 0:\n        gates_per_step")
 
 
 def _dist():
@@ -285,6 +309,12 @@ def test_bench_self_launch_two_ranks_on_this_box():
     if one_gpu:
         assert line["shared_gpu"] is True and line["n_gpus"] == 1
     assert line["value_min_rank"] <= line["value_max_rank"]
+    # BASELINE configs[2] in the same run: 32 768 mixed gates split contiguously over the two ranks, words checked on rank 0
+    ms = line["extra_workloads"]["mixed_32768_strong"]
+    assert ms["value"] > 0 and ms["scaling"] == "strong" and ms["gpu_words_match_oracle"] is True
+    assert [r["gates_per_step"] for r in ms["per_rank"]] == [16384, 16384] and [r["first_gate"] for r in ms["per_rank"]] == [0, 16384]
+    assert line["summary"]["mixed_32768_strong_gates_per_s"] == ms["value"]
+    assert json.dumps(line).index('"mixed_32768_strong_gates_per_s"') < 2048        # in the head of the line the driver keeps
 
 
 @pytest.mark.gpu
