@@ -365,7 +365,20 @@ void Lvl2Gates(std::mt19937& eng)
     std::vector<uint32_t> ksk(ORC2_KSK_WORDS);
     orc2_bkgen(3007, g_s0.data(), s2.data(), bk.data());
     orc2_kskgen(4007, g_s0.data(), s2.data(), ksk.data());
+#ifdef CUFHE_AMD_USE_TFHEPP
+    {   // the form a cuFHE user with TFHEpp writes: the keys travel inside a TFHEpp::EvalKey
+        TFHEpp::EvalKey ek2;
+        ek2.bklvl02 = std::make_unique<TFHEpp::BootstrappingKey<TFHEpp::lvl02param>>();
+        ek2.iksklvl20 = std::make_unique<TFHEpp::KeySwitchingKey<TFHEpp::lvl20param>>();
+        static_assert(sizeof(*ek2.bklvl02) == ORC2_BK_WORDS * sizeof(uint64_t) && sizeof(*ek2.iksklvl20) == ORC2_KSK_WORDS * sizeof(uint32_t),
+                      "stub containers and the oracle's key layouts have the same size");
+        std::memcpy(ek2.bklvl02->data(), bk.data(), sizeof(*ek2.bklvl02));
+        std::memcpy(ek2.iksklvl20->data(), ksk.data(), sizeof(*ek2.iksklvl20));
+        lvl2::Initialize(ek2);
+    }
+#else
     lvl2::Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
+#endif
     const int K = 64, W = ORC_LVL0_WORDS;
     std::vector<uint32_t> h(4 * K * W);
     std::vector<uint8_t> pt(3 * K);
@@ -433,10 +446,30 @@ int main(int argc, char** argv)
     // the whole program again with every output waiting for the users of its buffer (include/cufhe_amd.h, "sched_rename" 0)
     if (getenv("CUFHE_AMD_NO_SCHED_RENAME")) CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 0));
     SetGPUNum(gpus);
+#ifdef CUFHE_AMD_USE_TFHEPP
+    {   // Initialize(const TFHEpp::EvalKey&), src/cufhe_gates_gpu.cu:42-47 -- here over the test-only stand-in headers of
+        // tests/cpp/tfhepp_stub (TFHEpp itself is not in the reference tree): the branch of cufhe_amd.hpp a cuFHE user compiles
+        TFHEpp::EvalKey ek;
+        ek.bklvl01 = std::make_unique<TFHEpp::BootstrappingKey<TFHEpp::lvl01param>>();
+        ek.iksklvl10 = std::make_unique<TFHEpp::KeySwitchingKey<TFHEpp::lvl10param>>();
+        static_assert(sizeof(*ek.bklvl01) == ORC_BK_WORDS * sizeof(uint32_t) && sizeof(*ek.iksklvl10) == ORC_KSK_WORDS * sizeof(uint32_t),
+                      "stub containers and the oracle's key layouts have the same size");
+        std::memcpy(ek.bklvl01->data(), bk.data(), sizeof(*ek.bklvl01));
+        std::memcpy(ek.iksklvl10->data(), ksk.data(), sizeof(*ek.iksklvl10));
+        Initialize(ek);
+    }
+#else
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
+#endif
     ReferenceGlobals(gpus);
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc
     AllGates<TFHEpp::lvl0param>(kNumSMs, kNumTests, eng);   // test_gate_gpu_multi.cc
+    if (getenv("CUFHE_AMD_TEST_QUICK")) {                   // the gate tests and the lvl2 keys only (the USE_TFHEPP build's run)
+        Lvl2Gates(eng);
+        CleanUp();
+        std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
+        return g_failures ? 1 : 0;
+    }
     Chained(eng);
     Intensive(eng);
     DeviceResident(eng);

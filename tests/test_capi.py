@@ -4,6 +4,7 @@ argument checking that does not need one is exercised."""
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -125,6 +126,37 @@ def test_parameter_sets_match_the_oracle_builds():
         assert p.ksk_words == p.k * p.N * p.t * (1 << (p.basebit - 1)) * (p.n + 1)
     assert names == list(ol.SETS)
     assert lib.cufhe_amd_ps_get_params(99, ctypes.byref(PsParams())) < 0
+
+
+def test_shim_compiles_with_the_tfhepp_branch(tmp_path):
+    """include/cufhe_amd.hpp with -DCUFHE_AMD_USE_TFHEPP -- the branch a cuFHE user compiles: parameter structs, TLWE / TRLWE / TRGSW
+    and EvalKey from <params.hpp> / <cloudkey.hpp>, Initialize(const TFHEpp::EvalKey&) as src/cufhe_gates_gpu.cu:42-47 -- against the
+    test-only stand-in headers of tests/cpp/tfhepp_stub (TFHEpp is an empty submodule in the reference tree; the stub pins nothing
+    about it, it keeps the branch from rotting).  The reference's own test programs (tests/cpp/test_gate_api.cpp) compile and link
+    in that configuration; tests/test_gpu_parity.py runs the binary on the GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_gate_api_tfhepp")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-DCUFHE_AMD_USE_TFHEPP", "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"),
+                           "-o", exe, os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
+                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    # and a translation unit that uses nothing but the reference's own spellings
+    src = tmp_path / "user.cpp"
+    src.write_text('''#define CUFHE_AMD_USE_TFHEPP
+#include "cufhe_amd.hpp"
+void user(const TFHEpp::EvalKey& ek) {
+    cufhe::SetGPUNum(1);
+    cufhe::Initialize(ek);                                  // src/cufhe_gates_gpu.cu:42-47
+    cufhe::Ctxt<TFHEpp::lvl1param> a, b, c;                 // test/test_gate_gpu.cc:36-91
+    cufhe::Stream st; st.Create();
+    cufhe::Nand(c, a, b, st);
+    cufhe::Synchronize();
+    cufhe::lvl2::Initialize(ek);
+    st.Destroy(); cufhe::CleanUp();
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
+                           "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"), str(src)])
 
 
 def test_recorded_pmc_facts_belong_to_the_committed_device_code():

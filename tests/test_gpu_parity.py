@@ -303,6 +303,29 @@ def test_cpp_gate_api_mirror(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+def test_cpp_gate_api_tfhepp_branch(engine):
+    """The same source compiled with -DCUFHE_AMD_USE_TFHEPP over tests/cpp/tfhepp_stub (tests/test_capi.py builds it on the CPU):
+    keys handed over as a TFHEpp::EvalKey (Initialize(ek), lvl2::Initialize(ek)), every gate of both levels decrypt-checked."""
+    import os
+    import subprocess
+    root = ol.ROOT
+    exe = os.path.join(root, "tests", "cpp", "test_gate_api_tfhepp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DCUFHE_AMD_USE_TFHEPP", "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"),
+                           "-o", exe, os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
+                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle",
+                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, CUFHE_AMD_TEST_QUICK="1"))
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
+
+
 def test_cpp_gate_api_three_logical_gpus(engine):
     """The same program with SetGPUNum(3) (test/test_gate_gpu_multi.cc:36-93: default-constructed streams
     round-robin the devices, include/cufhe_gpu.cuh:154-159): per-device key replicas, schedulers, launch threads
