@@ -144,7 +144,8 @@ class Ctxt:
 
     def __init__(self, level=0):
         self.level = int(level)
-        self.tlwehost = np.zeros(LVL_WORDS[self.level], dtype=np.uint32)
+        # n + 1 / k N + 1 words of the parameter set the per-gate API runs on ("param_set"; the BASELINE set unless chosen otherwise)
+        self.tlwehost = np.zeros(lib.cufhe_amd_ctxt_words(self.level), dtype=np.uint32)
         h = ctypes.c_void_p()
         check(lib.cufhe_amd_ctxt_create(self.level, _ptr(self.tlwehost), ctypes.byref(h)))
         self._h = h
@@ -418,8 +419,9 @@ def ps_initialize(ps, bk, ksk):
     check(lib.cufhe_amd_ps_initialize(int(ps), _ptr(bk), bk.size, _ptr(ksk), ksk.size))
 
 
-def ps_gate_batch(ps, ops, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
-    words = ps_params(ps).lvl0_words
+def ps_gate_batch(ps, ops, out, in0, in1=None, in2=None, count=None, device=0, stream=None, level=0):
+    """level 0: blind rotate then key switch on n + 1 words; level 1: key switch then blind rotate on k N + 1 words"""
+    words = ps_params(ps).lvl1_words if level else ps_params(ps).lvl0_words
     if count is None:
         count = out.words // words
     if np.isscalar(ops):
@@ -427,9 +429,9 @@ def ps_gate_batch(ps, ops, out, in0, in1=None, in2=None, count=None, device=0, s
     else:
         ops_arr, stride = np.ascontiguousarray(ops, dtype=np.int32), 1
         assert ops_arr.size >= count
-    check(lib.cufhe_amd_ps_gate_batch(int(ps), device, stream, count, _ptr(ops_arr), stride, out.ptr, in0.ptr,
-                                      in1.ptr if in1 is not None else None,
-                                      in2.ptr if in2 is not None else None, words))
+    check(lib.cufhe_amd_ps_gate_batch_level(int(ps), device, stream, int(level), count, _ptr(ops_arr), stride, out.ptr, in0.ptr,
+                                            in1.ptr if in1 is not None else None,
+                                            in2.ptr if in2 is not None else None, words))
 
 
 def ps_blind_rotate_batch(ps, tlwe0, acc, count, steps=-1, device=0, stream=None):

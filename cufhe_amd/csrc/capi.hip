@@ -613,14 +613,17 @@ using sched::GateRef;
 template <class GetGate>
 int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lvl2.inc.h
 template <class GetGate>
-int run_gates_ps(int set, int device, void* stream, size_t count, GetGate get);   // paramsets.inc.h
-long g_lvl0_param_set = -1;    // >= 0: gates on lvl0 ciphertexts bootstrap through this parameter set (same n as the default)
+int run_gates_ps(int set, int device, void* stream, int level, size_t count, GetGate get);   // paramsets.inc.h
+int ps_ctxt_words(int set, int level);
+// >= 0: the per-gate API (both ciphertext levels, both gate orders) runs on this compiled parameter set -- the reference's build-time
+// choice (CMakeLists.txt:8-24) serves every entry point the same way; ciphertexts then have the set's sizes (cufhe_amd_ctxt_words)
+long g_lvl0_param_set = -1;
 
 template <class GetGate>
 int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 {
     if (level == 0 && g_lvl0_ring == 2048) return run_gates_lvl2(device, stream, count, get);
-    if (level == 0 && g_lvl0_param_set >= 0) return run_gates_ps((int)g_lvl0_param_set, device, stream, count, get);
+    if ((level == 0 || level == 1) && g_lvl0_param_set >= 0) return run_gates_ps((int)g_lvl0_param_set, device, stream, level, count, get);
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
@@ -1336,11 +1339,17 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
     if (!strcmp(key, "ps_batch_threshold")) { g_ps_batch_threshold = value; return 0; }
     if (!strcmp(key, "ll2_threshold")) { g_ll2_threshold = value; return 0; }
-    if (!strcmp(key, "lvl0_param_set")) {
+    if (!strcmp(key, "param_set") || !strcmp(key, "lvl0_param_set")) {
         if (value >= 0) {
             cufhe_amd_ps_params p;
             if (int rc = cufhe_amd_ps_get_params((int)value, &p)) return rc;
-            if ((int)p.lvl0_words != kLvl0Words) return fail(-1, "lvl0_param_set: the set's lvl0 ciphertexts differ in size from the per-gate API's (n must be 630)");
+            // ciphertext device slots are carved for the largest compiled sizes (HipBackend::slot_words), so a set only has to fit them
+            if ((int)p.lvl0_words > kLvl0Words || (int)p.lvl1_words > kLvl1Words) return fail(-1, "param_set: the set's ciphertexts exceed the per-gate API's buffers");
+        }
+        if (value != g_lvl0_param_set) {
+            // recorded gates were sized and routed for the old set: they complete first
+            std::lock_guard<std::mutex> lk2(g_sched_mu);
+            if (int rc = sched_synchronize_all()) return rc;
         }
         g_lvl0_param_set = value;
         return 0;

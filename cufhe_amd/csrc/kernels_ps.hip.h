@@ -25,7 +25,7 @@
 //   blind_rotate_ps_batch_kernel  one WAVE per rotation, 8 rotations per workgroup walking the key together
 //       (large launches): the shape of blind_rotate_kernel -- accumulator and sums in registers, key rows
 //       staged once per workgroup in LDS by LDS-DMA one row ahead, one barrier per row -- written over PS.
-// NTT-domain key: [step][limb][row][out][q < R/2][lane][2] doubles: a TRGSW row of one limb is one contiguous
+// NTT-domain key: [step][limb, HIGH limb first][row][out][q < R/2][lane][2] doubles: a TRGSW row of one limb is one contiguous
 // block of (k+1) polynomials, each in the spectrum order of the wave transform (registers 2q, 2q+1 of a lane).
 #pragma once
 #include <type_traits>
@@ -232,7 +232,9 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
     }
     PO::forward(x, ctx);
     const size_t step = poly / D::bk_step_polys, in_step = poly % D::bk_step_polys;       // in_step = row * K1 + out
-    double2* dst = (double2*)(bk_ntt + ((step * PS::limbs + limb) * D::bk_step_polys + in_step) * D::N);
+    // the limbs of a step are stored HIGH limb first: the wave-per-rotation kernel walks them in storage order and then only has to
+    // keep the top 32 - limb_bits bits of what the earlier limbs contributed (blind_rotate_ps_batch_kernel, `delta`)
+    double2* dst = (double2*)(bk_ntt + ((step * PS::limbs + (PS::limbs - 1 - limb)) * D::bk_step_polys + in_step) * D::N);
 #pragma unroll
     for (int q = 0; q < PO::R / 2; q++) {
         double2 v;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
 #pragma unroll 1
             for (int s = 0; s < D::SUMS; s++) {      // :206-221, one product per (output component, key limb)
                 const int out = s / PS::limbs, limb = s % PS::limbs;
-                const double2* kp = (const double2*)(bk_ntt + ((((size_t)i * PS::limbs + limb) * D::ROWS + row) * K1 + out) * N) + lane;
+                const double2* kp = (const double2*)(bk_ntt + ((((size_t)i * PS::limbs + (PS::limbs - 1 - limb)) * D::ROWS + row) * K1 + out) * N) + lane;
                 double* sp = sumL + s * N + lane;
                 double2 b[R / 2];
 #pragma unroll
@@ -508,15 +510,22 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
-        uint32_t delta[K1][R];      // only live for sets with key limbs
+        // Sets with key limbs: the limbs are walked from the highest down (the key is stored that way), so what the limbs before the last
+        // contribute is a multiple of 2^limb_bits -- with limb_bits >= 16 only its top 16 bits have to be carried through the last
+        // limb's row walk, two coefficients (r, r + R/2) to a register: R/2 registers per component where there were R (the full words
+        // were what spilled: 19 registers of scratch on the 80-bit set).  The last limb (shift 0) goes straight into the accumulator.
+        constexpr bool kPackDelta = PS::limbs > 1 && PS::limb_bits >= 16;
+        constexpr int kDeltaRegs = PS::limbs == 1 ? 1 : kPackDelta ? R / 2 : R;
+        uint32_t delta[K1][kDeltaRegs];      // only live for sets with key limbs
         if (PS::limbs > 1) {
 #pragma unroll
             for (int o = 0; o < K1; o++)
 #pragma unroll
-                for (int r = 0; r < R; r++) delta[o][r] = 0;
+                for (int r = 0; r < kDeltaRegs; r++) delta[o][r] = 0;
         }
 #pragma unroll 1
-        for (int limb = 0; limb < PS::limbs; limb++) {
+        for (int slot = 0; slot < PS::limbs; slot++) {
+            const int limb = PS::limbs - 1 - slot;
             double A[K1][R];
 #pragma unroll
             for (int o = 0; o < K1; o++)
@@ -570,16 +579,22 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const uint32_t v = fpf::lift_u32(A[o][r]);     // the limb's exact sum mod 2^32
-                    if (PS::limbs == 1) acc[o][r] += v;
-                    else delta[o][r] += v << shl;
+                    if (PS::limbs == 1) {
+                        acc[o][r] += v;
+                    } else if (limb > 0) {                         // v << shl is a multiple of 2^limb_bits
+                        if (kPackDelta) {
+                            const uint32_t top = (v << shl) >> 16;                 // bits 16..31 of the contribution
+                            if (r < R / 2) delta[o][r] = (delta[o][r] & 0xFFFF0000u) | ((delta[o][r] + top) & 0xFFFFu);
+                            else delta[o][r - R / 2] += top << 16;
+                        } else {
+                            delta[o][r] += v << shl;
+                        }
+                    } else {                                       // the last limb: everything into the accumulator
+                        const uint32_t carried = !kPackDelta ? delta[o][r] : r < R / 2 ? delta[o][r] << 16 : delta[o][r - R / 2] & 0xFFFF0000u;
+                        acc[o][r] += v + carried;
+                    }
                 }
             }
-        }
-        if (PS::limbs > 1) {
-#pragma unroll
-            for (int o = 0; o < K1; o++)
-#pragma unroll
-                for (int r = 0; r < R; r++) acc[o][r] += delta[o][r];
         }
     }
 

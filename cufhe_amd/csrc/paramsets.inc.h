@@ -1,8 +1,10 @@
 // paramsets.inc.h -- host side of the parameter-set-generic gate path (kernels_ps.hip.h); included by
 // capi.hip.  The reference chooses its parameter set when it is built (CMakeLists.txt:8-24); here every
-// set of kernels_ps.hip.h is compiled in and chosen by index at run time.  Gates take and return lvl0
-// ciphertexts of the chosen set: blind rotate -> sample extract -> key switch (__HomGate__ br -> iks,
-// src/bootstrap_gpu.cu:402-421; Mux :515-588; Not / Copy :681-703).
+// set of kernels_ps.hip.h is compiled in and chosen by index at run time ("param_set" puts the whole per-gate
+// API on one, as the reference's build-time choice does).  Both gate orders of the reference: on lvl0 ciphertexts
+// of the chosen set blind rotate -> sample extract -> key switch (__HomGate__ br -> iks, src/bootstrap_gpu.cu:402-421;
+// Mux :515-588), on lvl1 ciphertexts (k N + 1 words) key switch of the linear combination -> blind rotate -> sample
+// extract (__HomGate__ iks -> br, :383-400; Mux :706-780); Not / Copy :681-703.
 
 namespace {
 
@@ -112,13 +114,14 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
 }
 
 template <class PS, class GetGate>
-int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
+int ps_run_gates(int set, int device, void* stream, int level, size_t count, GetGate get)
 {
     using D = PsDims<PS>;
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     PsState& ps = ps_state(set, device);
     if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+    if (level != 0 && level != 1) return fail(-1, "level must be 0 or 1");
     if (count == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t negmu = 0u - kMu;
@@ -130,10 +133,13 @@ int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
         else if (op < CUFHE_AMD_MUX) nrot += 1;
     }
     Scratch sc;
-    if (int rc = open_scratch(s, st, nrot * D::lvl1_words * sizeof(uint32_t) + (count * 4 + 8) * sizeof(LinDesc) + 8192, &sc)) return rc;
-    uint32_t* tmp1 = nullptr;
-    if (nrot)
+    if (int rc = open_scratch(s, st, nrot * (D::lvl1_words + D::lvl0_words) * sizeof(uint32_t) + (count * 5 + 8) * sizeof(LinDesc) + 8192, &sc)) return rc;
+    uint32_t *tmp1 = nullptr, *tmp0 = nullptr;     // lvl1 / lvl0 temporaries, one per rotation
+    if (nrot) {
         if (int rc = sc.alloc((void**)&tmp1, nrot * D::lvl1_words * sizeof(uint32_t))) return rc;
+        if (level == 1)
+            if (int rc = sc.alloc((void**)&tmp0, nrot * D::lvl0_words * sizeof(uint32_t))) return rc;
+    }
     std::vector<LinDesc> rot, ks, lin;
     size_t ir = 0;
     for (size_t g = 0; g < count; g++) {
@@ -149,30 +155,61 @@ int ps_run_gates(int set, int device, void* stream, size_t count, GetGate get)
             uint32_t* ta = tmp1 + (ir + 0) * D::lvl1_words;
             uint32_t* tb = tmp1 + (ir + 1) * D::lvl1_words;
             const bool neg = gr.op == CUFHE_AMD_NMUX;
-            rot.push_back({gr.in0, gr.in1, ta, 1, 1, negmu, 0u});
-            rot.push_back({gr.in0, gr.in2, tb, -1, 1, negmu, 0u});
-            ks.push_back({ta, tb, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            if (level == 0) {   // src/bootstrap_gpu.cu:515-588
+                rot.push_back({gr.in0, gr.in1, ta, 1, 1, negmu, 0u});
+                rot.push_back({gr.in0, gr.in2, tb, -1, 1, negmu, 0u});
+                ks.push_back({ta, tb, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            } else {            // src/bootstrap_gpu.cu:706-780: two key switches, two rotations, the sum of the extracted ciphertexts
+                uint32_t* t0a = tmp0 + (ir + 0) * D::lvl0_words;
+                uint32_t* t0b = tmp0 + (ir + 1) * D::lvl0_words;
+                ks.push_back({gr.in0, gr.in1, t0a, 1, 1, negmu, 0u});
+                ks.push_back({gr.in0, gr.in2, t0b, -1, 1, negmu, 0u});
+                rot.push_back({t0a, t0a, ta, 1, 0, 0u, 0u});
+                rot.push_back({t0b, t0b, tb, 1, 0, 0u, 0u});
+                lin.push_back({ta, tb, gr.out, neg ? -1 : 1, neg ? -1 : 1, neg ? negmu : kMu, 0u});
+            }
             ir += 2;
             continue;
         }
-        uint32_t* t1 = tmp1 + ir * D::lvl1_words;
-        rot.push_back({gr.in0, gr.in1, t1, kGateTab[gr.op][0], kGateTab[gr.op][1], (uint32_t)kGateTab[gr.op][2] * kMu, 0u});
-        ks.push_back({t1, t1, gr.out, 1, 0, 0u, 0u});
+        const int ca = kGateTab[gr.op][0], cb = kGateTab[gr.op][1];
+        const uint32_t off = (uint32_t)kGateTab[gr.op][2] * kMu;
+        if (level == 0) {       // __HomGate__ br -> iks, src/bootstrap_gpu.cu:402-421
+            uint32_t* t1 = tmp1 + ir * D::lvl1_words;
+            rot.push_back({gr.in0, gr.in1, t1, ca, cb, off, 0u});
+            ks.push_back({t1, t1, gr.out, 1, 0, 0u, 0u});
+        } else {                // __HomGate__ iks -> br, src/bootstrap_gpu.cu:383-400
+            uint32_t* t0 = tmp0 + ir * D::lvl0_words;
+            ks.push_back({gr.in0, gr.in1, t0, ca, cb, off, 0u});
+            rot.push_back({t0, t0, gr.out, 1, 0, 0u, 0u});
+        }
         ir += 1;
     }
     LinDesc *drot, *dks, *dlin;
     if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
     if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
     if (int rc = upload_descs(s, sc, lin, &dlin)) return rc;
-    if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, nullptr)) return rc;
-    if (int rc = ps_launch_keyswitch<PS>(s, ps, st, dks, ks.size())) return rc;
-    return launch_lincomb(st, dlin, lin.size(), D::lvl0_words);
+    if (level == 0) {
+        if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, nullptr)) return rc;
+        if (int rc = ps_launch_keyswitch<PS>(s, ps, st, dks, ks.size())) return rc;
+    } else {
+        if (int rc = ps_launch_keyswitch<PS>(s, ps, st, dks, ks.size())) return rc;
+        if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, nullptr)) return rc;
+    }
+    return launch_lincomb(st, dlin, lin.size(), level ? D::lvl1_words : D::lvl0_words);
 }
 
 template <class GetGate>
-int run_gates_ps(int set, int device, void* stream, size_t count, GetGate get)
+int run_gates_ps(int set, int device, void* stream, int level, size_t count, GetGate get)
 {
-    return ps_dispatch(set, [&](auto psx) { return ps_run_gates<decltype(psx)>(set, device, stream, count, get); });
+    return ps_dispatch(set, [&](auto psx) { return ps_run_gates<decltype(psx)>(set, device, stream, level, count, get); });
+}
+
+// words of a level-0 / level-1 ciphertext of a set
+int ps_ctxt_words(int set, int level)
+{
+    int w = 0;
+    (void)ps_dispatch(set, [&](auto psx) { w = level ? PsDims<decltype(psx)>::lvl1_words : PsDims<decltype(psx)>::lvl0_words; return 0; });
+    return w;
 }
 
 void ps_release(int device)
@@ -259,16 +296,22 @@ int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const 
     });
 }
 
-int cufhe_amd_ps_gate_batch(int set, int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
-                            uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words)
+int cufhe_amd_ps_gate_batch_level(int set, int device, void* stream, int level, size_t count, const int32_t* ops, int ops_stride,
+                                  uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words)
 {
     if (!ops) return fail(-1, "null ops");
     return ps_dispatch(set, [&](auto psx) {
-        return ps_run_gates<decltype(psx)>(set, device, stream, count, [&](size_t g) {
+        return ps_run_gates<decltype(psx)>(set, device, stream, level, count, [&](size_t g) {
             return GateRef{ops[g * (size_t)ops_stride], out + g * stride_words, in0 ? in0 + g * stride_words : nullptr,
                            in1 ? in1 + g * stride_words : nullptr, in2 ? in2 + g * stride_words : nullptr};
         });
     });
+}
+
+int cufhe_amd_ps_gate_batch(int set, int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
+                            uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words)
+{
+    return cufhe_amd_ps_gate_batch_level(set, device, stream, 0, count, ops, ops_stride, out, in0, in1, in2, stride_words);
 }
 
 int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe0, uint32_t* acc, int steps)

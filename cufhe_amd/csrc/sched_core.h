@@ -71,7 +71,8 @@ class Backend {
     // returns the number of CPUs the thread was pinned to (0: left to the OS)
     virtual int bind_worker_thread() { bind_thread(); return 0; }
     virtual int num_streams() = 0;
-    virtual int words(int level) = 0;                                 // words of a level-`level` ciphertext
+    virtual int words(int level) = 0;                                 // words of a level-`level` ciphertext (what copies move)
+    virtual int slot_words(int level) { return words(level); }        // words a device slot must hold (>= words(level) at any time)
     virtual int alloc_device(size_t bytes, void** p) = 0;
     virtual int free_device(void* p) = 0;
     virtual int alloc_pinned(size_t bytes, void** p) = 0;
@@ -716,7 +717,7 @@ inline int DeviceSched::slot_alloc(int level, uint32_t** out)
 {
     std::vector<uint32_t*>& fl = free_slots_[level];
     if (fl.empty()) {
-        const size_t slot_bytes = ((size_t)be_->words(level) * 4 + 255) & ~(size_t)255;
+        const size_t slot_bytes = ((size_t)be_->slot_words(level) * 4 + 255) & ~(size_t)255;
         const size_t count = std::max<size_t>(16, std::min<size_t>(512, ((size_t)4 << 20) / slot_bytes));    // slabs of <= 4 MiB
         void* slab = nullptr;
         be_->bind_thread();

@@ -65,6 +65,12 @@ class HipBackend : public sched::Backend {
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
     int words(int level) override
     {
+        if (level <= 1 && g_lvl0_param_set >= 0) return ps_ctxt_words((int)g_lvl0_param_set, level);       // the active parameter set's sizes
+        return slot_words(level);
+    }
+    // device slots are carved for the largest ciphertext of any compiled set, so "param_set" may change while ciphertexts live
+    int slot_words(int level) override
+    {
         return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : level == 2 ? 2 * kN : (int)(2 * kBkStepDoubles);     // 3: TRGSW, NTT domain (doubles)
     }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
@@ -330,6 +336,13 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
     g_ctxt_owner.erase(it);
     S->ctxt_destroy(c);       // no flush, no wait: the buffers are recycled when the last gate naming them retires
     return 0;
+}
+
+int cufhe_amd_ctxt_words(int level)
+{
+    if (level < 0 || level > 1) return fail(-1, "level must be 0 or 1");
+    if (g_lvl0_param_set >= 0) return ps_ctxt_words((int)g_lvl0_param_set, level);
+    return level ? kLvl1Words : kLvl0Words;
 }
 
 uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)

@@ -247,8 +247,11 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * the C++ shim) runs through the N = 2048 path.
  * "lvl2_kernel" (default -1 = by measured cost): blind-rotate kernel of the N = 2048 ring: 1 = four quarter-transform waves per rotation with
  * register sums, two rotations per CU (launches above one rotation per CU); 0 = eight half-transform waves, one rotation per CU.
- * "lvl0_param_set" (default -1): index of a cufhe_amd_ps_* parameter set with n = 630 through which every level-0
- * entry point bootstraps instead (cufhe_amd_ps_initialize first).
+ * "param_set" (default -1; "lvl0_param_set" is the same option under its old name): index of a cufhe_amd_ps_* parameter set on
+ * which the whole per-gate API runs instead -- both ciphertext levels and both gate orders, as the set chosen when the reference
+ * is built serves every entry point (CMakeLists.txt:8-24); cufhe_amd_ps_initialize first.  Ciphertexts then have the set's sizes
+ * (cufhe_amd_ctxt_words: n + 1 and k N + 1 words; include/cufhe_amd.hpp selects the matching parameter structs with
+ * -DCUFHE_AMD_PARAM_SET_K2N512 / -DCUFHE_AMD_PARAM_SET_CGGI16).  Changing it waits for everything recorded.
  * "share_devices" (default 0): 1 lets SetGPUNum(G) exceed the visible GPU count, logical devices wrapping around the
  * physical ones (every logical device keeps its own key replica, scheduler, launch thread and streams): the
  * reference's multi-GPU programs (test/test_gate_gpu_multi.cc) rehearsed on fewer GPUs.
@@ -308,8 +311,8 @@ int cufhe_amd_lvl2_keyswitch_batch(int device, void* stream, size_t count, const
  * numbers as cufhe_amd_get_params, computed by the generic kernels), 1 = "k2n512" (k = 2 over the N = 512 ring),
  * 2 = "cggi16" (the original TFHE 80-bit set; its external product exceeds the exact range of the FP64 field, so
  * the key is taken in two 16-bit limbs).  The numeric parameters of TFHEpp's headers are not in the reference tree
- * (SURVEY.md F3): a set is what cufhe_amd_ps_get_params reports.  Gates take and return lvl0 ciphertexts of the
- * set (n + 1 words), keys use TFHEpp's layouts with the set's dimensions. */
+ * (SURVEY.md F3): a set is what cufhe_amd_ps_get_params reports.  Gates take and return ciphertexts of the set at
+ * either level (n + 1 or k N + 1 words), keys use TFHEpp's layouts with the set's dimensions. */
 typedef struct cufhe_amd_ps_params {
     char name[32];
     uint32_t n, N, nbit, k, l, Bgbit, t, basebit, key_limbs, key_limb_bits, mu;
@@ -319,6 +322,12 @@ typedef struct cufhe_amd_ps_params {
 int cufhe_amd_ps_count(void);
 int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* out);
 int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
+/* words of a level-0 / level-1 ciphertext of the per-gate API as configured now ("param_set") */
+int cufhe_amd_ctxt_words(int level);
+/* the same gates on ciphertexts of `level`: 0 = blind rotate then key switch on n + 1 words, 1 = key switch then blind rotate on
+ * k N + 1 words (the reference's two __HomGate__ orders, src/bootstrap_gpu.cu:383-421, Mux :515-588 / :706-780) */
+int cufhe_amd_ps_gate_batch_level(int set, int device, void* stream, int level, size_t count, const int32_t* ops, int ops_stride,
+                                  uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words);
 /* same contract as cufhe_amd_gate_batch at level 0 */
 int cufhe_amd_ps_gate_batch(int set, int device, void* stream, size_t count, const int32_t* ops, int ops_stride,
                             uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2,

@@ -26,6 +26,22 @@
 
 #include "cufhe_amd.h"
 
+// The reference picks its parameter set when it is BUILT (CMakeLists.txt:8-24: USE_80BIT_SECURITY, USE_CGGI19, USE_CONCRETE ... select
+// TFHEpp's structs); every entry point and both gate orders then run on that set.  Here the library carries its sets compiled in
+// (cufhe_amd_ps_*), and this header picks one the same way, at build time of the CALLER:
+//   (none)                         the BASELINE set, hand-tuned kernels         n = 630, N = 1024, k = 1, l = 3, Bg = 2^6
+//   -DCUFHE_AMD_PARAM_SET_K2N512   set 1 of cufhe_amd_ps_get_params              n = 630, N = 512,  k = 2, l = 3, Bg = 2^6
+//   -DCUFHE_AMD_PARAM_SET_CGGI16   set 2, the original TFHE 80-bit set          n = 500, N = 1024, k = 1, l = 2, Bg = 2^10
+// Initialize(bk, ..) then loads the keys into that set and switches the per-gate API onto it ("param_set"): Ctxt<lvl0param> has
+// n + 1 words of the set, Ctxt<lvl1param> k N + 1, And ... NMux run blind rotate -> key switch on the first and key switch ->
+// blind rotate on the second (src/bootstrap_gpu.cu:383-421).  The TRLWE-level operations and the N = 2048 ring stay with the
+// BASELINE set.
+#if defined(CUFHE_AMD_PARAM_SET_K2N512)
+#define CUFHE_AMD_PARAM_SET_INDEX 1
+#elif defined(CUFHE_AMD_PARAM_SET_CGGI16)
+#define CUFHE_AMD_PARAM_SET_INDEX 2
+#endif
+
 #ifdef CUFHE_AMD_USE_TFHEPP
 #include <cloudkey.hpp>
 #include <params.hpp>
@@ -33,13 +49,23 @@
 namespace TFHEpp {
 struct lvl0param {
     using T = uint32_t;
+#if defined(CUFHE_AMD_PARAM_SET_CGGI16)
+    static constexpr uint32_t n = 500, k = 1;
+#else
     static constexpr uint32_t n = 630, k = 1;
+#endif
     static constexpr T mu = 1u << 29;
     static constexpr T μ = mu;             // TFHEpp's spelling
 };
 struct lvl1param {
     using T = uint32_t;
+#if defined(CUFHE_AMD_PARAM_SET_K2N512)
+    static constexpr uint32_t nbit = 9, n = 1u << nbit, k = 2, l = 3, Bgbit = 6, Bg = 1u << Bgbit;
+#elif defined(CUFHE_AMD_PARAM_SET_CGGI16)
+    static constexpr uint32_t nbit = 10, n = 1u << nbit, k = 1, l = 2, Bgbit = 10, Bg = 1u << Bgbit;
+#else
     static constexpr uint32_t nbit = 10, n = 1u << nbit, k = 1, l = 3, Bgbit = 6, Bg = 1u << Bgbit;
+#endif
     static constexpr T mu = 1u << 29;
     static constexpr T μ = mu;
 };
@@ -89,7 +115,18 @@ inline void Initialize() { CUFHE_AMD_CHECK(cufhe_amd_initialize_ntt()); }
 /// bk: [n][(k+1)l][k+1][N], ksk: [kN][t][2^(basebit-1)][n+1] torus words (TFHEpp's in-memory layouts)
 inline void Initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
 {
+#ifdef CUFHE_AMD_PARAM_SET_INDEX
+    CUFHE_AMD_CHECK(cufhe_amd_initialize_ntt());
+    CUFHE_AMD_CHECK(cufhe_amd_ps_initialize(CUFHE_AMD_PARAM_SET_INDEX, bk, bk_words, ksk, ksk_words));
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("param_set", CUFHE_AMD_PARAM_SET_INDEX));
+    if (cufhe_amd_ctxt_words(0) != (int)(TFHEpp::lvl0param::k * TFHEpp::lvl0param::n + 1) ||
+        cufhe_amd_ctxt_words(1) != (int)(TFHEpp::lvl1param::k * TFHEpp::lvl1param::n + 1)) {
+        std::fprintf(stderr, "cufhe_amd.hpp: the parameter structs of this build do not match parameter set %d of the library\n", CUFHE_AMD_PARAM_SET_INDEX);
+        std::exit(-1);
+    }
+#else
     CUFHE_AMD_CHECK(cufhe_amd_initialize(bk, bk_words, ksk, ksk_words));
+#endif
 }
 #ifdef CUFHE_AMD_USE_TFHEPP
 inline void Initialize(const TFHEpp::EvalKey& ek)
@@ -234,6 +271,7 @@ CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
 // reference, results are in the host members after Synchronize() or StreamQuery(st) == true.  TRGSW2NTT completes
 // before returning (the reference waits for its D2H copy too).
 
+#ifndef CUFHE_AMD_PARAM_SET_INDEX      // the TRLWE-level operations run on the BASELINE set only
 /// struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134
 struct cuFHETRLWElvl1 {
     TFHEpp::TRLWE<TFHEpp::lvl1param> trlwehost;
@@ -320,6 +358,7 @@ inline void gCMUXNTT(cuFHETRLWElvl1& res, cuFHETRGSWNTTlvl1& cs, cuFHETRLWElvl1&
 {
     CUFHE_AMD_CHECK(cufhe_amd_enqueue_cmux(st.device_id(), st.st(), 0, res.handle, cs.handle, c1.handle, c0.handle));
 }
+#endif  // CUFHE_AMD_PARAM_SET_INDEX
 
 #undef CUFHE_AMD_GATE1
 #undef CUFHE_AMD_GATE2

@@ -18,7 +18,7 @@
 
 using namespace cufhe;
 
-static std::vector<uint32_t> g_s0(ORC_n), g_s1(ORC_N);
+static std::vector<uint32_t> g_s0(ORC_n), g_s1(ORC_K * ORC_N);
 static orc_rng g_rng;
 static int g_failures = 0;
 
@@ -261,6 +261,7 @@ void MixedAtSize(std::mt19937& eng)
     delete[] st;
 }
 
+#ifndef CUFHE_AMD_PARAM_SET_INDEX
 // test/test_perf.cc:36-87 (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt coefficient 0)
 // and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch.
 void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
@@ -407,6 +408,8 @@ void Lvl2Gates(std::mt19937& eng)
     CUFHE_AMD_CHECK(cufhe_amd_set_option("lvl0_ring", 1024));
 }
 
+#endif  // CUFHE_AMD_PARAM_SET_INDEX
+
 // Source written against the reference's header touches its public globals and the stream type directly
 // (include/cufhe_gpu.cuh:44-46 `extern int _gpuNum; extern int streamCount;`, :154-165 the default Stream constructor,
 // :183 `cudaStream_t st()`): the same lines must compile and behave here.
@@ -464,6 +467,18 @@ int main(int argc, char** argv)
     ReferenceGlobals(gpus);
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc
     AllGates<TFHEpp::lvl0param>(kNumSMs, kNumTests, eng);   // test_gate_gpu_multi.cc
+#ifdef CUFHE_AMD_PARAM_SET_INDEX
+    // a build on another parameter set (-DCUFHE_AMD_PARAM_SET_... with the oracle compiled for the same set, -DORC_SET_...): the
+    // gate tests above ran key switch -> blind rotate on lvl1 ciphertexts and blind rotate -> key switch on lvl0 ciphertexts of
+    // that set; then the programs that only need gates
+    Chained(eng);
+    Intensive(eng);
+    DeviceResident(eng);
+    RippleAdders(eng);
+    CleanUp();
+    std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
+    return g_failures ? 1 : 0;
+#else
     if (getenv("CUFHE_AMD_TEST_QUICK")) {                   // the gate tests and the lvl2 keys only (the USE_TFHEPP build's run)
         Lvl2Gates(eng);
         CleanUp();
@@ -481,4 +496,5 @@ int main(int argc, char** argv)
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
     return g_failures ? 1 : 0;
+#endif
 }

@@ -13,12 +13,17 @@ convolution in 64-bit integers (no transform, no prime, no floating point), writ
   sample extract at index 0           src/bootstrap_gpu.cu:366-381
   key switch                          include/keyswitch_gpu.cuh:13-23 (iksoffsetgen), :83-134 (KeySwitchFromTLWE)
 
-It writes tests/golden/golden_independent_v3.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
+It writes tests/golden/golden_independent_v4.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
 NMUX on level-0 ciphertexts (blind rotate, then key switch), NAND on level-1 ciphertexts (the other order:
 IdentityKeySwitchPreAdd, then __BlindRotate__; src/bootstrap_gpu.cu:383-400, include/keyswitch_gpu.cuh:136-188), and one
 NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
 defines that path); NAND, XOR and MUX on the k = 2 / N = 512 set and NAND, ORYN on the n = 500 / l = 2 / Bg = 2^10 set
-(DESIGN.md 5b).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
+(DESIGN.md 5b).  Since v4 also the inputs at which a misreading is most likely to hide (the cases the oracle tests feed the
+kernels, tests/test_gpu_parity.py): runs of abar = 0 (include/gatebootstrapping_gpu.cuh:157-181: (X^0 - 1) acc = 0, the digits of the
+bare offset), bbar = 2N / N / 1 (:29-52, the three branches of the test vector), input words 0x7FFFFFFF, a key whose first two CMux
+steps are all 0x80000000 and whose other words are drawn from {0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001} (the external
+product's sums closest to the exactness bound), MUX on level-1 ciphertexts (src/bootstrap_gpu.cu:706-743: two key switches, two
+blind rotations, the sum of the two EXTRACTED ciphertexts) and Not / Copy (:681-703).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
 key words define a word-level check); the fixture stores the seeds, a sha256 of each generated key, the inputs and the
 expected output words.  Takes a few minutes; run in the build container only:  python tests/golden/make_golden_independent.py
 """
@@ -204,14 +209,79 @@ def key_for(seed, R):
     return bk, ksk, {"seed": seed, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
 
 
+def gate_mux_level1(inc, in1, in0, bk, ksk, R):
+    """__MuxBootstrap__<iksP, brP, mu> on level-1 ciphertexts (src/bootstrap_gpu.cu:706-743): key switch of inc + in1 - mu, blind
+    rotation, sample extract; the same for -inc + in0 - mu; the two extracted ciphertexts added, mu added to b"""
+    def leg(ca, x):
+        pre = [(ca * int(a) + int(b)) & R.mask for a, b in zip(inc, x)]
+        pre[R.k * R.N] = (pre[R.k * R.N] - MU0) & R.mask
+        return sample_extract0(blind_rotate(keyswitch(pre, ksk, R), bk, R), R)
+    t1, t0 = leg(1, in1), leg(-1, in0)
+    out = [(a + b) & R.mask for a, b in zip(t1, t0)]
+    out[R.k * R.N] = (out[R.k * R.N] + R.mu) & R.mask
+    return out
+
+
+EXTREME_WORDS = (0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001)
+
+
+def key_extreme(seed, R):
+    """key words of maximal magnitude: the first two CMux steps all 0x80000000 (-2^31 in a signed reading), the rest drawn from
+    EXTREME_WORDS; the key-switching key uniform (drawn after the bootstrapping key, from the same generator)"""
+    rng = np.random.default_rng(seed)
+    K1 = R.k + 1
+    ext = np.array(EXTREME_WORDS, np.uint32)
+    bk = ext[rng.integers(0, ext.size, R.n * K1 * R.l * K1 * R.N)]
+    bk[: 2 * K1 * R.l * K1 * R.N] = 0x80000000
+    bk = bk.reshape(R.n, K1 * R.l, K1, R.N)
+    ksk = random_words(rng, R.k * R.N * R.t * 2 * (R.n + 1)).reshape(R.k * R.N, R.t, 2, R.n + 1)
+    return bk, ksk, {"seed": seed, "kind": "extreme", "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(),
+                     "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
+
+
+def edge_inputs(irng):
+    """level-0 operand pairs whose linear combinations hit the corners of modswitch / RotatedTestVector:
+       a: NAND (c = -in0 - in1 + mu):  c.a[0..7] = c.a[100] = c.a[629] = 0 -> abar = 0 ;  c.b = 0           -> bbar = 2N
+       b: AND  (c =  in0 + in1 - mu):  c.a[0..7] = 0x7FFFFFFF              -> abar = N ;  c.b = 0x80000000 -> bbar = N
+       c: OR   (c =  in0 + in1 + mu):  c.a[0..3] = 0xFFFFFFFF (rounds up to abar = 2N, i.e. 0)  ;  c.b = 0xFFFFFFFF -> bbar = 1"""
+    prs = []
+    for _ in range(3):
+        prs.append([random_words(irng, 631).astype(np.int64), random_words(irng, 631).astype(np.int64)])
+    a0, a1 = prs[0]
+    for i in list(range(8)) + [100, 629]:
+        a1[i] = (-a0[i]) & 0xFFFFFFFF                    # -in0 - in1 = 0
+    a1[630] = (MU0 - a0[630]) & 0xFFFFFFFF               # -b0 - b1 + mu = 0
+    b0, b1 = prs[1]
+    for i in range(8):
+        b1[i] = (0x7FFFFFFF - b0[i]) & 0xFFFFFFFF
+    b1[630] = (0x80000000 + MU0 - b0[630]) & 0xFFFFFFFF
+    c0, c1 = prs[2]
+    for i in range(4):
+        c1[i] = (0xFFFFFFFF - c0[i]) & 0xFFFFFFFF
+    c1[630] = (0xFFFFFFFF - MU0 - c0[630]) & 0xFFFFFFFF
+    return [[x.astype(np.uint32) for x in p] for p in prs]
+
+
 def main():
-    out = {"format": 3, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
+    out = {"format": 4, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
     t0 = time.time()
     irng = np.random.default_rng(777)
     ins0 = [random_words(irng, 631) for _ in range(3)]
     ins1 = [random_words(irng, 1025) for _ in range(2)]
     ins500 = [random_words(irng, 501) for _ in range(2)]
-    out["inputs"] = {"level0": [x.tolist() for x in ins0], "level1": [x.tolist() for x in ins1], "level0_n500": [x.tolist() for x in ins500]}
+    # drawn after everything the v3 fixture drew, so that its cases keep their words
+    ins1.append(random_words(irng, 1025))
+    edges = edge_inputs(irng)
+    out["inputs"] = {"level0": [x.tolist() for x in ins0], "level1": [x.tolist() for x in ins1], "level0_n500": [x.tolist() for x in ins500],
+                     "level0_edge_a": [x.tolist() for x in edges[0]], "level0_edge_b": [x.tolist() for x in edges[1]],
+                     "level0_edge_c": [x.tolist() for x in edges[2]]}
+    # the corners are where they are meant to be (python integers, the reference's formulas)
+    ca = lincomb(-1, edges[0][0], -1, edges[0][1], MU0)
+    assert all(modswitch(ca[i] + (1 << 20), LVL1) == 0 for i in list(range(8)) + [100, 629]) and 2 * 1024 - modswitch(ca[630], LVL1) == 2048
+    cb = lincomb(1, edges[1][0], 1, edges[1][1], -MU0)
+    assert all(modswitch(cb[i] + (1 << 20), LVL1) == 1024 for i in range(8)) and 2 * 1024 - modswitch(cb[630], LVL1) == 1024
+    cc = lincomb(1, edges[2][0], 1, edges[2][1], MU0)
+    assert all(modswitch(cc[i] + (1 << 20), LVL1) == 0 for i in range(4)) and 2 * 1024 - modswitch(cc[630], LVL1) == 1
     # --- BASELINE set: n = 630, N = 1024
     bk, ksk, key1 = key_for(20261004, LVL1)
     for op in GATES:
@@ -225,6 +295,23 @@ def main():
     print("NAND, default set, level 1", flush=True)
     out["cases"].append({"set": "default", "level": 1, "op": "NAND", "key": key1, "inputs": "level1", "operands": [0, 1],
                          "expected": gate2_level1("NAND", ins1[0], ins1[1], bk, ksk, LVL1)})
+    for op, tag in (("NAND", "a"), ("AND", "b"), ("OR", "c")):
+        print(op, "default set, level 0, edge inputs", tag, flush=True)
+        e = edges["abc".index(tag)]
+        out["cases"].append({"set": "default", "level": 0, "op": op, "key": key1, "inputs": "level0_edge_" + tag, "operands": [0, 1],
+                             "expected": gate2(op, e[0], e[1], bk, ksk, LVL1)})
+    print("MUX, default set, level 1", flush=True)
+    out["cases"].append({"set": "default", "level": 1, "op": "MUX", "key": key1, "inputs": "level1", "operands": [0, 1, 2],
+                         "expected": gate_mux_level1(ins1[0], ins1[1], ins1[2], bk, ksk, LVL1)})
+    # Not / Copy: no bootstrapping (src/bootstrap_gpu.cu:681-703)
+    out["cases"].append({"set": "default", "level": 0, "op": "NOT", "key": key1, "inputs": "level0", "operands": [2],
+                         "expected": [(-int(v)) & 0xFFFFFFFF for v in ins0[2]]})
+    out["cases"].append({"set": "default", "level": 1, "op": "COPY", "key": key1, "inputs": "level1", "operands": [1],
+                         "expected": [int(v) for v in ins1[1]]})
+    bkx, kskx, keyx = key_extreme(20261008, LVL1)
+    print("NAND, default set, level 0, extreme key words", flush=True)
+    out["cases"].append({"set": "default", "level": 0, "op": "NAND", "key": keyx, "inputs": "level0", "operands": [0, 1],
+                         "expected": gate2("NAND", ins0[0], ins0[1], bkx, kskx, LVL1)})
     # --- the other compiled parameter sets
     bk, ksk, key = key_for(20261006, K2N512)
     for op in ("NAND", "XOR"):
@@ -234,18 +321,24 @@ def main():
     print("MUX, k2n512", flush=True)
     out["cases"].append({"set": "k2n512", "level": 0, "op": "MUX", "key": key, "inputs": "level0", "operands": [0, 1, 2],
                          "expected": gate_mux(ins0[0], ins0[1], ins0[2], bk, ksk, K2N512)})
+    print("NAND, k2n512, level 1 (k N + 1 = 1025 words)", flush=True)
+    out["cases"].append({"set": "k2n512", "level": 1, "op": "NAND", "key": key, "inputs": "level1", "operands": [0, 1],
+                         "expected": gate2_level1("NAND", ins1[0], ins1[1], bk, ksk, K2N512)})
     bk, ksk, key = key_for(20261007, CGGI16)
     for op in ("NAND", "ORYN"):
         print(op, "cggi16 (n = 500, l = 2, Bg = 2^10)", flush=True)
         out["cases"].append({"set": "cggi16", "level": 0, "op": op, "key": key, "inputs": "level0_n500", "operands": [0, 1],
                              "expected": gate2(op, ins500[0], ins500[1], bk, ksk, CGGI16)})
+    print("XOR, cggi16, level 1", flush=True)
+    out["cases"].append({"set": "cggi16", "level": 1, "op": "XOR", "key": key, "inputs": "level1", "operands": [0, 1],
+                         "expected": gate2_level1("XOR", ins1[0], ins1[1], bk, ksk, CGGI16)})
     # --- N = 2048 ring, 64-bit torus
     bk2, ksk2, key2 = key_for(20261005, LVL2)
     print("NAND, N = 2048", flush=True)
     out["cases"].append({"set": "lvl2", "level": 0, "op": "NAND", "key": key2, "inputs": "level0", "operands": [0, 1],
                          "expected": gate2("NAND", ins0[0], ins0[1], bk2, ksk2, LVL2)})
     out["seconds"] = round(time.time() - t0, 1)
-    dst = os.path.join(HERE, "golden_independent_v3.json")
+    dst = os.path.join(HERE, "golden_independent_v4.json")
     json.dump(out, open(dst, "w"))
     print("wrote", dst, out["seconds"], "s")
 

@@ -1,10 +1,12 @@
 """Words of full-size gates against a fixture that shares no code with the oracle or the kernels.
 
-tests/golden/golden_independent_v3.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
+tests/golden/golden_independent_v4.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
 integers, the external product as an exact schoolbook negacyclic convolution (no transform), restated from the
 reference's text.  Both the C oracle (CPU test) and the HIP path (GPU test) must reproduce its words: all ten two-input
 gates, MUX and NMUX on level-0 ciphertexts and NAND on level-1 ciphertexts of the BASELINE set, one NAND through the
-N = 2048 ring, and a few gates on each of the other compiled parameter sets (k = 2 / N = 512; n = 500 / l = 2 / Bg = 2^10).  Keys are regenerated from the fixture's seeds and checked
+N = 2048 ring, and a few gates on each of the other compiled parameter sets (k = 2 / N = 512; n = 500 / l = 2 / Bg = 2^10); since v4 also
+the corner inputs the oracle tests use (runs of abar = 0, bbar = 2N / N / 1, words 0x7FFFFFFF, a key of extreme words), MUX on level-1
+ciphertexts and Not / Copy.  Keys are regenerated from the fixture's seeds and checked
 against its sha256 sums -- a mismatch there is a failure, not a skip."""
 import hashlib
 import json
@@ -15,7 +17,7 @@ import pytest
 
 import oracle_lib as ol
 
-FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v3.json")
+FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v4.json")
 OPS = {n: i for i, n in enumerate(ol.OPS)}
 
 
@@ -38,7 +40,12 @@ def keys_for(case):
     if (name, seed) not in _keys:
         n, N, k, l, bits, t = SETS[name]
         rng = np.random.default_rng(seed)
-        bk = words(n * (k + 1) * l * (k + 1) * N, rng, bits)
+        if case["key"].get("kind") == "extreme":     # the generator's key_extreme(): first two CMux steps -2^31, the rest from five extreme words
+            ext = np.array((0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001), np.uint32)
+            bk = ext[rng.integers(0, ext.size, n * (k + 1) * l * (k + 1) * N)]
+            bk[: 2 * (k + 1) * l * (k + 1) * N] = 0x80000000
+        else:
+            bk = words(n * (k + 1) * l * (k + 1) * N, rng, bits)
         ksk = words(k * N * t * 2 * (n + 1), rng)
         assert hashlib.sha256(bk.tobytes()).hexdigest() == case["key"]["bk_sha256"], "numpy generated other key words than the fixture was made with"
         assert hashlib.sha256(ksk.tobytes()).hexdigest() == case["key"]["ksk_sha256"]
@@ -61,8 +68,23 @@ def cases():
 def test_fixture_is_what_the_generator_describes():
     fx = fixture()
     got = [(c["set"], c["level"], c["op"]) for c in fx["cases"]]
-    assert got == [("default", 0, op) for op in ol.OPS[:12]] + [("default", 1, "NAND"), ("k2n512", 0, "NAND"), ("k2n512", 0, "XOR"),
-                                                                ("k2n512", 0, "MUX"), ("cggi16", 0, "NAND"), ("cggi16", 0, "ORYN"), ("lvl2", 0, "NAND")]
+    assert got == [("default", 0, op) for op in ol.OPS[:12]] + [("default", 1, "NAND"),
+                                                                ("default", 0, "NAND"), ("default", 0, "AND"), ("default", 0, "OR"),      # corner inputs
+                                                                ("default", 1, "MUX"), ("default", 0, "NOT"), ("default", 1, "COPY"),
+                                                                ("default", 0, "NAND"),                                                   # extreme key words
+                                                                ("k2n512", 0, "NAND"), ("k2n512", 0, "XOR"),
+                                                                ("k2n512", 0, "MUX"), ("k2n512", 1, "NAND"), ("cggi16", 0, "NAND"), ("cggi16", 0, "ORYN"),
+                                                                ("cggi16", 1, "XOR"), ("lvl2", 0, "NAND")]
+    assert [c["inputs"] for c in fx["cases"][13:16]] == ["level0_edge_a", "level0_edge_b", "level0_edge_c"] and fx["cases"][19]["key"]["kind"] == "extreme"
+    # the corner inputs sit where the generator says (the reference's modswitch, include/gatebootstrapping_gpu.cuh:10-16, on python integers)
+    e = {t: [np.array(x, np.uint32).astype(np.int64) for x in fx["inputs"]["level0_edge_" + t]] for t in "abc"}
+    ms = lambda v: (int(v) & 0xFFFFFFFF) >> 21
+    ca = (-e["a"][0] - e["a"][1]) & 0xFFFFFFFF
+    assert all(ms(ca[i] + (1 << 20)) == 0 for i in list(range(8)) + [100, 629]) and 2048 - ms(ca[630] + (1 << 29)) == 2048
+    cb = (e["b"][0] + e["b"][1]) & 0xFFFFFFFF
+    assert all(ms(cb[i] + (1 << 20)) == 1024 for i in range(8)) and 2048 - ms(cb[630] - (1 << 29)) == 1024
+    cc = (e["c"][0] + e["c"][1]) & 0xFFFFFFFF
+    assert all(ms(cc[i] + (1 << 20)) == 0 for i in range(4)) and 2048 - ms(cc[630] + (1 << 29)) == 1
     for c in fx["cases"]:
         n, N, k = SETS[c["set"]][:3]
         assert len(c["expected"]) == (k * N + 1 if c["level"] else n + 1)
@@ -76,14 +98,15 @@ def test_oracle_words_match_independent_generator(oracle):
         got = np.zeros(want.size, np.uint32)
         op = np.array([OPS[case["op"]]], np.int32)
         third = ins[2].ctypes.data if len(ins) > 2 else None
+        second = ins[1].ctypes.data if len(ins) > 1 else None
         if case["set"] == "lvl2":
             ek = oracle.orc2_evalkey_create(bk, ksk)
-            oracle.orc2_gate_batch(ek, op, 0, 1, got, ins[0], ins[1].ctypes.data, third, 1)
+            oracle.orc2_gate_batch(ek, op, 0, 1, got, ins[0], second, third, 1)
             oracle.orc2_evalkey_destroy(ek)
         else:
             L = ol.load_set(case["set"])           # the oracle compiled for the set ("default" = liboracle.so)
             ek = L.orc_evalkey_create(bk, ksk)
-            L.orc_gate_batch(ek, op, 0, case["level"], 1, got, ins[0], ins[1].ctypes.data, third, 1)
+            L.orc_gate_batch(ek, op, 0, case["level"], 1, got, ins[0], second, third, 1)
             L.orc_evalkey_destroy(ek)
         assert np.array_equal(got, want), f"oracle words differ from the independent generator: {case['set']} level {case['level']} {case['op']}"
 
@@ -101,7 +124,7 @@ loaded = None
 for case, ins, want in tg.cases():
     bk, ksk = tg.keys_for(case)
     name = case["set"]
-    if loaded != name:
+    if loaded != (name, case["key"]["seed"]):
         if name == "default":
             eng.Initialize(bk, ksk)
         elif name == "lvl2":
@@ -110,17 +133,18 @@ for case, ins, want in tg.cases():
         else:
             eng.Initialize()
             api.ps_initialize(ps_index[name], bk, ksk)
-        loaded = name
+        loaded = (name, case["key"]["seed"])
     d = [api.DeviceBuffer(x.size).upload(x) for x in ins]
     out = api.DeviceBuffer(want.size)
+    second = d[1] if len(d) > 1 else None
     third = d[2] if len(d) > 2 else None
     op = tg.OPS[case["op"]]
     if name == "default":
-        api.gate_batch(op, case["level"], out, d[0], d[1], third, count=1)
+        api.gate_batch(op, case["level"], out, d[0], second, third, count=1)
     elif name == "lvl2":
-        api.lvl2_gate_batch(op, out, d[0], d[1], third, count=1)
+        api.lvl2_gate_batch(op, out, d[0], second, third, count=1)
     else:
-        api.ps_gate_batch(ps_index[name], op, out, d[0], d[1], third, count=1)
+        api.ps_gate_batch(ps_index[name], op, out, d[0], second, third, count=1, level=case["level"])
     eng.Synchronize()
     assert np.array_equal(out.download(), want), \
         f"HIP words differ from the independent generator: {name} level {case['level']} {case['op']}"

@@ -106,19 +106,22 @@ def test_keyswitch_words(engine, pset):
             assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g} (ks_wg_threshold {thr})"
 
 
-def test_every_gate_words_and_truth_table(engine, pset, keys):
+@pytest.mark.parametrize("level", [0, 1])
+def test_every_gate_words_and_truth_table(engine, pset, keys, level):
+    """level 0: __HomGate__ br -> iks on n + 1 words (src/bootstrap_gpu.cu:402-421, Mux :515-588); level 1: the other order on
+    k N + 1 words, key switch of the linear combination first (:383-400, Mux :706-780) -- every op, every set, both launch shapes"""
     name, idx, L, K = pset
     combos = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.uint8)
     count = len(combos)
-    ins = [K.encrypt(combos[:, i], 0, seed=900 + i) for i in range(3)]
+    ins = [K.encrypt(combos[:, i], level, seed=900 + i) for i in range(3)]
     dins = [_up(engine, x) for x in ins]
-    dout = engine.api.DeviceBuffer(count * K.words[0])
+    dout = engine.api.DeviceBuffer(count * K.words[level])
     for op in range(14):
-        engine.api.ps_gate_batch(idx, op, dout, dins[0], dins[1], dins[2], count=count)
+        engine.api.ps_gate_batch(idx, op, dout, dins[0], dins[1], dins[2], count=count, level=level)
         got = dout.download().reshape(count, -1)
-        assert np.array_equal(got, K.gate_batch(op, 0, ins[0], ins[1], ins[2])), f"{name} {ol.OPS[op]}: words differ from the oracle"
-        assert list(K.decrypt(got, 0)) == [ol.truth(L, op, *map(int, c)) for c in combos], f"{name} {ol.OPS[op]}: decrypt != truth table"
-    if name == "default":
+        assert np.array_equal(got, K.gate_batch(op, level, ins[0], ins[1], ins[2])), f"{name} {ol.OPS[op]} level {level}: words differ from the oracle"
+        assert list(K.decrypt(got, level)) == [ol.truth(L, op, *map(int, c)) for c in combos], f"{name} {ol.OPS[op]} level {level}: decrypt != truth table"
+    if name == "default" and level == 0:
         # the generic kernels and the hand-scheduled ones are two implementations of one function
         engine.Initialize(K.bk, K.ksk)
         try:
@@ -145,26 +148,25 @@ def test_mixed_batch(engine, pset):
     assert list(K.decrypt(got, 0)) == [ol.truth(L, int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
 
 
-def test_per_gate_api_over_a_parameter_set(engine, pset):
-    """cufhe_amd_set_option("lvl0_param_set"): the Stream / Ctxt / Nand ... surface and its scheduler over another set
-    (sets with the default n only: the per-gate API's lvl0 ciphertexts keep their size)."""
+@pytest.mark.parametrize("level", [0, 1])
+def test_per_gate_api_over_a_parameter_set(engine, pset, level):
+    """cufhe_amd_set_option("param_set"): the Stream / Ctxt / Nand ... surface and its scheduler over another set, both ciphertext
+    levels -- the 80-bit set included, whose lvl0 ciphertexts have 501 words (Ctxt takes its size from the active set; the device
+    slots are carved for the largest compiled size)."""
     name, idx, L, K = pset
     api = engine.api
-    if K.n != ol.n:
-        with pytest.raises(engine.CufheAmdError):
-            api.set_option("lvl0_param_set", idx)
-        return
-    api.set_option("lvl0_param_set", idx)
+    api.set_option("param_set", idx)
     try:
+        assert [api.Ctxt(lv).tlwehost.size for lv in (0, 1)] == [K.words[0], K.words[1]]
         count = 24
         rng = np.random.default_rng(31)
         bits = rng.integers(0, 2, size=(3, count)).astype(np.uint8)
-        enc = [K.encrypt(bits[i], 0, seed=3100 + i) for i in range(3)]
-        cts = [[api.Ctxt(0) for _ in range(count)] for _ in range(3)]
+        enc = [K.encrypt(bits[i], level, seed=3100 + i) for i in range(3)]
+        cts = [[api.Ctxt(level) for _ in range(count)] for _ in range(3)]
         for i in range(3):
             for g in range(count):
                 cts[i][g].tlwehost[:] = enc[i][g]
-        outs = [api.Ctxt(0) for _ in range(count)]
+        outs = [api.Ctxt(level) for _ in range(count)]
         sts = [api.Stream() for _ in range(4)]
         for s in sts:
             s.Create()
@@ -173,8 +175,35 @@ def test_per_gate_api_over_a_parameter_set(engine, pset):
         api.Synchronize()
         ops = np.array([[0, 5, 10][g % 3] for g in range(count)], np.int32)
         got = np.stack([o.tlwehost for o in outs])
-        assert np.array_equal(got, K.gate_batch(ops, 0, enc[0], enc[1], enc[2]))
+        assert np.array_equal(got, K.gate_batch(ops, level, enc[0], enc[1], enc[2]))
+        assert list(K.decrypt(got, level)) == [ol.truth(L, int(ops[g]), int(bits[0, g]), int(bits[1, g]), int(bits[2, g])) for g in range(count)]
         for s in sts:
             s.Destroy()
     finally:
-        api.set_option("lvl0_param_set", -1)
+        api.set_option("param_set", -1)
+    assert api.Ctxt(0).tlwehost.size == ol.n + 1
+
+
+@pytest.mark.parametrize("name", ["cggi16", "k2n512"])
+def test_cpp_gate_api_on_a_parameter_set(engine, name):
+    """The reference's own test programs (tests/cpp/test_gate_api.cpp: test_gate_gpu.cc on lvl1 ciphertexts, test_gate_gpu_multi.cc on
+    lvl0, test_api_gpu.cu's chains, test_intensive.cc, the ripple-carry adders) compiled the way a user picks a set in the reference --
+    at build time (CMakeLists.txt:8-24; here -DCUFHE_AMD_PARAM_SET_<SET> for include/cufhe_amd.hpp and -DORC_SET_<SET> for the oracle's
+    key generation and decryption) -- through the cufhe:: API: every gate of both orders decrypts to its truth table."""
+    import os
+    import subprocess
+    root = ol.ROOT
+    exe = os.path.join(root, "tests", "cpp", "test_gate_api_" + name)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DCUFHE_AMD_PARAM_SET_" + name.upper(), "-DORC_SET_" + name.upper(), "-o", exe,
+                           os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
+                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle_" + name,
+                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        k = ol.Keys(ol.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
