@@ -97,7 +97,6 @@ int phys_device(int device)
     if (g_share_devices && g_phys_count > 0) return (g_device_base + device) % g_phys_count;
     return device + g_device_base;
 }
-long g_wg_threshold = 0;    // rotations per launch up to which the workgroup-per-rotation kernel is used
 long g_ks_split_threshold = -1; // key switches per launch up to which each ciphertext is split over 8 workgroups
 // Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, tools/ks_per_wg.py, MI355X, ms per launch of n key switches):
 //   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.66 (2048)
@@ -105,8 +104,10 @@ long g_ks_split_threshold = -1; // key switches per launch up to which each ciph
 //   table through LDS, ceil(n / 256) ciphertexts per workgroup (one grid round, every CU busy):
 //                                 0.94 (256)  1.07 (512)  1.17 (1024)  1.23 (1536)  1.27 (2048)  1.39 (3072)  1.55 (4096)
 //     (round 2 always put 16 per workgroup: 1.53 - 1.59 whatever n <= 4096)
-// so: split up to 192, one workgroup per ciphertext up to 1600, the shared-table kernel above.
-constexpr long kKsAutoSplit = 192, kKsAutoWg = 1600;
+// so: split up to 192, one workgroup per ciphertext up to 1600, the shared-table kernel above -- on 256 CUs; in units of the
+// device's CU count: 3/4 and 25/4 ciphertexts per CU
+inline long ks_auto_split(int cus) { return 3L * std::max(1, cus) / 4; }
+inline long ks_auto_wg(int cus) { return 25L * std::max(1, cus) / 4; }
 long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16
@@ -473,29 +474,31 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     }
     if (!s.br_lds_opt_in) {      // > 64 KiB of dynamic LDS needs an opt-in, per device
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBrLdsBytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLlLdsBytes));
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ll2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLl2LdsBytes));
         s.br_lds_opt_in = true;
     }
-    // One round of the batch kernel's grid is 256 workgroups x 8 rotations and takes ~19 ms however few of its
-    // wave slots are used, so a launch of 2049 rotations used to cost two rounds.  Launches are cut into
+    // One round of the batch kernel's grid is a workgroup of 8 rotations per CU and takes ~19 ms however few of its
+    // wave slots are used, so a launch of a few rotations past a whole round used to cost two rounds.  Launches are cut into
     // whole rounds plus a tail, and the tail takes the cheapest of: the low-latency kernel (a CU per
-    // rotation, 3.5 ms per round of 256), the batch kernel with one rotation per SIMD (~11 ms per round of
-    // 1024), a full round.  All variants compute identical words.
-    constexpr size_t kRound = 256 * kBrWavesPerBlock;
+    // rotation, 3.3 ms per started round of one rotation per CU), its paired form (two per CU, 5.3 - 5.8 ms), the batch
+    // kernel with one rotation per SIMD (~12 ms per round of four per CU), a full round.  All variants compute identical
+    // words.  Every rule below is in units of the device's CU count (MI355X: 256; the measured milliseconds are that chip's).
+    const size_t cu = (size_t)std::max(1, s.cus);
+    const size_t kRound = cu * kBrWavesPerBlock;
     auto launch_batch = [&](const LinDesc* dd, size_t n, int active, uint32_t* dump) {
         const unsigned blocks = (unsigned)((n + active - 1) / active);
         hipLaunchKernelGGL(blind_rotate_kernel, dim3(blocks), dim3(kBrThreads), kBrLdsBytes, st, dd, (int)n,
                            s.bk_ntt, s.tables_r4, steps, dump, active);
     };
-    // Measured on MI355X (tools/latency_sweep.py, profiles/r02_latency_sweep.txt), ms per launch of n rotations:
-    //   low-latency kernel  3.1 (n <= 64), 3.6 / 6.7 / 10.0 / 13.3 / 16.6 per started round of 256 (key switch included)
-    //   its paired form     5.3 - 5.8 per started round of 512 (11.5 for 1024, 17.1 for 1536, 22.9 for 2048)
-    //   one rotation per SIMD 12.7 (n <= 1024)          two per SIMD 20.7 (n <= 2048)
-    // so: low-latency up to 256, rounds of 512 on the paired kernel (+ a last round of up to 256 on the single one) up
-    // to 1536, a full round of the batch kernel above.  ("ll2_threshold" 0 gives the rules without the paired kernel:
-    // low-latency up to 768, one-per-SIMD for 769..1024, both for 1025..1280.)
+    // Measured on MI355X, 256 CUs (tools/latency_sweep.py, tools/ll_times.py; profiles/r02_latency_sweep.txt, r05_ll_ab.txt), ms per
+    // launch of n rotations, key switch included:
+    //   low-latency kernel  2.9 (n <= 64), 3.3 / 6.7 / 10.0 / 13.3 / 16.6 per started round of one rotation per CU
+    //   its paired form     5.0 - 5.3 per started round of two per CU (10.4 for four, 17.1 for six, 22.9 for eight)
+    //   one rotation per SIMD 12.7 (n <= 4 per CU)          two per SIMD 20.7 (n <= 8 per CU)
+    // so: low-latency up to one rotation per CU, rounds of two per CU on the paired kernel (+ a last round of up to one per CU on
+    // the single one) up to six per CU, a full round of the batch kernel above.  ("ll2_threshold" 0 gives the rules without the
+    // paired kernel: low-latency up to three per CU, one-per-SIMD up to four, both up to five.)
     const bool auto_ll = g_ll_threshold < 0, auto_half = g_half_threshold < 0;
     auto launch_ll = [&](const LinDesc* dd, size_t n, uint32_t* dump) {
         // smallest batches: one 16-wave workgroup per rotation, transforms split in halves (kernels_ll.hip.h)
@@ -512,28 +515,24 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
             launch_ll2(dd, n, dump);
             return;
         }
-        if (g_ll2_threshold < 0 && auto_ll && auto_half && (long)g_wg_threshold == 0 && n > 256 && n <= 1536) {
-            // rounds of 512 on the paired kernel (5.7 ms each) and a last started round of up to 256 on the single one (3.3)
-            const size_t rem = n % 512, paired = (rem == 0 || rem > 256) ? n : n - rem;
+        if (g_ll2_threshold < 0 && auto_ll && auto_half && n > cu && n <= 6 * cu) {
+            // rounds of two rotations per CU on the paired kernel and a last started round of up to one per CU on the single one
+            const size_t rem = n % (2 * cu), paired = (rem == 0 || rem > cu) ? n : n - rem;
             launch_ll2(dd, paired, dump);
             if (paired < n) launch_ll(dd + paired, n - paired, dump ? dump + paired * 2 * kN : nullptr);
             return;
         }
-        if (auto_ll && auto_half && n > 1024 && n <= 1280) {
-            // (without the paired kernel) 1024 at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.2):
+        if (auto_ll && auto_half && n > 4 * cu && n <= 5 * cu) {
+            // (without the paired kernel) four per CU at one rotation per SIMD (12.0 ms) and the rest on the low-latency kernel (3.2):
             // 15.5 ms against 16.6 for five rounds of the low-latency kernel and 20 for a full round
-            launch_batch(dd, 1024, kBrWavesPerBlock / 2, dump);
-            launch_ll(dd + 1024, n - 1024, dump ? dump + (size_t)1024 * 2 * kN : nullptr);
+            launch_batch(dd, 4 * cu, kBrWavesPerBlock / 2, dump);
+            launch_ll(dd + 4 * cu, n - 4 * cu, dump ? dump + 4 * cu * 2 * kN : nullptr);
             return;
         }
-        const bool use_ll = auto_ll ? n <= 768 : (long)n <= g_ll_threshold;
-        const bool use_half = auto_half ? n <= 1024 : (long)n <= g_half_threshold;
+        const bool use_ll = auto_ll ? n <= 3 * cu : (long)n <= g_ll_threshold;
+        const bool use_half = auto_half ? n <= 4 * cu : (long)n <= g_half_threshold;
         if (use_ll) {
             launch_ll(dd, n, dump);
-        } else if ((long)n <= g_wg_threshold) {
-            // one 8-wave workgroup per rotation (kernels.hip.h); unused with the default thresholds
-            hipLaunchKernelGGL(blind_rotate_wg_kernel, dim3((unsigned)n), dim3(kWgThreads), kWgLdsBytes, st, dd, (int)n,
-                               s.bk_ntt, s.tables, steps, dump);
         } else if (use_half) {
             launch_batch(dd, n, kBrWavesPerBlock / 2, dump);
         } else {
@@ -541,7 +540,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
         }
     };
     const size_t tail = count % kRound;
-    const long tail_max = std::max(auto_half ? 1024L : g_half_threshold, std::max(auto_ll ? (g_ll2_threshold < 0 ? 1536L : 1280L) : g_ll_threshold, g_wg_threshold));
+    const long tail_max = std::max(auto_half ? (long)(4 * cu) : g_half_threshold, auto_ll ? (long)((g_ll2_threshold < 0 ? 6 : 5) * cu) : g_ll_threshold);
     if (g_tail_split && count > kRound && tail != 0 && (long)tail <= tail_max) {
         const size_t full = count - tail;
         launch_batch(d, full, kBrWavesPerBlock, acc_dump);
@@ -571,8 +570,8 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
         s.ks_lds_opt_in = true;
     }
-    const long split_max = g_ks_split_threshold < 0 ? kKsAutoSplit : g_ks_split_threshold;
-    const long wg_max = g_ks_wg_threshold < 0 ? kKsAutoWg : g_ks_wg_threshold;
+    const long split_max = g_ks_split_threshold < 0 ? ks_auto_split(s.cus) : g_ks_split_threshold;
+    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(s.cus) : g_ks_wg_threshold;
     if ((long)count <= split_max) {
         hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
         hipLaunchKernelGGL(keyswitch_split_kernel, dim3((unsigned)count * kKsSplit), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
@@ -1331,7 +1330,6 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "sched_affinity")) { g_sched_affinity = value != 0; return 0; }
     if (!strcmp(key, "sched_zero_copy")) { g_sched_zero_copy = value != 0; return 0; }
     if (!strcmp(key, "share_devices")) { g_share_devices = value; g_phys_count = cufhe_amd_device_count(); return 0; }
-    if (!strcmp(key, "wg_threshold")) { g_wg_threshold = value; return 0; }
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
     if (!strcmp(key, "half_threshold")) { g_half_threshold = value; return 0; }
     if (!strcmp(key, "tail_split")) { g_tail_split = value; return 0; }

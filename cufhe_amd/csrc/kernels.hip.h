@@ -8,7 +8,8 @@
 //                                                   include/keyswitch_gpu.cuh:83-188
 //   lincomb_kernel         __NotBootstrap__/__CopyBootstrap__ and the Mux/NMux sums
 //                                                   src/bootstrap_gpu.cu:681-703,728-740
-//   blind_rotate_wg_kernel / keyswitch_wg_kernel   the same two, one workgroup per ciphertext
+//   keyswitch_wg_kernel / keyswitch_split_kernel   the key switch with one / eight workgroups per ciphertext (small launches;
+//                                                  the low-latency blind rotations are in kernels_ll.hip.h)
 //                                                   (small launches: lowest latency)
 //   sample_extract_kernel, cmux_kernel             SEIandKS / Refresh / CMUXNTT pieces
 //                                                   src/keyswitch_gpu.cu:26-40, src/bootstrap_gpu.cu:197-285
@@ -372,139 +373,6 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
             const int e = lane + 64 * r;
             if (e == 0) { o[0] = acc0[r]; o[kN] = acc1[r]; }
             else o[kN - e] = 0u - acc0[r];
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------
-// Low-latency blind rotate: ONE WORKGROUP per rotation (small batches, ms/gate latency).
-//
-// The batch kernel above gives a rotation one wave, i.e. one SIMD's worth of FP64 issue:
-// 13 ms per gate however idle the chip is.  Here the 8 NTTs of a CMux step are spread over
-// the CU: waves 0-5 each take one TRGSW row (digit polynomial -> forward NTT -> products with
-// the row's two key polynomials, which the wave prefetches straight from L2 into registers
-// one step ahead), and add their products into two shared NTT-domain sums in LDS with
-// ds_add_f64 -- exact integer additions, so the result does not depend on arrival order.
-// After a barrier waves 0 and 1 run the two inverse NTTs and update the accumulator, which
-// lives in LDS (stored twice, e and e+N, so the rotated read needs no wrap-around).  Two
-// barriers per step; same arithmetic, same words as the batch kernel.
-// ----------------------------------------------------------------------------------
-constexpr int kWgThreads = 512;
-constexpr int kWgRowWaves = kBkRows;                                          // 6
-constexpr int kWgLdsTables = 0;
-constexpr int kWgLdsTiles = kWgLdsTables + kLdsTableBytes;                    // 16128
-constexpr int kWgLdsAcc = kWgLdsTiles + kWgRowWaves * kTileBytes;             // + 50688
-constexpr int kWgLdsSum = kWgLdsAcc + 2 * 2 * kN * 4;                         // + 16384
-constexpr int kWgLdsAbar = kWgLdsSum + 2 * kN * 8;                            // + 16384
-constexpr int kWgLdsBytes = kWgLdsAbar + kAbarBytes + 16;                     // 100880
-
-__global__ __launch_bounds__(kWgThreads, 2) void blind_rotate_wg_kernel(
-    const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const NttTables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int g = blockIdx.x;
-    if (g >= count) return;
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    load_tables_to_lds((double*)(smem + kWgLdsTables), gt);
-    uint32_t* accL = (uint32_t*)(smem + kWgLdsAcc);          // [j][copy][N]
-    double* sumL = (double*)(smem + kWgLdsSum);               // [out][reg][lane]
-    uint16_t* abar_lds = (uint16_t*)(smem + kWgLdsAbar);
-    uint32_t* bbar_slot = (uint32_t*)(smem + kWgLdsAbar + kAbarBytes);
-
-    const LinDesc d = descs[g];
-    for (int i = tid; i <= kLvl0N; i += kWgThreads) {
-        const uint32_t c = (uint32_t)d.ca * d.in0[i] + (uint32_t)d.cb * d.in1[i];
-        if (i < kLvl0N) abar_lds[i] = (uint16_t)((c + (1u << (32 - 2 - kNbit))) >> (32 - 1 - kNbit));
-        else *bbar_slot = 2 * kN - ((c + d.off) >> (32 - 1 - kNbit));
-    }
-    for (int i = tid; i < 2 * kN; i += kWgThreads) sumL[i] = 0.0;
-    __syncthreads();
-    {   // RotatedTestVector, include/gatebootstrapping_gpu.cuh:29-52
-        const uint32_t bbar = *bbar_slot;
-        for (int e = tid; e < kN; e += kWgThreads) {
-            const bool neg = (bbar != 2 * kN) && (((uint32_t)e < (bbar & (kN - 1))) != ((bbar >> kNbit) != 0));
-            const uint32_t v = neg ? 0u - kMu : kMu;
-            accL[e] = 0; accL[kN + e] = 0;
-            accL[2 * kN + e] = v; accL[3 * kN + e] = v;
-        }
-    }
-    __syncthreads();
-
-    const bool row_wave = wave < kWgRowWaves;
-    const int wj = wave / kL, wd = wave % kL;                 // this wave's TRGSW row = wj * l + wd
-    const WaveCtx ctx = make_wave_ctx(smem, kWgLdsTiles + (row_wave ? wave : 0) * kTileBytes, kWgLdsTables, gt, lane);
-    double2 b[16];
-    if (row_wave && steps > 0) {
-        const double2* row = (const double2*)(bk_ntt + ((size_t)0 * kBkRows + wave) * (2 * kN));
-#pragma unroll
-        for (int q = 0; q < 16; q++) b[q] = row[q * 64 + lane];
-    }
-
-#pragma unroll 1
-    for (int i = 0; i < steps; i++) {
-        const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
-        if (row_wave) {
-            const char* accj = (const char*)(accL + wj * 2 * kN);
-            const int alo = (int)(abar & (kN - 1));
-            const bool ahi = (abar >> kNbit) != 0;
-            const char* rbase = accj + opaque(4 * ((lane - alo) & (kN - 1)));
-            const char* cbase = accj + opaque(4 * lane);
-            uint32_t rot[kRegs], cur[kRegs];
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) { rot[r] = *(const uint32_t*)(rbase + 256 * r); cur[r] = *(const uint32_t*)(cbase + 256 * r); }
-            const uint32_t pos = 32 - (wd + 1) * kBgbit;
-            double x[kRegs];
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                const bool neg = (lane < alo - 64 * r) != ahi;
-                const uint32_t t = ((neg ? 0u - rot[r] : rot[r]) - cur[r] + decomp_offset()) ^ decomp_signmask();
-                x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, pos, (uint32_t)kBgbit);
-            }
-            ntt_forward<true>(x, ctx);
-            double* s0 = sumL + lane;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                __hip_atomic_fetch_add(s0 + (2 * q) * 64, fpf::mulmod_wide(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(s0 + (2 * q + 1) * 64, fpf::mulmod_wide(x[2 * q + 1], b[q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(s0 + kN + (2 * q) * 64, fpf::mulmod_wide(x[2 * q], b[q + 8].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(s0 + kN + (2 * q + 1) * 64, fpf::mulmod_wide(x[2 * q + 1], b[q + 8].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        __syncthreads();
-        if (row_wave && i + 1 < steps) {         // next step's row, in flight during the inverse NTTs
-            const double2* row = (const double2*)(bk_ntt + ((size_t)(i + 1) * kBkRows + wave) * (2 * kN));
-#pragma unroll
-            for (int q = 0; q < 16; q++) b[q] = row[q * 64 + lane];
-        }
-        if (wave < 2) {
-            double* s = sumL + wave * kN + lane;
-            double A[kRegs];
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) { A[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-            ntt_inverse(A, ctx);
-            char* acck = (char*)(accL + wave * 2 * kN) + opaque(4 * lane);
-#pragma unroll
-            for (int r = 0; r < kRegs; r++) {
-                const uint32_t v = *(const uint32_t*)(acck + 256 * r) + fpf::lift_u32(A[r]);
-                *(uint32_t*)(acck + 256 * r) = v;
-                *(uint32_t*)(acck + 256 * r + 4096) = v;
-            }
-        }
-        __syncthreads();
-    }
-
-    if (acc_dump) {
-        uint32_t* o = acc_dump + (size_t)g * 2 * kN;
-        for (int e = tid; e < kN; e += kWgThreads) { o[e] = accL[e]; o[kN + e] = accL[2 * kN + e]; }
-    }
-    if (d.out) {
-        uint32_t* o = d.out;      // __SampleExtractIndex__<P,0>
-        for (int e = tid; e < kN; e += kWgThreads) {
-            if (e == 0) { o[0] = accL[0]; o[kN] = accL[2 * kN]; }
-            else o[kN - e] = 0u - accL[e];
         }
     }
 }

@@ -71,7 +71,7 @@ constexpr int kBrLdsBk = 0;
 constexpr int kBrLdsTables = kBrLdsBk + kBkRowBuffers * kBkRowBytes;            // 49152
 constexpr int kBrLdsTiles = kBrLdsTables + kLdsTablePackedBytes;                // the packed r4 tables (ntt_wave.h)
 constexpr int kBrLdsAbar = kBrLdsTiles + kBrWavesPerBlock * kTileBytes;
-constexpr int kBrLdsBytes = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;         // 143104
+constexpr int kBrLdsBytes = kBrLdsAbar + kBrWavesPerBlock * kAbarBytes;         // 145920
 
 // gadget decomposition constants, include/gatebootstrapping_gpu.cuh:18-27,145-150
 __host__ __device__ constexpr uint32_t decomp_offset()

@@ -113,8 +113,9 @@ int launch_keyswitch_lvl2(DeviceState& s, hipStream_t st, const LinDesc64* d, si
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    // a workgroup per ciphertext costs 2.1 us per ciphertext (8.5 ms per 4096), the shared-table kernel 3.1 ms per launch
-    if ((long)count <= (g_ks_wg_threshold < 0 ? 1400 : g_ks_wg_threshold)) {
+    // a workgroup per ciphertext costs 2.1 us per ciphertext (8.5 ms per 4096 on 256 CUs), the shared-table kernel 3.1 ms per launch:
+    // the first up to 1400 = 5.5 ciphertexts per CU
+    if ((long)count <= (g_ks_wg_threshold < 0 ? 11L * std::max(1, s.cus) / 2 : g_ks_wg_threshold)) {
         // a workgroup per ciphertext, rows from L2: lowest latency for small and middle-sized launches
         hipLaunchKernelGGL(keyswitch_lvl2_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk2);
     } else {
@@ -233,11 +234,27 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
         HIP_TRY(hipSetDevice(phys_device(i)));
         if (s.keys2_ready) {
             HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(s.bk2_ntt));
-            HIP_TRY(hipFree(s.bk2q_ntt));
-            HIP_TRY(hipFree(s.ksk2));
             s.keys2_ready = false;
+            (void)hipFree(s.bk2_ntt);
+            (void)hipFree(s.bk2q_ntt);
+            (void)hipFree(s.ksk2);
+            s.bk2_ntt = s.bk2q_ntt = nullptr;
+            s.ksk2 = nullptr;
         }
+        // about 1 GB per device (the key in both kernel layouts): whatever was allocated goes again if a later step fails -- keys2_ready
+        // stays false then, and cleanup only frees what is marked ready
+        uint64_t* d_bk = nullptr;
+        struct Undo {
+            DeviceState& s; uint64_t*& d_bk; bool armed = true;
+            ~Undo()
+            {
+                (void)hipFree(d_bk);
+                if (!armed) return;
+                (void)hipFree(s.bk2_ntt); (void)hipFree(s.bk2q_ntt); (void)hipFree(s.ksk2);
+                s.bk2_ntt = s.bk2q_ntt = nullptr;
+                s.ksk2 = nullptr;
+            }
+        } undo{s, d_bk};
         HIP_TRY(hipMalloc((void**)&s.bk2_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
         HIP_TRY(hipMalloc((void**)&s.bk2q_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
         const size_t ksk_rows = want_ksk / kKsRowWords;
@@ -245,7 +262,6 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
         HIP_TRY(hipMemset(s.ksk2, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy2D(s.ksk2, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
                             kKsRowWords * sizeof(uint32_t), ksk_rows, hipMemcpyHostToDevice));
-        uint64_t* d_bk = nullptr;
         HIP_TRY(hipMalloc((void**)&d_bk, want_bk * sizeof(uint64_t)));
         HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint64_t), hipMemcpyHostToDevice));
         const size_t polys = want_bk / k2N;
@@ -259,7 +275,7 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
                            s.bk2q_ntt, d_bk, polys, s.tables2q, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(d_bk));
+        undo.armed = false;          // d_bk is freed by the guard
         s.keys2_ready = true;
     }
     return 0;

@@ -9,10 +9,10 @@
 namespace {
 
 long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-per-rotation kernel is used (-1: by cost)
-// By cost (tools/ps_latency.py, tools/ps_times.py; blind rotation + key switch): the workgroup-per-rotation kernel takes
-// 5.0 / 3.5 / 4.0 ms per started round of 256 (default / k2n512 / cggi16), a round of the wave-per-rotation kernel (up to
-// 2048 rotations) 21 / 18.5 / 26 ms: the second wins from the fifth / sixth / seventh started round on.
-template <class PS> constexpr long kPsAutoBatch = PS::limbs > 1 ? 1537 : PS::Nbit == 9 ? 1281 : 1025;
+// By cost (tools/ps_latency.py, tools/ps_times.py; blind rotation + key switch, MI355X): the workgroup-per-rotation kernel takes
+// 5.0 / 3.5 / 4.0 ms per started round of one rotation per CU (default / k2n512 / cggi16), a round of the wave-per-rotation kernel
+// (up to eight per CU) 21 / 18.5 / 26 ms: the second wins from the fifth / sixth / seventh started round on.
+template <class PS> long ps_auto_batch(int cus) { return (PS::limbs > 1 ? 6L : PS::Nbit == 9 ? 5L : 4L) * std::max(1, cus) + 1; }
 
 struct PsState {
     bool ready = false, lds_opt_in = false, ks_lds_opt_in = false;
@@ -32,7 +32,7 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
     if (count == 0) return 0;
     EventPair ev{};
     if (int rc = prof_begin(s, st, ev)) return rc;
-    const long wg_max = g_ks_wg_threshold < 0 ? kKsAutoWg : g_ks_wg_threshold;
+    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(s.cus) : g_ks_wg_threshold;
     if ((long)count > wg_max && ps.ksk_padded) {
         // 16 ciphertexts per workgroup, table rows through LDS
         const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
@@ -99,7 +99,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_batch_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsbLds<PS>::bytes));
         ps.lds_opt_in = true;
     }
-    if ((long)count >= (g_ps_batch_threshold < 0 ? kPsAutoBatch<PS> : g_ps_batch_threshold)) {
+    if ((long)count >= (g_ps_batch_threshold < 0 ? ps_auto_batch<PS>(s.cus) : g_ps_batch_threshold)) {
         // one wave per rotation, 8 rotations per workgroup share the key rows (throughput shape)
         const unsigned blocks = (unsigned)((count + PsbLds<PS>::waves - 1) / PsbLds<PS>::waves);
         hipLaunchKernelGGL(blind_rotate_ps_batch_kernel<PS>, dim3(blocks), dim3(PsbLds<PS>::threads), PsbLds<PS>::bytes, st, d, (int)count,

@@ -75,7 +75,10 @@ class HipBackend : public sched::Backend {
     }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
     int free_device(void* p) override { return chk(hipFree(p), "hipFree"); }
-    int alloc_pinned(size_t bytes, void** p) override { return chk(hipHostMalloc(p, bytes, hipHostMallocDefault), "hipHostMalloc"); }
+    // The gather kernel writes results straight into this memory and the host reads them once the group's event has completed: that
+    // needs host-coherent (fine-grained) pinned memory mapped into the device, asked for explicitly rather than left to what
+    // hipHostMallocDefault happens to mean
+    int alloc_pinned(size_t bytes, void** p) override { return chk(hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc"); }
     int free_pinned(void* p) override { return chk(hipHostFree(p), "hipHostFree"); }
     int h2d(int s, void* dst, const void* src, size_t bytes) override
     {

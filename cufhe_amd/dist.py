@@ -169,27 +169,44 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
     t0 = time.monotonic()
     rc = 0
     pending = set(range(world))
-    while pending:
-        for r in list(pending):
-            code = procs[r].poll()
-            if code is not None:
-                pending.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 128 - code
-        if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
-            if rc == 0:
-                rc = 124
-            end_all(sorted(pending))
-            pending = set()
-        if pending:
-            time.sleep(poll)
-    # every rank has exited; anything a rank left behind in its process group could still hold rank 0's pipe open
+    # The ranks lead their own sessions, so a Ctrl-C or a SIGTERM aimed at the launcher (a harness timeout) does not reach them by
+    # itself: SIGTERM is turned into an exception for the duration of the wait, and ANY exception ends the ranks before it goes on.
     import signal
-    for pr in procs:
-        try:
-            os.killpg(pr.pid, signal.SIGKILL)
-        except (ProcessLookupError, PermissionError):
-            pass
+
+    class _Terminated(BaseException):
+        pass
+
+    def _on_term(signum, frame):
+        raise _Terminated()
+    old_term = None
+    try:
+        old_term = signal.signal(signal.SIGTERM, _on_term)
+    except ValueError:          # not the main thread: signals go to the main thread, nothing to install
+        old_term = None
+    try:
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 128 - code
+            if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
+                if rc == 0:
+                    rc = 124
+                end_all(sorted(pending))        # kills each group BEFORE reaping its leader: the pgid cannot have been reused
+                pending = set()
+            if pending:
+                time.sleep(poll)
+    except BaseException:
+        end_all(sorted(pending))
+        raise
+    finally:
+        if old_term is not None:
+            signal.signal(signal.SIGTERM, old_term)
+    # Every rank has been reaped (poll / wait above), so its pid -- and with it the pgid -- may already belong to somebody else: no
+    # signal is sent by number any more.  A grandchild a rank left behind cannot hold the job up either: the reader below gives up
+    # after 10 s and returns what rank 0 wrote.
     reader.join(10)
     out = chunks[0].decode(errors="replace") if chunks else ""
     return rc, out

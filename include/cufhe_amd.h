@@ -224,16 +224,17 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
 /* ---- tuning ----
  * "device_base": physical HIP device that logical device 0 maps to (default 0).  A process
  * that drives one GPU of a node (one rank per GPU) sets it to its local rank before Initialize.
- * Launch shape of the blind rotation (all variants produce identical words).  A launch is cut into whole
+ * Launch shape of the blind rotation (all variants produce identical words; the rules are in units of the device's CU count,
+ * the numbers below are MI355X's 256 CUs).  A launch is cut into whole
  * rounds of the batch kernel's grid (2048 rotations: two per SIMD, highest throughput) plus a tail, and the
- * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: up to 256 rotations the 16-wave
- * workgroup-per-rotation kernel with split transforms (lowest latency: 3.1 ms for up to 64, 3.7 for 256); up to
- * 1536 rounds of 512 on its two-rotations-per-workgroup form (5.8 ms each) plus a last round of up to 256 on the
+ * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: up to 256 rotations (one per CU) the 16-wave
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 2.9 ms for up to 64, 3.3 for 256); up to
+ * 1536 rounds of 512 on its two-rotations-per-workgroup form (5.3 ms each) plus a last round of up to 256 on the
  * single form; above that a full round (20.7 ms).  "ll2_threshold" (default -1 = by cost; 0 = never; n = for every
  * launch up to n) governs the paired form; "ll_threshold" / "half_threshold" (default -1 = by cost) force the single
- * form / the batch kernel with one rotation per SIMD up to the given count, "wg_threshold" (default 0) the older
- * 8-wave workgroup-per-rotation kernel, "tail_split" 0 launches everything above 2048 as one grid.
- * "ks_wg_threshold" / "ks_split_threshold" (default -1 = by measured cost: 1600 / 192): the same choice
+ * form / the batch kernel with one rotation per SIMD up to the given count, "tail_split" 0 launches everything above
+ * one round as one grid.
+ * "ks_wg_threshold" / "ks_split_threshold" (default -1 = by measured cost: 1600 / 192 on 256 CUs): the same choice
  * for the key switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (0.05 ms
  * up to 32, 0.19 ms at 192), up to ks_wg_threshold one workgroup per ciphertext (0.22 ms up to 256,
  * 0.8 ms at 1024), above that the ciphertexts of a workgroup share each step of the key in LDS:

@@ -15,22 +15,20 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["batch", "half", "wg", "ll", "ll2"])
+@pytest.fixture(params=["batch", "half", "ll", "ll2"])
 def br_kernel(request, engine):
     """Run a test once per blind-rotate kernel: wave-per-rotation (batch: two rotations per SIMD; half: one
-    per SIMD, the tail shape), workgroup-per-rotation (wg), the 16-wave split-transform kernel (ll, lowest latency) and
+    per SIMD, the tail shape), the 16-wave split-transform kernel (ll, lowest latency: a workgroup per rotation) and
     its two-rotations-per-workgroup form (ll2).  All must give the oracle's words."""
     which = request.param
     engine.api.set_option("ll2_threshold", 1 << 30 if which == "ll2" else 0)
     engine.api.set_option("ll_threshold", 1 << 30 if which == "ll" else 0)
-    engine.api.set_option("wg_threshold", 1 << 30 if which in ("wg", "ll") else 0)
     engine.api.set_option("half_threshold", 1 << 30 if which == "half" else 0)   # "batch": two rotations per SIMD whatever the count
     engine.api.set_option("ks_wg_threshold", 0 if which in ("batch", "half") else 1 << 30)
     engine.api.set_option("ks_split_threshold", 1 << 30 if which == "ll" else 0)   # ll: 8 workgroups per key switch
     yield which
     engine.api.set_option("ll2_threshold", -1)
     engine.api.set_option("ll_threshold", -1)
-    engine.api.set_option("wg_threshold", 0)
     engine.api.set_option("ks_wg_threshold", -1)
     engine.api.set_option("ks_split_threshold", -1)
     engine.api.set_option("half_threshold", -1)
@@ -278,6 +276,17 @@ def test_scheduler_hazards_and_g_gates(engine, keys, oracle):
     st.Destroy()
 
 
+def _variant_env(**extra):
+    """The variants of the C++ program (more logical GPUs, renaming off) repeat what test_cpp_gate_api_mirror ran in full; by default they
+    skip its three at-size parts (4096 bootstraps + Refresh, 32768 mixed gates, the N = 2048 ring), which do not depend on the variant:
+    the suite stays well inside the driver's time limit on a slow box.  CUFHE_AMD_FULL_GPU_SUITE=1 runs everything everywhere."""
+    import os
+    env = dict(os.environ, **extra)
+    if not os.environ.get("CUFHE_AMD_FULL_GPU_SUITE"):
+        env["CUFHE_AMD_TEST_SKIP_AT_SIZE"] = "1"
+    return env
+
+
 def test_cpp_gate_api_mirror(engine):
     """tests/cpp/test_gate_api.cpp: the reference's own test programs (test_gate_gpu.cc,
     test_gate_gpu_multi.cc, test_intensive.cc, test_api_gpu.cu) against include/cufhe_amd.hpp,
@@ -326,6 +335,32 @@ def test_cpp_gate_api_tfhepp_branch(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
+@pytest.mark.parametrize("name", ["cggi16", "k2n512"])
+def test_cpp_gate_api_on_a_parameter_set(engine, name):
+    """The reference's own test programs (tests/cpp/test_gate_api.cpp: test_gate_gpu.cc on lvl1 ciphertexts, test_gate_gpu_multi.cc on
+    lvl0, test_api_gpu.cu's chains, test_intensive.cc, the ripple-carry adders) compiled the way a user picks a set in the reference --
+    at build time (CMakeLists.txt:8-24; here -DCUFHE_AMD_PARAM_SET_<SET> for include/cufhe_amd.hpp and -DORC_SET_<SET> for the oracle's
+    key generation and decryption) -- through the cufhe:: API: every gate of both orders decrypts to its truth table."""
+    import os
+    import subprocess
+    root = ol.ROOT
+    exe = os.path.join(root, "tests", "cpp", "test_gate_api_" + name)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DCUFHE_AMD_PARAM_SET_" + name.upper(), "-DORC_SET_" + name.upper(), "-o", exe,
+                           os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
+                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle_" + name,
+                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    engine.CleanUp()
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+        print(out.stdout[-3000:])
+        assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    finally:
+        import oracle_lib
+        k = oracle_lib.Keys(oracle_lib.load(), seed=1)
+        engine.SetGPUNum(1)
+        engine.Initialize(k.bk, k.ksk)
+
+
 def test_cpp_gate_api_three_logical_gpus(engine):
     """The same program with SetGPUNum(3) (test/test_gate_gpu_multi.cc:36-93: default-constructed streams
     round-robin the devices, include/cufhe_gpu.cuh:154-159): per-device key replicas, schedulers, launch threads
@@ -336,7 +371,7 @@ def test_cpp_gate_api_three_logical_gpus(engine):
     assert os.path.exists(exe), "built by test_cpp_gate_api_mirror"
     engine.CleanUp()
     try:
-        out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=900, env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1"))
+        out = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=900, env=_variant_env(CUFHE_AMD_SHARE_DEVICES="1"))
         print(out.stdout[-3000:])
         assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     finally:
@@ -358,7 +393,7 @@ def test_cpp_gate_api_without_output_renaming(engine):
     engine.CleanUp()
     try:
         out = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=900,
-                             env=dict(os.environ, CUFHE_AMD_SHARE_DEVICES="1", CUFHE_AMD_NO_SCHED_RENAME="1"))
+                             env=_variant_env(CUFHE_AMD_SHARE_DEVICES="1", CUFHE_AMD_NO_SCHED_RENAME="1"))
         print(out.stdout[-3000:])
         assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     finally:
@@ -508,14 +543,14 @@ def test_ragged_batch_sizes(engine, keys, count):
     for thr in (0, 1 << 30):            # batch kernels, then low-latency kernels
         if thr and count > 300:
             continue                     # one workgroup per rotation: keep the test short
-        engine.api.set_option("wg_threshold", thr)
+        engine.api.set_option("ll_threshold", thr if thr else -1)
         engine.api.set_option("ks_wg_threshold", thr)
         try:
             dout.upload(np.zeros(count * (ol.n + 1), np.uint32))
             engine.gate_batch(ol.OPS.index("XOR"), 0, dout, dins[0], dins[1], count=count)
             got = dout.download().reshape(count, -1)
         finally:
-            engine.api.set_option("wg_threshold", 0)
+            engine.api.set_option("ll_threshold", -1)
             engine.api.set_option("ks_wg_threshold", -1)
         assert np.array_equal(keys.decrypt(got, 0), bits[0] ^ bits[1])
         idx = np.unique(np.array([0, count // 2, count - 1]))
@@ -523,7 +558,7 @@ def test_ragged_batch_sizes(engine, keys, count):
         assert np.array_equal(got[idx], want)
 
 
-@pytest.mark.parametrize("count,opts", [(700, dict(ll_threshold=0, wg_threshold=0)),        # one rotation per SIMD (4 of 8 waves)
+@pytest.mark.parametrize("count,opts", [(700, dict(ll_threshold=0, ll2_threshold=0)),        # one rotation per SIMD (4 of 8 waves)
                                         (1100, dict(ll2_threshold=0)), (3200, dict(ll2_threshold=0)),   # (rounds +) 1024 at one per SIMD + low-latency kernel
                                         (300, {}), (600, {}), (1300, {}), (1536, {}), (3500, {}),       # paired low-latency kernel: all / 512 + single kernel / tail
                                         (2049, {}), (2700, {}), (4600, {})])                  # full rounds + a tail
@@ -543,7 +578,6 @@ def test_launch_shapes_with_tails(engine, keys, count, opts):
         got = dout.download().reshape(count, -1)
     finally:
         engine.api.set_option("ll_threshold", -1)
-        engine.api.set_option("wg_threshold", 0)
         engine.api.set_option("ll2_threshold", -1)
     assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
     cut = count - count % 2048

@@ -78,7 +78,7 @@ def test_staging_paths_and_flush_timeline(engine, keys, zero_copy):
     api = engine.api
     api.set_option("sched_zero_copy", zero_copy)
     try:
-        count = 1300                   # three chunks of 512 inputs in the first level, a ragged last one
+        count = 1100                   # three chunks of 512 inputs in the first level, a ragged last one
         rng = np.random.default_rng(901 + zero_copy)
         bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
         (a, ea), (b, eb) = (_ctxts(api, keys, bits[i], 0, 9100 + i) for i in range(2))

@@ -32,22 +32,22 @@ def t(count, reps=5):
     return sorted(ts)[len(ts) // 2]
 
 
-def opts(ll, wg, half, split):
+def opts(ll, ll2, half, split):
     eng.api.set_option("ll_threshold", ll)
-    eng.api.set_option("wg_threshold", wg)
+    eng.api.set_option("ll2_threshold", ll2)
     eng.api.set_option("half_threshold", half)
     eng.api.set_option("tail_split", split)
 
 
 BIG = 1 << 30
 small = (1, 16, 64, 256, 384, 512, 640, 768, 1024, 1280, 1536, 2048)
-for name, o in dict(ll=(BIG, BIG, 0, 0), wg=(0, BIG, 0, 0), half=(0, 0, BIG, 0), batch=(0, 0, 0, 0)).items():
+for name, o in dict(ll=(BIG, 0, 0, 0), ll2=(0, BIG, 0, 0), half=(0, 0, BIG, 0), batch=(0, 0, 0, 0)).items():
     opts(*o)
     print(name, " ".join(f"{c}:{t(c):.2f}" for c in small), flush=True)
 big = (2049, 2112, 2304, 2560, 2816, 3072, 3500, 4096, 4097, 4352, 5000, 6144, 8192)
-opts(1280, 1024, 0, 0)
-print("round-1 launch shapes  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
-opts(-1, 0, -1, 1)
+opts(1280, 0, 0, 0)
+print("without tail split     ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
+opts(-1, -1, -1, 1)
 print("tail split (defaults)  ", " ".join(f"{c}:{t(c, 3):.2f}" for c in big), flush=True)
 print("gates/s (defaults)     ", " ".join(f"{c}:{c / t(c, 3) * 1e3:.0f}" for c in big), flush=True)
 eng.CleanUp()
