@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         for (int k = 0; k < kKsT; k++) {
             // field f = val + 2: 0 -> +row(v=2), 1 -> +row(v=1), 2 -> nothing, 3 -> -row(v=1)
             // (requesting the rows of several digits before adding any -- fewer dependent LDS round trips per step -- was
-            // measured in round 5: 1.33 ms per 4096 either way, the step is not bound by them)
+            // measured: 1.33 ms per 4096 either way, the step is not bound by them; profiles/r04_radix4_and_latency.md)
             const uint32_t f = (dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1);
             if (f != 2) {
                 const int roff = (k * kKsNumBase + (f == 0 ? 1 : 0)) * (kKsRowPad * 4);

@@ -1,7 +1,7 @@
 // ntt_r4.h -- radix-4 butterflies over the FP64 prime field and their lazy-reduction bounds at compile time.
 //
 // The reference's transform is radix-2: N/2 log N general modular products (include/ntt_gpu/ntt_gpuntt.cuh:170-224,
-// CooleyTukeyUnit / GentlemanSandeUnit), and so were rounds 1-4 here (ntt_wave.h: ct_bfly / gs_bfly, 8 FP64 operations per
+// CooleyTukeyUnit / GentlemanSandeUnit), and so are the transforms of ntt_wave.h / ntt_wave512.h (ct_bfly / gs_bfly, 8 FP64 operations per
 // butterfly).  Two consecutive merged-psi stages on four elements use the twiddles w | u, I u (root[2m + 1] = root[2m] psi^(N/2)
 // and psi^(N/2) = I, the fourth root of unity), so they can be written with THREE general products and one product by I:
 //

@@ -1,5 +1,5 @@
 // Microbenchmark: which exact modular-arithmetic butterfly is cheapest on gfx950?
-// Decides the NTT field for the BlindRotate hot path (see DESIGN.md "Field choice").
+// Decides the NTT field for the BlindRotate hot path.
 // Each variant runs NB independent butterfly chains per lane for ITERS iterations;
 // we report butterflies/s over the whole chip and the implied cycles per wave-butterfly.
 #include <hip/hip_runtime.h>
