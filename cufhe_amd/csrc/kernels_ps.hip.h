@@ -514,7 +514,11 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
         // contribute is a multiple of 2^limb_bits -- with limb_bits >= 16 only its top 16 bits have to be carried through the last
         // limb's row walk, two coefficients (r, r + R/2) to a register: R/2 registers per component where there were R (the full words
         // were what spilled: 19 registers of scratch on the 80-bit set).  The last limb (shift 0) goes straight into the accumulator.
+#ifdef CUFHE_AMD_PS_NO_PACK      // experiment (tools/build_variant.py): the full words carried, as until round 5
+        constexpr bool kPackDelta = false;
+#else
         constexpr bool kPackDelta = PS::limbs > 1 && PS::limb_bits >= 16;
+#endif
         constexpr int kDeltaRegs = PS::limbs == 1 ? 1 : kPackDelta ? R / 2 : R;
         uint32_t delta[K1][kDeltaRegs];      // only live for sets with key limbs
         if (PS::limbs > 1) {
@@ -576,22 +580,27 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
 #pragma unroll
                 for (int r = 0; r < R; r++) A[o][r] = fpf::reduce(A[o][r]);
                 PO::inverse(A[o], ctx);
+                uint32_t v[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) v[r] = fpf::lift_u32(A[o][r]);       // the limb's exact sum mod 2^32
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const uint32_t v = fpf::lift_u32(A[o][r]);     // the limb's exact sum mod 2^32
                     if (PS::limbs == 1) {
-                        acc[o][r] += v;
+                        acc[o][r] += v[r];
                     } else if (limb > 0) {                         // v << shl is a multiple of 2^limb_bits
-                        if (kPackDelta) {
-                            const uint32_t top = (v << shl) >> 16;                 // bits 16..31 of the contribution
+                        if (kPackDelta && PS::limbs == 2) {
+                            // the only limb before the last: bits 16..31 of (v << 16) are v's low half -- one and, one shift-or per pair
+                            if (r < R / 2) delta[o][r] = (v[r] & 0xFFFFu) | (v[r + R / 2] << 16);
+                        } else if (kPackDelta) {
+                            const uint32_t top = (v[r] << shl) >> 16;              // bits 16..31 of the contribution
                             if (r < R / 2) delta[o][r] = (delta[o][r] & 0xFFFF0000u) | ((delta[o][r] + top) & 0xFFFFu);
                             else delta[o][r - R / 2] += top << 16;
                         } else {
-                            delta[o][r] += v << shl;
+                            delta[o][r] += v[r] << shl;
                         }
                     } else {                                       // the last limb: everything into the accumulator
                         const uint32_t carried = !kPackDelta ? delta[o][r] : r < R / 2 ? delta[o][r] << 16 : delta[o][r - R / 2] & 0xFFFF0000u;
-                        acc[o][r] += v + carried;
+                        acc[o][r] += v[r] + carried;
                     }
                 }
             }
