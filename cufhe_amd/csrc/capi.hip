@@ -78,6 +78,7 @@ struct DeviceState {
     NttTables* tables2 = nullptr;      // [2]: the two half transforms
     double* bk2_ntt = nullptr;
     Ntt512Tables* tables2q = nullptr;  // [4]: the four quarter transforms (kernels_lvl2q.hip.h)
+    struct QuarterR4Tables* tables2q4 = nullptr;   // [4]: their radix-4 twiddle products per lam / per lane
     double* bk2q_ntt = nullptr;        // the same key in the quarter layout
     bool br2q_lds_opt_in = false;
     uint32_t* ksk2 = nullptr;
@@ -934,6 +935,8 @@ int cufhe_amd_cleanup(void)
         if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.bk2q_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
         if (s.tables2q) HIP_TRY(hipFree(s.tables2q));
+        if (s.tables2q4) HIP_TRY(hipFree(s.tables2q4));
+        s.tables2q4 = nullptr;
         s.keys2_ready = s.br2_lds_opt_in = s.br2q_lds_opt_in = s.ks2_lds_opt_in = false;
         s.tables2 = nullptr; s.tables2q = nullptr; s.bk2_ntt = nullptr; s.bk2q_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables_r4)); HIP_TRY(hipFree(s.tables512)); }
