@@ -78,7 +78,6 @@ struct DeviceState {
     NttTables* tables2 = nullptr;      // [2]: the two half transforms
     double* bk2_ntt = nullptr;
     Ntt512Tables* tables2q = nullptr;  // [4]: the four quarter transforms (kernels_lvl2q.hip.h)
-    struct QuarterR4Tables* tables2q4 = nullptr;   // [4]: their radix-4 twiddle products per lam / per lane
     double* bk2q_ntt = nullptr;        // the same key in the quarter layout
     bool br2q_lds_opt_in = false;
     uint32_t* ksk2 = nullptr;
@@ -230,6 +229,37 @@ void build_tables(NttTables& t, bool r4 = false)
     fill_tables(t, fwd, inv, r4);
 }
 
+// exact product mod p of two balanced residues held in doubles, balanced again
+double prod_balanced(double a, double b)
+{
+    const __int128 p = (__int128)fpf::P_U64;
+    __int128 v = ((__int128)(int64_t)a * (__int128)(int64_t)b) % p;
+    if (v < 0) v += p;
+    return balanced((uint64_t)v);
+}
+
+// Radix-4 form of a 512-point transform (ntt_wave512.h: q4): the product of a block's stage-a and first stage-b twiddle, u w
+// (forward) and v w (inverse) -- in the spare slot 7 of tu_fwd / tu_inv for the wave-uniform block, in uwb_* / uwc_* per lam and per
+// lane.  The second stage-b twiddle must be I times (forward) / -I times (inverse) the first: false if it is not.
+bool fill_r4_products_512(Ntt512Tables& t)
+{
+    auto apart = [&](double w1, double w2, bool inverse) { return prod_balanced(w1, inverse ? -fpf::ROOT4 : fpf::ROOT4) == w2; };
+    if (!apart(t.tu_fwd[1], t.tu_fwd[2], false) || !apart(t.tu_inv[1], t.tu_inv[2], true)) return false;
+    t.tu_fwd[7] = prod_balanced(t.tu_fwd[0], t.tu_fwd[1]);
+    t.tu_inv[7] = prod_balanced(t.tu_inv[0], t.tu_inv[1]);
+    for (int lam = 0; lam < 8; lam++) {
+        if (!apart(t.tb_fwd[8 + lam], t.tb_fwd[16 + lam], false) || !apart(t.tb_inv[8 + lam], t.tb_inv[16 + lam], true)) return false;
+        t.uwb_fwd[lam] = prod_balanced(t.tb_fwd[lam], t.tb_fwd[8 + lam]);
+        t.uwb_inv[lam] = prod_balanced(t.tb_inv[lam], t.tb_inv[8 + lam]);
+    }
+    for (int lane = 0; lane < 64; lane++) {
+        if (!apart(t.tc_fwd[64 + lane], t.tc_fwd[128 + lane], false) || !apart(t.tc_inv[64 + lane], t.tc_inv[128 + lane], true)) return false;
+        t.uwc_fwd[lane] = prod_balanced(t.tc_fwd[lane], t.tc_fwd[64 + lane]);
+        t.uwc_inv[lane] = prod_balanced(t.tc_inv[lane], t.tc_inv[64 + lane]);
+    }
+    return true;
+}
+
 // Tables of one 512-point transform from accessors rf(idx) / ri(idx) = forward / inverse twiddle of
 // group g at the stage with m groups, idx = m + g.
 template <class RF, class RI>
@@ -341,6 +371,8 @@ int ensure_ntt(int device)
     CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables_r4, &host, sizeof(NttTables), hipMemcpyHostToDevice));
     static Ntt512Tables host512[3];
     build_tables_512(host512);
+    for (int h = 0; h < 2; h++)
+        if (!fill_r4_products_512(host512[h])) return fail(-2, "half-transform tables: the stage-b twiddles of a block are not I apart (radix-4 form)");
     CUFHE_AMD_TRY_UNDO(hipMalloc((void**)&s.tables512, sizeof(host512)));
     CUFHE_AMD_TRY_UNDO(hipMemcpy(s.tables512, host512, sizeof(host512), hipMemcpyHostToDevice));
 #undef CUFHE_AMD_TRY_UNDO
@@ -935,8 +967,6 @@ int cufhe_amd_cleanup(void)
         if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.bk2q_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
         if (s.tables2q) HIP_TRY(hipFree(s.tables2q));
-        if (s.tables2q4) HIP_TRY(hipFree(s.tables2q4));
-        s.tables2q4 = nullptr;
         s.keys2_ready = s.br2_lds_opt_in = s.br2q_lds_opt_in = s.ks2_lds_opt_in = false;
         s.tables2 = nullptr; s.tables2q = nullptr; s.bk2_ntt = nullptr; s.bk2q_ntt = nullptr; s.ksk2 = nullptr;
         if (s.ntt_ready) { HIP_TRY(hipFree(s.tables)); HIP_TRY(hipFree(s.tables_r4)); HIP_TRY(hipFree(s.tables512)); }

@@ -139,6 +139,11 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         twb[k] = lds_ld(row_wave ? ctx.tb_fwd : ctx.tb_inv, 64 * k);
         twc[k] = lds_ld(row_wave ? ctx.tc_fwd : ctx.tc_inv, 512 * k);
     }
+    if (!row_wave) {      // the inverse transform runs in radix-4 form: slot 2 of each block holds the product v w (no register more)
+        tu[2] = gt2[h].tu_inv[7];
+        twb[2] = gt2[h].uwb_inv[lane & 7];
+        twc[2] = gt2[h].uwc_inv[lane];
+    }
     // The coefficient-wise tail of a step is spread over all 16 waves: wave k owns the slices (out, hh, rr) =
     // (m, k >> 3, k & 7), m = 0, 1, i.e. coefficients lane + 64 rr + 512 hh of accumulator component m.
     const int hh = wave >> 3, rr = wave & 7;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
             double* s = sumL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) { u[r] = fpf::reduce(s[r * 64]); s[r * 64] = 0.0; }
-            ntt512_inverse_pinned(u, ctx, tu, twb, twc);      // u_h[e], e = lane + 64 r, |u| <= p
+            ntt512_inverse_r4_pinned(u, ctx, tu, twb, twc);      // u_h[e], e = lane + 64 r, |u| <= p
             double* hd = handL + out * kN + h * kH + lane;
 #pragma unroll
             for (int r = 0; r < kRegs8; r++) hd[r * 64] = u[r];
@@ -366,6 +371,11 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         twb[k] = lds_ld(row_wave ? ctx.tb_fwd : ctx.tb_inv, 64 * k);
         twc[k] = lds_ld(row_wave ? ctx.tc_fwd : ctx.tc_inv, 512 * k);
     }
+    if (!row_wave) {      // the inverse transform runs in radix-4 form: slot 2 of each block holds the product v w (no register more)
+        tu[2] = gt2[h].tu_inv[7];
+        twb[2] = gt2[h].uwb_inv[lane & 7];
+        twc[2] = gt2[h].uwc_inv[lane];
+    }
     const int hh = wave >> 3, rr = wave & 7;
     const int ecoef = lane + 64 * rr + kH * hh;
 
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         double u[kRegs8];
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) u[k] = fpf::reduce(s[k * 64]);
-        ntt512_inverse_pinned(u, ctx, tu, twb, twc);
+        ntt512_inverse_r4_pinned(u, ctx, tu, twb, twc);
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) s[k * 64] = u[k];
         inv_sync();

@@ -36,7 +36,6 @@
 // Ten barriers of four waves per step; the partner workgroup on the CU runs through them.
 #pragma once
 #include "kernels_lvl2.hip.h"
-#include "ntt_r4.h"
 #include "ntt_wave512.h"
 
 namespace cufhe_amd {
@@ -90,7 +89,8 @@ constexpr int kQTabDoubles = 2 * 7 * 8 + 7 * 64;                      // 560
 constexpr int kQTabBytes = kQTabDoubles * 8;                          // 4480
 constexpr int kQLdsAbar = kQLdsTab + kQWaves * kQTabBytes;
 constexpr int kQLdsR4 = kQLdsAbar + kAbarBytes + 16;                  // per quarter [uwb_fwd 8 | uwb_inv 8 | uwc_fwd 64 | uwc_inv 64] doubles
-constexpr int kQLdsBytes = kQLdsR4 + kQWaves * 144 * 8;               // 74768
+constexpr int kQR4Doubles = 144;                                      // Ntt512Tables: uwb_fwd 8 | uwb_inv 8 | uwc_fwd 64 | uwc_inv 64
+constexpr int kQLdsBytes = kQLdsR4 + kQWaves * kQR4Doubles * 8;       // 74768
 static_assert(2 * kQLdsBytes <= 160 * 1024, "two rotations per CU");
 static_assert(8 * k2BkRows * kQPoints == kQLdsRBytes && 2 * kQWaves * kQPoints * 8 == kQLdsRBytes, "digit buffer and exchange halves fit the accumulator copy's region");
 
@@ -114,135 +114,8 @@ __device__ __forceinline__ void ct_three_stages_w2(double (&x)[kRegs8], const do
     }
 }
 
-// ---- radix-4 form of the quarter transforms (round 5) --------------------------------------------------------------------------
-// A three-stage block on the eight registers of a lane (strides 4, 2, 1; twiddles tw0 | tw1, tw2 = I tw1 | tw3..6) is one radix-4
-// pass over stages (a, b) -- groups {r, r + 2, r + 4, r + 6}, r = 0, 1: x0 = x[r], coarse partner x[r + 4] (twiddle w = tw0), fine
-// partner x[r + 2] (u = tw1), the product u w from a table of its own (QuarterR4Tables; the uniform one in the spare slot 7 of
-// tu_fwd / tu_inv) -- followed (forward) or preceded (inverse) by the radix-2 stage c: 30 + 30 + 32 operations where three radix-2
-// stages take 96 (ntt_r4.h: ct_bfly4 / gs_bfly4, the product by I in four operations).  The bound of every register is carried
-// through the passes at compile time as in ntt_r4.h (maximum over lanes, units of p; a layout change makes all eight equal to the
-// largest): each product picks mulmod or mulmod_wide from the bound of its input and a reduction is spent on a register only when
-// its bound asks for one -- 10 registers per inverse transform where the radix-2 schedule swept all eight twice.
+// ---- the radix-4 schedules of the quarter transforms (machinery: ntt_wave512.h, q4) ----
 namespace q4 {
-struct B8 { double v[8]; };
-constexpr B8 uniform8(double b) { return B8{{b, b, b, b, b, b, b, b}}; }
-constexpr double max8(const B8& b)
-{
-    double m = 0;
-    for (int i = 0; i < 8; i++) m = b.v[i] > m ? b.v[i] : m;
-    return m;
-}
-constexpr B8 ct_r4_bounds(const B8& in)
-{
-    B8 o{};
-    for (int r = 0; r < 2; r++) {
-        const double a = in.v[r], pf = r4::after_product(in.v[r + 2]), pc = r4::after_product(in.v[r + 4]), pcf = r4::after_product(in.v[r + 6]);
-        const double sum = r4::checked(r4::checked(a + pc) + r4::checked(pf + pcf)), dif = r4::checked(r4::checked(a + pc) + fpf::AFTER_MUL_ROOT4);
-        o.v[r] = sum; o.v[r + 2] = sum; o.v[r + 4] = dif; o.v[r + 6] = dif;
-    }
-    return o;
-}
-// stage c of a forward block; REDUCE_ADDEND: the pass-through register is reduced first (the last stage of the transform)
-template <bool REDUCE_ADDEND>
-constexpr B8 ct_c_bounds(const B8& in)
-{
-    B8 o{};
-    for (int g = 0; g < 4; g++) {
-        const double t = r4::after_product(in.v[2 * g + 1]);
-        o.v[2 * g] = o.v[2 * g + 1] = r4::checked((REDUCE_ADDEND ? r4::kReduced : in.v[2 * g]) + t);
-    }
-    return o;
-}
-constexpr B8 gs_c_bounds(const B8& in)
-{
-    B8 o{};
-    for (int g = 0; g < 4; g++) {
-        const double s = r4::checked(in.v[2 * g] + in.v[2 * g + 1]);
-        o.v[2 * g] = s;
-        o.v[2 * g + 1] = r4::after_product(s);
-    }
-    return o;
-}
-constexpr B8 gs_r4_bounds(const B8& in)
-{
-    B8 o{};
-    for (int r = 0; r < 2; r++) {
-        const double s0 = r4::checked(in.v[r] + in.v[r + 2]), s1 = r4::checked(in.v[r + 4] + in.v[r + 6]);
-        o.v[r] = r4::checked(s0 + s1);
-        o.v[r + 4] = r4::after_product(r4::checked(s0 + s1));
-        o.v[r + 2] = r4::after_product(r4::checked(s0 + fpf::AFTER_MUL_ROOT4));
-        o.v[r + 6] = r4::after_product(r4::checked(s0 + fpf::AFTER_MUL_ROOT4));
-    }
-    return o;
-}
-constexpr B8 reduce8_bounds(const B8& in, double limit)
-{
-    B8 o = in;
-    for (int r = 0; r < 8; r++)
-        if (in.v[r] > limit) o.v[r] = r4::kReduced;
-    return o;
-}
-// schedules as types (S::in() = the bounds on entry)
-template <int MICRO> struct U8 { static constexpr B8 in() { return uniform8(MICRO * 1e-6); } };
-template <class S> struct CtR4 { static constexpr B8 in() { return ct_r4_bounds(S::in()); } };
-template <class S, bool RA> struct CtC { static constexpr B8 in() { return ct_c_bounds<RA>(S::in()); } };
-template <class S> struct GsC { static constexpr B8 in() { return gs_c_bounds(S::in()); } };
-template <class S> struct GsR4 { static constexpr B8 in() { return gs_r4_bounds(S::in()); } };
-template <class S> struct Xpose8 { static constexpr B8 in() { return uniform8(max8(S::in())); } };
-template <class S, int LIMIT_MILLI> struct Red8 { static constexpr B8 in() { return reduce8_bounds(S::in(), LIMIT_MILLI * 0.001); } };
-
-template <class S, int R = 0, int LIMIT_MILLI = 0>
-__device__ __forceinline__ void reduce_above8(double (&x)[kRegs8])
-{
-    if constexpr (R < 8) {
-        if constexpr (S::in().v[R] > LIMIT_MILLI * 0.001) x[R] = fpf::reduce(x[R]);
-        reduce_above8<S, R + 1, LIMIT_MILLI>(x);
-    }
-}
-// the radix-4 pass of a forward block on a lane with input schedule S
-template <class S>
-__device__ __forceinline__ void ct_r4_pass(double (&x)[kRegs8], double w, double u, double uw)
-{
-    constexpr B8 b = S::in();
-    r4::ct_bfly4<r4::needs_wide(b.v[4]), r4::needs_wide(b.v[2]), r4::needs_wide(b.v[6])>(x[0], x[2], x[4], x[6], w, u, uw);
-    r4::ct_bfly4<r4::needs_wide(b.v[5]), r4::needs_wide(b.v[3]), r4::needs_wide(b.v[7])>(x[1], x[3], x[5], x[7], w, u, uw);
-}
-template <class S, bool REDUCE_ADDEND, int G = 0, class TW>
-__device__ __forceinline__ void ct_c_stage(double (&x)[kRegs8], const TW& tw)
-{
-    if constexpr (G < 4) {
-        if constexpr (REDUCE_ADDEND) x[2 * G] = fpf::reduce(x[2 * G]);
-        const double t = r4::product<r4::needs_wide(S::in().v[2 * G + 1])>(x[2 * G + 1], tw(3 + G));
-        const double a = x[2 * G];
-        x[2 * G] = a + t;
-        x[2 * G + 1] = a - t;
-        ct_c_stage<S, REDUCE_ADDEND, G + 1>(x, tw);
-    }
-}
-template <class S, int G = 0, class TW>
-__device__ __forceinline__ void gs_c_stage(double (&x)[kRegs8], const TW& tw)
-{
-    if constexpr (G < 4) {
-        const double a = x[2 * G], b = x[2 * G + 1];
-        x[2 * G] = a + b;
-        x[2 * G + 1] = r4::product<r4::needs_wide(S::in().v[2 * G] + S::in().v[2 * G + 1])>(a - b, tw(3 + G));
-        gs_c_stage<S, G + 1>(x, tw);
-    }
-}
-template <class S>
-__device__ __forceinline__ void gs_r4_pass(double (&x)[kRegs8], double w, double v, double vw)
-{
-    constexpr B8 b = S::in();
-    {
-        constexpr double s0 = b.v[0] + b.v[2], s1 = b.v[4] + b.v[6];
-        r4::gs_bfly4<r4::needs_wide(s0 + s1), r4::needs_wide(s0 + fpf::AFTER_MUL_ROOT4), r4::needs_wide(s0 + fpf::AFTER_MUL_ROOT4)>(x[0], x[2], x[4], x[6], w, v, vw);
-    }
-    {
-        constexpr double s0 = b.v[1] + b.v[3], s1 = b.v[5] + b.v[7];
-        r4::gs_bfly4<r4::needs_wide(s0 + s1), r4::needs_wide(s0 + fpf::AFTER_MUL_ROOT4), r4::needs_wide(s0 + fpf::AFTER_MUL_ROOT4)>(x[1], x[3], x[5], x[7], w, v, vw);
-    }
-}
-
 // forward schedule on gadget digits after the exact split (|in| <= kQSplitDigitBound / p < 0.05)
 constexpr int kInMicro = 50000;
 static_assert(kQSplitDigitBound / fpf::P < kInMicro * 1e-6, "split digits exceed the schedule's input bound");
@@ -271,13 +144,6 @@ static_assert(max8(IOut::in()) <= kLim * 0.001 && 4 * max8(IOut::in()) < fpf::LI
               "radix-4 inverse quarter transform: outputs exceed what the last two inverse stages accept");
 }  // namespace q4
 
-// products u w / v w of the radix-4 passes whose twiddles are per lam (block B) or per lane (block C), one per quarter
-struct QuarterR4Tables {
-    double uwb_fwd[8], uwb_inv[8];
-    double uwc_fwd[64], uwc_inv[64];
-};
-constexpr int kQR4Doubles = sizeof(QuarterR4Tables) / 8;      // 144
-
 // per-lane addresses of a quarter wave
 struct QuarterCtx {
     char *a1, *b1, *b2;               // the wave's transpose tile (slot maps of ntt_wave512.h; c2 == a1)
@@ -285,7 +151,7 @@ struct QuarterCtx {
     const char* tc_fwd;               // ... + 8 lane                            (+ 512 k)
     const char* tc_mirror;            // forward stage 6-8 twiddles of quarter 3 - q at lane 63 - L: the inverse ones, negated and re-indexed
     const Ntt512Tables* gt;           // global tables of this quarter (wave-uniform stage 0-2 twiddles; slot 7: their product u w / v w)
-    const char* r4b;                  // LDS copy of this quarter's QuarterR4Tables + 8 lam: uwb_fwd (+ 64: uwb_inv)
+    const char* r4b;                  // LDS copy of this quarter's Ntt512Tables::uwb_fwd .. uwc_inv + 8 lam: uwb_fwd (+ 64: uwb_inv)
     const char* r4c;                  // ... + 8 * 16 + 8 lane: uwc_fwd (+ 512: uwc_inv)
 };
 
@@ -459,7 +325,7 @@ __global__ __launch_bounds__(kNttThreads) void bk2q_to_ntt_kernel(
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
     const RotDesc2* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
-    const Ntt512Tables* __restrict__ tq, const QuarterR4Tables* __restrict__ tq4, int steps, uint64_t* __restrict__ acc_dump)
+    const Ntt512Tables* __restrict__ tq, int steps, uint64_t* __restrict__ acc_dump)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int g = blockIdx.x;
@@ -481,7 +347,7 @@ __global__ __launch_bounds__(kQThreads, 2) void blind_rotate_lvl2q_kernel(
         // [tb_fwd 56 | tb_inv 56] are contiguous in Ntt512Tables, tc_fwd follows
         ((double*)(smem + kQLdsTab))[i] = k < 112 ? tq[q].tb_fwd[k] : tq[q].tc_fwd[k - 112];
     }
-    for (int i = tid; i < kQWaves * kQR4Doubles; i += kQThreads) ((double*)(smem + kQLdsR4))[i] = ((const double*)tq4)[i];
+    for (int i = tid; i < kQWaves * kQR4Doubles; i += kQThreads) ((double*)(smem + kQLdsR4))[i] = tq[i / kQR4Doubles].uwb_fwd[i % kQR4Doubles];
     __syncthreads();
 
     QuarterCtx ctx;

@@ -43,45 +43,10 @@ void build_tables_lvl2q(Ntt512Tables (&t)[4])
                         [&](int idx) { const int m = top(idx); return Rinv[4 * m + q * m + (idx - m)]; });
 }
 
-// exact product mod p of two balanced residues held in doubles, balanced again
-double prod_balanced(double a, double b)
-{
-    const __int128 p = (__int128)fpf::P_U64;
-    __int128 v = ((__int128)(int64_t)a * (__int128)(int64_t)b) % p;
-    if (v < 0) v += p;
-    return balanced((uint64_t)v);
-}
-
-// Radix-4 form of the quarter transforms (kernels_lvl2q.hip.h: q4): the product of a block's stage-a and stage-b twiddles, u w
-// (forward) and v w (inverse) -- in the spare slot 7 of tu_fwd / tu_inv for the wave-uniform block, in QuarterR4Tables per lam
-// and per lane.  The second stage-b twiddle must be I times (forward) / -I times (inverse) the first: checked here.
-int build_tables_lvl2q_r4(Ntt512Tables (&t)[4], QuarterR4Tables (&r)[4])
-{
-    for (int q = 0; q < 4; q++) {
-        auto check = [&](double w1, double w2, bool inverse) {
-            return prod_balanced(w1, inverse ? -fpf::ROOT4 : fpf::ROOT4) == w2;
-        };
-        if (!check(t[q].tu_fwd[1], t[q].tu_fwd[2], false) || !check(t[q].tu_inv[1], t[q].tu_inv[2], true)) return -1;
-        t[q].tu_fwd[7] = prod_balanced(t[q].tu_fwd[0], t[q].tu_fwd[1]);
-        t[q].tu_inv[7] = prod_balanced(t[q].tu_inv[0], t[q].tu_inv[1]);
-        for (int lam = 0; lam < 8; lam++) {
-            if (!check(t[q].tb_fwd[8 + lam], t[q].tb_fwd[16 + lam], false) || !check(t[q].tb_inv[8 + lam], t[q].tb_inv[16 + lam], true)) return -1;
-            r[q].uwb_fwd[lam] = prod_balanced(t[q].tb_fwd[lam], t[q].tb_fwd[8 + lam]);
-            r[q].uwb_inv[lam] = prod_balanced(t[q].tb_inv[lam], t[q].tb_inv[8 + lam]);
-        }
-        for (int lane = 0; lane < 64; lane++) {
-            if (!check(t[q].tc_fwd[64 + lane], t[q].tc_fwd[128 + lane], false) || !check(t[q].tc_inv[64 + lane], t[q].tc_inv[128 + lane], true)) return -1;
-            r[q].uwc_fwd[lane] = prod_balanced(t[q].tc_fwd[lane], t[q].tc_fwd[64 + lane]);
-            r[q].uwc_inv[lane] = prod_balanced(t[q].tc_inv[lane], t[q].tc_inv[64 + lane]);
-        }
-    }
-    return 0;
-}
-
 int ensure_tables_lvl2(int device)
 {
     DeviceState& s = g_dev[device];
-    if (s.tables2 && s.tables2q && s.tables2q4) return 0;
+    if (s.tables2 && s.tables2q) return 0;
     HIP_TRY(hipSetDevice(phys_device(device)));
     if (!s.cus) {
         hipDeviceProp_t prop;
@@ -94,15 +59,13 @@ int ensure_tables_lvl2(int device)
         HIP_TRY(hipMalloc((void**)&s.tables2, sizeof(host)));
         HIP_TRY(hipMemcpy(s.tables2, host, sizeof(host), hipMemcpyHostToDevice));
     }
-    if (!s.tables2q || !s.tables2q4) {
+    if (!s.tables2q) {
         static Ntt512Tables hostq[4];
-        static QuarterR4Tables hostq4[4];
         build_tables_lvl2q(hostq);
-        if (build_tables_lvl2q_r4(hostq, hostq4)) return fail(-2, "quarter tables: the stage-b twiddles of a block are not I apart (radix-4 form)");
-        if (!s.tables2q) HIP_TRY(hipMalloc((void**)&s.tables2q, sizeof(hostq)));
+        for (int q = 0; q < 4; q++)
+            if (!fill_r4_products_512(hostq[q])) return fail(-2, "quarter tables: the stage-b twiddles of a block are not I apart (radix-4 form)");
+        HIP_TRY(hipMalloc((void**)&s.tables2q, sizeof(hostq)));
         HIP_TRY(hipMemcpy(s.tables2q, hostq, sizeof(hostq), hipMemcpyHostToDevice));
-        if (!s.tables2q4) HIP_TRY(hipMalloc((void**)&s.tables2q4, sizeof(hostq4)));
-        HIP_TRY(hipMemcpy(s.tables2q4, hostq4, sizeof(hostq4), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -124,7 +87,7 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
             s.br2q_lds_opt_in = true;
         }
         hipLaunchKernelGGL(blind_rotate_lvl2q_kernel, dim3((unsigned)count), dim3(kQThreads), kQLdsBytes, st, d, (int)count,
-                           s.bk2q_ntt, s.tables2q, s.tables2q4, steps, acc_dump);
+                           s.bk2q_ntt, s.tables2q, steps, acc_dump);
     } else {
         if (!s.br2_lds_opt_in) {
             HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3LdsBytes));
