@@ -253,7 +253,7 @@ def cgroup_cpu_quota():
         return None
 
 
-def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=10.0):
+def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=15.0):
     """Time the optimised CPU gate (oracle/cpu_fast.c) on a bounded sample of the same workload: on every core this process may
     use (all visible cores unless the cgroup quota says fewer) and, measured separately, on ONE thread."""
     fek = L.fast_evalkey_create(bk, ksk)

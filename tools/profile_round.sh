@@ -7,9 +7,11 @@
 # PMC slots: 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -e
 TAG=${1:-r03}
+PART=${2:-all}     # stats | pmc | all: the passes take about 15 minutes together; a gpurun call is limited to 20
 export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}_prof
 mkdir -p $OUT
+if [ "$PART" != "pmc" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.json
 echo "stats pass done"
 # one launch shape per kernel row: the headline workload alone (4096 NAND: every blind_rotate_kernel launch is 4096 rotations, every
@@ -18,6 +20,8 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats_nand -o st --output-format csv --
 echo "nand-only stats pass done"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_lvl2 -o st --output-format csv -- python3 bench.py --workload nand_lvl2 --steps 3 --warmup 1 --no-extra --no-cpu-baseline > $OUT/nand_lvl2_bench_under_rocprof.json
 echo "lvl2-only stats pass done"
+fi
+if [ "$PART" = "stats" ]; then exit 0; fi
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE \
     --kernel-trace -d $OUT/pmc_sq -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-api > /dev/null
 echo "sq pass done"
