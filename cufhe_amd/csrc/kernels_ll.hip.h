@@ -36,8 +36,9 @@ constexpr int kLlLdsAcc = kLlLdsTiles + 16 * kTile512Bytes;                   //
 constexpr int kLlLdsSum = kLlLdsAcc + 2 * 2 * kN * 4;                         // + 16384   [j][copy][N] u32
 constexpr int kLlLdsHand = kLlLdsSum + 2 * kN * 8;                            // + 16384   [out][h][c][lane] f64
 constexpr int kLlLdsDig = kLlLdsHand + 2 * kN * 8;                            // + 16384   [out][h][e] f64
-constexpr int kLlLdsAbar = kLlLdsDig + kBkRows * 2 * 64 * 8;                  // + 6144    [row][h][lane] 8 digits x i8
-constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 145424
+constexpr int kLlDigBytes = 2 * 2 * 8 * 64 * 4;                               // single kernel: decomposed words [m][hh][rr][lane] u32; paired kernel: [row][h][lane] 8 digits x i8 (6144)
+constexpr int kLlLdsAbar = kLlLdsDig + kLlDigBytes;                           // + 8192
+constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 147472
 static_assert(kBgbit <= 8, "digits are packed as signed bytes");
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
@@ -56,6 +57,30 @@ __device__ __forceinline__ void ll_split_first_stages(double (&x)[kRegs8], const
     for (int r = 0; r < 4; r++) {
         const double a = (double)(int32_t)__builtin_amdgcn_sbfe(q0.x, 8u * r, 8u), a1 = (double)(int32_t)__builtin_amdgcn_sbfe(q0.y, 8u * r, 8u);
         const double b = (double)(int32_t)__builtin_amdgcn_sbfe(q1.x, 8u * r, 8u), b1 = (double)(int32_t)__builtin_amdgcn_sbfe(q1.y, 8u * r, 8u);
+        if (h == 0) {
+            const double u = __builtin_fma(b, fpf::ROOT4, a), u1 = __builtin_fma(b1, fpf::ROOT4, a1);
+            x[r] = __builtin_fma(u1, fpf::ROOT8, u);
+            x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
+        } else {
+            const double v = __builtin_fma(-b, fpf::ROOT4, a);
+            const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
+            x[r] = v + t;
+            x[r + 4] = v - t;
+        }
+    }
+}
+
+// The same from the DECOMPOSED WORDS of the coefficients (single-rotation kernel): w0[r] / w1[r] hold the word of e = lane + 64 r and
+// e + 512 with the sign mask applied, the row's digit is the signed field at bit `pos` (include/gatebootstrapping_gpu.cuh:157-181).
+// The tail then stores one dword per coefficient and component -- lane-contiguous, conflict-free -- instead of l bytes into words
+// that eight lanes share a bank for.
+__device__ __forceinline__ void ll_split_first_stages_words(double (&x)[kRegs8], const uint32_t (&w0)[8], const uint32_t (&w1)[8], int h, uint32_t pos)
+{
+    constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double a = (double)(int32_t)__builtin_amdgcn_sbfe(w0[r], pos, (uint32_t)kBgbit), a1 = (double)(int32_t)__builtin_amdgcn_sbfe(w0[r + 4], pos, (uint32_t)kBgbit);
+        const double b = (double)(int32_t)__builtin_amdgcn_sbfe(w1[r], pos, (uint32_t)kBgbit), b1 = (double)(int32_t)__builtin_amdgcn_sbfe(w1[r + 4], pos, (uint32_t)kBgbit);
         if (h == 0) {
             const double u = __builtin_fma(b, fpf::ROOT4, a), u1 = __builtin_fma(b1, fpf::ROOT4, a1);
             x[r] = __builtin_fma(u1, fpf::ROOT8, u);
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     }
     __syncthreads();
 
-    uint2* digL = (uint2*)(smem + kLlLdsDig);                 // [row][h][lane]
+    uint32_t* digW = (uint32_t*)(smem + kLlLdsDig);           // [m][hh][rr][lane]: the decomposed word of coefficient lane + 64 rr + 512 hh of component m
     const bool row_wave = wave < kLlRowWaves;
     const int h = wave & 1;                                   // half transform of this wave (both roles)
     const int row = wave >> 1;                                // row waves: TRGSW row = wj * l + wd
@@ -157,14 +182,10 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         uint32_t rot[2];
 #pragma unroll
         for (int m = 0; m < 2; m++) rot[m] = accL[m * 2 * kN + ridx];
-        uint8_t* dst = (uint8_t*)digL + (hh * 64 + lane) * 8 + rr;
+        uint32_t* dst = digW + (hh * 8 + rr) * 64 + lane;
 #pragma unroll
-        for (int m = 0; m < 2; m++) {
-            const uint32_t t = ((neg ? 0u - rot[m] : rot[m]) - w[m] + decomp_offset()) ^ decomp_signmask();
-#pragma unroll
-            for (int dg = 0; dg < kL; dg++)
-                dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
-        }
+        for (int m = 0; m < 2; m++)
+            dst[m * (2 * 8 * 64)] = ((neg ? 0u - rot[m] : rot[m]) - w[m] + decomp_offset()) ^ decomp_signmask();
     };
     if (steps > 0) {
         uint32_t w[2];
@@ -189,11 +210,14 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
         if (((i + 1) & 63) == 0) abar_win = abar_lds[i + 1 + lane];       // entries 630..639 are padding, never used
         const uint32_t abar_next = __builtin_amdgcn_readlane(abar_win, (i + 1) & 63);
         if (row_wave) {
-            // digits of this row at e = lane + 64 r (word 0) and e + 512 (word 1), a signed byte each, left by the
-            // inverse waves (out = wj); then the first stage of the transform
-            const uint2 q0 = digL[(row * 2 + 0) * 64 + lane], q1 = digL[(row * 2 + 1) * 64 + lane];
+            // the decomposed words of component wj at e = lane + 64 r and e + 512, left by the tail; this row's digit is the
+            // field at bit 32 - (wd + 1) Bgbit; then the first two stages of the transform, exactly
+            const uint32_t* dgp = digW + wj * (2 * 8 * 64) + lane;
+            uint32_t w0[8], w1[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { w0[r] = dgp[r * 64]; w1[r] = dgp[(8 + r) * 64]; }
             double x[kRegs8];
-            ll_split_first_stages(x, q0, q1, h);
+            ll_split_first_stages_words(x, w0, w1, h, 32u - (uint32_t)(wd + 1) * kBgbit);
             ntt512_forward_pinned_from1(x, ctx, tu, twb, twc);
             double* s0 = sumL + h * kH + lane;
 #pragma unroll
