@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "csrc", "capi.hip")
 # and the N = 512 parameter-set kernel 4 % slower, so it is not a flag for the whole library
 SRC_LL = os.path.join(HERE, "csrc", "kernels_ll.hip")
 LL_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-# the main translation unit: the max-memory-clause strategy groups the LDS reads of a phase (round 4, second session, same box:
+# the main translation unit: the max-memory-clause strategy groups the LDS reads of a phase (same box:
 # blind_rotate_kernel 35.69 -> 35.34 ms per 4096 rotations, the N = 512 parameter-set kernel 33.7 -> 32.8 ms, everything else within 0.2 %;
 # max-ilp here: 36.26 ms)
 MAIN_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]

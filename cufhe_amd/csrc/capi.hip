@@ -103,7 +103,7 @@ long g_ks_split_threshold = -1; // key switches per launch up to which each ciph
 //   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.18 (1536)  1.38 (1792)  1.57 (2048)  3.10 (4096)
 //   table through LDS, ceil(n / 256) ciphertexts per workgroup (one grid round, every CU busy):
 //                                 0.94 (256)  1.07 (512)  1.17 (1024)  1.23 (1536)  1.27 (2048)  1.39 (3072)  1.55 (4096)
-//     (round 2 always put 16 per workgroup: 1.53 - 1.59 whatever n <= 4096)
+//     (16 per workgroup whatever the count: 1.53 - 1.59 for any n <= 4096)
 // so: split up to 192, one workgroup per ciphertext up to 1600, the shared-table kernel above -- on 256 CUs; in units of the
 // device's CU count: 3/4 and 25/4 ciphertexts per CU
 inline long ks_auto_split(int cus) { return 3L * std::max(1, cus) / 4; }
@@ -649,13 +649,13 @@ int run_gates_ps(int set, int device, void* stream, int level, size_t count, Get
 int ps_ctxt_words(int set, int level);
 // >= 0: the per-gate API (both ciphertext levels, both gate orders) runs on this compiled parameter set -- the reference's build-time
 // choice (CMakeLists.txt:8-24) serves every entry point the same way; ciphertexts then have the set's sizes (cufhe_amd_ctxt_words)
-long g_lvl0_param_set = -1;
+long g_param_set = -1;
 
 template <class GetGate>
 int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 {
     if (level == 0 && g_lvl0_ring == 2048) return run_gates_lvl2(device, stream, count, get);
-    if ((level == 0 || level == 1) && g_lvl0_param_set >= 0) return run_gates_ps((int)g_lvl0_param_set, device, stream, level, count, get);
+    if ((level == 0 || level == 1) && g_param_set >= 0) return run_gates_ps((int)g_param_set, device, stream, level, count, get);
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     if (!s.keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
@@ -1377,12 +1377,12 @@ int cufhe_amd_set_option(const char* key, long value)
             // ciphertext device slots are carved for the largest compiled sizes (HipBackend::slot_words), so a set only has to fit them
             if ((int)p.lvl0_words > kLvl0Words || (int)p.lvl1_words > kLvl1Words) return fail(-1, "param_set: the set's ciphertexts exceed the per-gate API's buffers");
         }
-        if (value != g_lvl0_param_set) {
+        if (value != g_param_set) {
             // recorded gates were sized and routed for the old set: they complete first
             std::lock_guard<std::mutex> lk2(g_sched_mu);
             if (int rc = sched_synchronize_all()) return rc;
         }
-        g_lvl0_param_set = value;
+        g_param_set = value;
         return 0;
     }
     if (!strcmp(key, "ks_per_wg")) {

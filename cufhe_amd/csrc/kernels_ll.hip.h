@@ -1,7 +1,7 @@
 // kernels_ll.hip.h -- low-latency blind rotate: one 16-wave workgroup per rotation, every
 // transform split into its two 512-point halves (ntt_wave512.h).
 //
-// Same words as blind_rotate_kernel / blind_rotate_wg_kernel (kernels.hip.h); used for launches
+// Same words as blind_rotate_kernel (kernels.hip.h); used for launches
 // too small to fill the chip with the wave-per-rotation kernel, where what counts is the length
 // of the dependent chain of ONE rotation: 630 CMux steps, each "decompose -> forward NTT ->
 // pointwise -> inverse NTT -> accumulate".
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
 #ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
-// The first TWO stages of half h of the forward transform on one row's gadget digits, exactly (round 4).  q0 / q1 hold, as signed
+// The first TWO stages of half h of the forward transform on one row's gadget digits, exactly.  q0 / q1 hold, as signed
 // bytes, the digits at e = lane + 64 r (q0) and e + 512 (q1), r = 0..7.  The 1024-point transform's stage 0 gives u_h = a +- I b, its
 // stage 1 pairs u_h[e] with u_h[e + 256] under zeta (h = 0) or zeta^3 (h = 1).  On the four original digits a, a' (e, e + 256) and
 // b, b' (e + 512, e + 768) both are exact linear forms -- zeta^3 I = zeta^5 = -zeta, so zeta^3 (a' - I b') = zeta^3 a' + zeta b' and the

@@ -208,8 +208,8 @@ __device__ __forceinline__ void accumulate_poly(double* sums, const double (&x)[
 }
 
 // ----------------------------------------------------------------------------------
-// The schedule (round 3; the round-2 kernel it replaces -- one sum region reused by the two halves, accumulator in LDS,
-// 64-bit LDS atomics, inverse jobs 8 + 4 -- is in the history of this file; its per-phase cycle counters are
+// The schedule (the kernel it replaces -- one sum region reused by the two halves, accumulator in LDS, 64-bit LDS atomics,
+// inverse jobs 8 + 4 -- is in the history of this file; its per-phase cycle counters are
 // profiles/r03_lvl2_phases_round2_kernel.txt).
 //
 // What those counters showed (tools/lvl2_phases.py):

@@ -240,7 +240,7 @@ __device__ __forceinline__ void quarter_inverse_r4(double (&x)[kRegs8], const Qu
     q4::gs_r4_pass<q4::IA1>(x, tu[0], tu[1], tu[7]);           // s1 s0
     q4::reduce_above8<q4::GsR4<q4::IA1>, 0, q4::kLim>(x);
 }
-#ifdef CUFHE_AMD_Q_RADIX2        // experiment (tools/build_variant.py): the radix-2 quarter transforms, as until round 5
+#ifdef CUFHE_AMD_Q_RADIX2        // experiment (tools/build_variant.py): the radix-2 quarter transforms (profiles/r05_lvl2_ab.txt)
 constexpr bool kQuarterR4 = false;
 #else
 constexpr bool kQuarterR4 = true;

@@ -131,7 +131,7 @@ template <> struct Poly<9> {
 };
 
 // The transforms of the wave-per-rotation kernel (blind_rotate_ps_batch_kernel): for the 1024-point ring the radix-4 passes of
-// ntt_r4.h on the r4 tables in their packed form (round 4; the workgroup-per-rotation kernel and the key conversion keep the
+// ntt_r4.h on the r4 tables in their packed form (the workgroup-per-rotation kernel and the key conversion keep the
 // radix-2 transform and tables above), for the 512-point ring Poly<9> as it is.  DIGIT_MAX = Bg/2.
 template <int NBIT, int DIGIT_MAX> struct PsbPoly;
 template <int DIGIT_MAX> struct PsbPoly<9, DIGIT_MAX> : Poly<9> {
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
         // contribute is a multiple of 2^limb_bits -- with limb_bits >= 16 only its top 16 bits have to be carried through the last
         // limb's row walk, two coefficients (r, r + R/2) to a register: R/2 registers per component where there were R (the full words
         // were what spilled: 19 registers of scratch on the 80-bit set).  The last limb (shift 0) goes straight into the accumulator.
-#ifdef CUFHE_AMD_PS_NO_PACK      // experiment (tools/build_variant.py): the full words carried, as until round 5
+#ifdef CUFHE_AMD_PS_NO_PACK      // experiment (tools/build_variant.py): the full words carried (profiles/r05_lvl2_ab.txt)
         constexpr bool kPackDelta = false;
 #else
         constexpr bool kPackDelta = PS::limbs > 1 && PS::limb_bits >= 16;

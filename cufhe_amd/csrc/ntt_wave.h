@@ -175,7 +175,7 @@ struct WaveCtx {
 // dst + 16 L).  Written as inline assembly ON PURPOSE: issued through __builtin_amdgcn_global_load_lds the compiler knows that
 // an asynchronous LDS write is in flight, cannot tell which LDS reads it may alias (every per-lane LDS base here is opaque) and
 // puts `s_waitcnt vmcnt(0)` in front of the NEXT ds_read whatever it reads -- the wave then sits out the whole L2 round trip
-// of the piece it has just requested, once per key row (found in the ISA in round 5: in front of the first ds_read_b128 of the
+// of the piece it has just requested, once per key row (found in the ISA: in front of the first ds_read_b128 of the
 // pointwise product).  The protocol of the callers never reads a buffer before the barrier that follows the wait below, so no
 // such wait is needed; with the request invisible to the compiler none is emitted.  lds_dma_wait_all() is the wait the
 // callers place in front of that barrier.  M0 carries the LDS base (a reserved register the compiler sets before each of its own uses).
@@ -232,7 +232,7 @@ __device__ __forceinline__ WaveCtx make_wave_ctx_packed(char* lds, int tile_off,
 __device__ __forceinline__ double2 lds_ld2(const char* p, int off) { return *(const double2*)(p + off); }
 // COUNT packed twiddles of this lane into registers (ds_read_b128 each two).  (No CUFHE_AMD_ABL_NO_TW form: with constants in
 // place of these twiddles hipcc folds a fifth of the transform's arithmetic away -- 470 FP64 instructions less in the kernel --
-// so that "ablation" measures a different program; round 5 found its -13 % to be exactly that.)
+// so that "ablation" measures a different program; its -13 % turned out to be exactly that: profiles/r04_radix4_and_latency.md.)
 template <int COUNT>
 __device__ __forceinline__ void load_packed(double (&tw)[COUNT], const char* base)
 {
@@ -316,7 +316,7 @@ __device__ __forceinline__ void ct_four_stages(double (&x)[kRegs], const TW& tw)
         //   x[r] = u + zeta u', x[r + 4] = u - zeta u'                stage 1, first group (zeta, 13 bits)
         //   x[r + 8], x[r + 12] = v +- zeta^3 (a' - I b')             stage 1, second group: its twiddle zeta^3 has 37 bits, but
         //                       = v +- (zeta^3 a' + zeta b')          zeta^3 I = zeta^5 = -zeta, so it only ever meets an input, not a product
-        // Nine exact FP64 operations per four elements (round 1-3: fourteen, the second group through a modular product); every
+        // Nine exact FP64 operations per four elements (fourteen with the second group through a modular product); every
         // value stays below |x| (1 + I + zeta + zeta^3) = 2^42.2 for gadget digits.
         ct_exact_first_two(x);
     } else {

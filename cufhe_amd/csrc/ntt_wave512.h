@@ -49,7 +49,7 @@ static_assert(sizeof(Ntt512Tables) == (16 + 1008 + 144) * 8, "Ntt512Tables: [tu 
 constexpr int kLds512TableDoubles = 2 * 7 * 8 + 2 * 7 * 64;     // tb_fwd .. tc_inv, contiguous: 1008
 constexpr int kLds512TableBytes = kLds512TableDoubles * 8;      // 8064 per half
 
-// ---- radix-4 form of the 512-point transforms (round 5; kernels_lvl2q.hip.h and the inverse waves of kernels_ll.hip.h) ----------
+// ---- radix-4 form of the 512-point transforms (kernels_lvl2q.hip.h and the inverse waves of kernels_ll.hip.h) ----------
 // A three-stage block on the eight registers of a lane (strides 4, 2, 1; twiddles tw0 | tw1, tw2 = I tw1 | tw3..6) is one radix-4
 // pass over stages (a, b) -- groups {r, r + 2, r + 4, r + 6}, r = 0, 1: x0 = x[r], coarse partner x[r + 4] (twiddle w = tw0), fine
 // partner x[r + 2] (u = tw1), the product u w from the uw* fields of Ntt512Tables (the uniform one in the spare slot 7 of

@@ -65,7 +65,7 @@ class HipBackend : public sched::Backend {
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
     int words(int level) override
     {
-        if (level <= 1 && g_lvl0_param_set >= 0) return ps_ctxt_words((int)g_lvl0_param_set, level);       // the active parameter set's sizes
+        if (level <= 1 && g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes
         return slot_words(level);
     }
     // device slots are carved for the largest ciphertext of any compiled set, so "param_set" may change while ciphertexts live
@@ -344,7 +344,7 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
 int cufhe_amd_ctxt_words(int level)
 {
     if (level < 0 || level > 1) return fail(-1, "level must be 0 or 1");
-    if (g_lvl0_param_set >= 0) return ps_ctxt_words((int)g_lvl0_param_set, level);
+    if (g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);
     return level ? kLvl1Words : kLvl0Words;
 }
 
@@ -382,7 +382,7 @@ int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_
         if (c->level != out->level) return fail(-1, "operands of one gate must have the same level");
     }
     const DeviceState& ds = g_dev[device];
-    if (!ds.keys_ready && !ds.keys2_ready && g_lvl0_param_set < 0 && !one) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!ds.keys_ready && !ds.keys2_ready && g_param_set < 0 && !one) return fail(-3, "Initialize(ek) has not been called for this device");
     if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins)) return sched_error(S->dev(device), rc);
     return 0;
 }

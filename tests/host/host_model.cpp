@@ -463,7 +463,7 @@ void hm_external_product_split(uint32_t* out, const int32_t* dig, const uint32_t
     if (stats) { stats[0] = t.bad; stats[1] = t.max_abs; stats[2] = t.max_mul_in; stats[3] = t.max_wide_in; }
 }
 
-// One external product with the schedule of blind_rotate_kernel since round 5 (radix-4 passes, per-register bounds, the last
+// One external product with the schedule of blind_rotate_kernel (radix-4 passes, per-register bounds, the last
 // product of each sum reducing it): same interface as hm_external_product; stats[4] = largest value / its register's
 // compile-time bound (must stay <= 1), stats[5..20] = the spectrum bound per layout-C register, stats[21..36] = the inverse's
 // output bound per layout-A register.

@@ -382,7 +382,7 @@ def test_cpp_gate_api_three_logical_gpus(engine):
 
 
 def test_cpp_gate_api_without_output_renaming(engine):
-    """The same program, two logical devices, with "sched_rename" 0 (the default is 1 since round 5: every other run of this
+    """The same program, two logical devices, with "sched_rename" 0 (the default is 1: every other run of this
     program renames): every check of the reference's test programs (truth tables, chained in-place gates, polling,
     device-resident g-gates, TRLWE-level primitives, launch-count bounds, tlwedevices after Synchronize) holds when every
     output waits for the users of its buffer instead."""
