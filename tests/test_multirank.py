@@ -147,6 +147,44 @@ def test_self_launcher_with_stub_children():
     assert rc == 124 and time.monotonic() - t0 < 60
 
 
+LAUNCHER_UNDER_SIGTERM = r'''
+import importlib.util, os, sys
+spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
+d = importlib.util.module_from_spec(spec); spec.loader.exec_module(d)
+child = "import os, time; open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid())); time.sleep(600)" % OUT
+open(os.path.join(OUT, "launcher"), "w").write(str(os.getpid()))
+d.spawn_ranks([sys.executable, "-c", child], 2, timeout=500)
+'''
+
+
+def test_launcher_ends_its_ranks_when_it_is_terminated(tmp_path):
+    """The ranks lead their own sessions, so a SIGTERM aimed at the launcher (a harness timeout) does not reach them by itself:
+    spawn_ranks turns it into an exception and ends the ranks before it goes on -- no GPU-resident process is left behind."""
+    import signal
+    import time
+    code = f"ROOT={ROOT!r}\nOUT={str(tmp_path)!r}\n" + LAUNCHER_UNDER_SIGTERM
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    deadline = time.monotonic() + 60
+    while time.monotonic() < deadline and not all((tmp_path / f).exists() and (tmp_path / f).read_text() for f in ("pid0", "pid1")):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f).read_text()) for f in ("pid0", "pid1")]
+    p.send_signal(signal.SIGTERM)
+    p.wait(60)
+    assert p.returncode != 0
+    for _ in range(100):
+        alive = []
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                alive.append(pid)
+            except ProcessLookupError:
+                pass
+        if not alive:
+            break
+        time.sleep(0.1)
+    assert not alive, f"ranks {alive} survived their launcher"
+
+
 SHARED_GPU_CHILD = r'''
 import json, os, sys, importlib.util
 spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "cufhe_amd", "dist.py"))
