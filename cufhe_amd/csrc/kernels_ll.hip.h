@@ -36,44 +36,22 @@ constexpr int kLlLdsAcc = kLlLdsTiles + 16 * kTile512Bytes;                   //
 constexpr int kLlLdsSum = kLlLdsAcc + 2 * 2 * kN * 4;                         // + 16384   [j][copy][N] u32
 constexpr int kLlLdsHand = kLlLdsSum + 2 * kN * 8;                            // + 16384   [out][h][c][lane] f64
 constexpr int kLlLdsDig = kLlLdsHand + 2 * kN * 8;                            // + 16384   [out][h][e] f64
-constexpr int kLlDigBytes = 2 * 2 * 8 * 64 * 4;                               // single kernel: decomposed words [m][hh][rr][lane] u32; paired kernel: [row][h][lane] 8 digits x i8 (6144)
+constexpr int kLlDigBytes = 2 * kN * 4;                                       // the decomposed words of one rotation, [m][e] u32
 constexpr int kLlLdsAbar = kLlLdsDig + kLlDigBytes;                           // + 8192
 constexpr int kLlLdsBytes = kLlLdsAbar + kAbarBytes + 16;                     // 147472
-static_assert(kBgbit <= 8, "digits are packed as signed bytes");
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
     const LinDesc* __restrict__ descs, int count, const double* __restrict__ bk_ntt,
     const Ntt512Tables* __restrict__ gt2, int steps, uint32_t* __restrict__ acc_dump);
 #ifndef CUFHE_AMD_LL_DECLARATIONS_ONLY
-// The first TWO stages of half h of the forward transform on one row's gadget digits, exactly.  q0 / q1 hold, as signed
-// bytes, the digits at e = lane + 64 r (q0) and e + 512 (q1), r = 0..7.  The 1024-point transform's stage 0 gives u_h = a +- I b, its
-// stage 1 pairs u_h[e] with u_h[e + 256] under zeta (h = 0) or zeta^3 (h = 1).  On the four original digits a, a' (e, e + 256) and
-// b, b' (e + 512, e + 768) both are exact linear forms -- zeta^3 I = zeta^5 = -zeta, so zeta^3 (a' - I b') = zeta^3 a' + zeta b' and the
-// 37-bit root only meets a 6-bit digit: five FMAs per pair where the general butterfly took ten operations.  |x| < 2^42.2.
-__device__ __forceinline__ void ll_split_first_stages(double (&x)[kRegs8], const uint2 q0, const uint2 q1, int h)
-{
-    constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const double a = (double)(int32_t)__builtin_amdgcn_sbfe(q0.x, 8u * r, 8u), a1 = (double)(int32_t)__builtin_amdgcn_sbfe(q0.y, 8u * r, 8u);
-        const double b = (double)(int32_t)__builtin_amdgcn_sbfe(q1.x, 8u * r, 8u), b1 = (double)(int32_t)__builtin_amdgcn_sbfe(q1.y, 8u * r, 8u);
-        if (h == 0) {
-            const double u = __builtin_fma(b, fpf::ROOT4, a), u1 = __builtin_fma(b1, fpf::ROOT4, a1);
-            x[r] = __builtin_fma(u1, fpf::ROOT8, u);
-            x[r + 4] = __builtin_fma(-u1, fpf::ROOT8, u);
-        } else {
-            const double v = __builtin_fma(-b, fpf::ROOT4, a);
-            const double t = __builtin_fma(a1, kZ3, b1 * fpf::ROOT8);
-            x[r] = v + t;
-            x[r + 4] = v - t;
-        }
-    }
-}
-
-// The same from the DECOMPOSED WORDS of the coefficients (single-rotation kernel): w0[r] / w1[r] hold the word of e = lane + 64 r and
-// e + 512 with the sign mask applied, the row's digit is the signed field at bit `pos` (include/gatebootstrapping_gpu.cuh:157-181).
-// The tail then stores one dword per coefficient and component -- lane-contiguous, conflict-free -- instead of l bytes into words
-// that eight lanes share a bank for.
+// The first TWO stages of half h of the forward transform on one row's gadget digits, exactly, from the DECOMPOSED WORDS of the
+// coefficients: w0[r] / w1[r] hold the word of e = lane + 64 r and e + 512 with the sign mask applied, the row's digit is the signed field
+// at bit `pos` (include/gatebootstrapping_gpu.cuh:157-181).  The 1024-point transform's stage 0 gives u_h = a +- I b, its stage 1 pairs
+// u_h[e] with u_h[e + 256] under zeta (h = 0) or zeta^3 (h = 1).  On the four original digits a, a' (e, e + 256) and b, b' (e + 512,
+// e + 768) both are exact linear forms -- zeta^3 I = zeta^5 = -zeta, so zeta^3 (a' - I b') = zeta^3 a' + zeta b' and the 37-bit root only
+// meets a 6-bit digit: five FMAs per pair where the general butterfly took ten operations.  |x| < 2^42.2.  (The tail stores one dword per
+// coefficient and component -- lane-contiguous, conflict-free -- instead of l digit bytes into words that eight lanes share a bank for,
+// and nothing has to be packed.)
 __device__ __forceinline__ void ll_split_first_stages_words(double (&x)[kRegs8], const uint32_t (&w0)[8], const uint32_t (&w1)[8], int h, uint32_t pos)
 {
     constexpr double kZ3 = fpf::ROOT8 * fpf::ROOT8 * fpf::ROOT8;
@@ -308,9 +286,9 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll_kernel(
 // LDS.  LDS per rotation: accumulator 8 KiB (one copy: the decomposition computes its rotated index), sums 16 KiB (an inverse wave leaves its half transform where it read its sum), digits
 // 6 KiB, abar list.
 // ----------------------------------------------------------------------------------
-constexpr int kLl2RotBytes = 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8 + kAbarBytes + 16;    // 32032
+constexpr int kLl2RotBytes = 2 * kN * 4 + 2 * kN * 8 + kLlDigBytes + kAbarBytes + 16;            // 34080
 constexpr int kLl2LdsRot = kLlLdsTiles + 16 * kTile512Bytes;
-constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes + 16;                                  // 152912 (+ the inverse waves' counter)
+constexpr int kLl2LdsBytes = kLl2LdsRot + 2 * kLl2RotBytes + 16;                                  // 157008 (+ the inverse waves' counter)
 static_assert(kLl2LdsBytes <= 160 * 1024, "paired low-latency kernel does not fit the CU's LDS");
 
 __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
@@ -325,7 +303,7 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    struct Rot { uint32_t* acc; double* sum; uint2* dig; uint16_t* abar; uint32_t* bbar; };
+    struct Rot { uint32_t* acc; double* sum; uint32_t* dig; uint16_t* abar; uint32_t* bbar; };
     Rot rot[2];
     int gidx[2];
 #pragma unroll
@@ -333,8 +311,8 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         char* base = smem + kLl2LdsRot + x * kLl2RotBytes;
         rot[x].acc = (uint32_t*)base;                                        // [j][N]
         rot[x].sum = (double*)(base + 2 * kN * 4);                           // [out][h][c][lane], then [out][h][e]
-        rot[x].dig = (uint2*)(base + 2 * kN * 4 + 2 * kN * 8);               // [row][h][lane]
-        rot[x].abar = (uint16_t*)(base + 2 * kN * 4 + 2 * kN * 8 + kBkRows * 2 * 64 * 8);
+        rot[x].dig = (uint32_t*)(base + 2 * kN * 4 + 2 * kN * 8);            // [m][e]: the decomposed word of coefficient e of component m
+        rot[x].abar = (uint16_t*)(base + 2 * kN * 4 + 2 * kN * 8 + kLlDigBytes);
         rot[x].bbar = (uint32_t*)((char*)rot[x].abar + kAbarBytes);
         const int g = 2 * (int)blockIdx.x + x;
         gidx[x] = g < count ? g : count - 1;             // an odd launch computes its last rotation twice (second copy: no output)
@@ -405,9 +383,12 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
 
     // row waves: digits -> first stage -> forward half transform -> products into the sums of rotation r
     auto row_phase = [&](const Rot& r) {
-        const uint2 q0 = r.dig[(row * 2 + 0) * 64 + lane], q1 = r.dig[(row * 2 + 1) * 64 + lane];
+        const uint32_t* dgp = r.dig + (row / kL) * kN + lane;
+        uint32_t w0[8], w1[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { w0[k] = dgp[k * 64]; w1[k] = dgp[kH + k * 64]; }
         double x[kRegs8];
-        ll_split_first_stages(x, q0, q1, h);
+        ll_split_first_stages_words(x, w0, w1, h, 32u - (uint32_t)(row % kL + 1) * kBgbit);
         ntt512_forward_pinned_from1(x, ctx, tu, twb, twc);
         double* s0 = r.sum + h * kH + lane;
 #pragma unroll
@@ -489,22 +470,13 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
         uint32_t rv[kRegs8];
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) rv[k] = accj[(lane + 64 * k + h * kH - alo) & (kN - 1)];
-        uint32_t lo[kL], hi[kL];
-#pragma unroll
-        for (int dg = 0; dg < kL; dg++) { lo[dg] = 0; hi[dg] = 0; }
+        // the decomposed word itself, one lane-contiguous dword per coefficient: the row waves take their digit field out of it
+        uint32_t* dgo = r.dig + out * kN + h * kH + lane;
 #pragma unroll
         for (int k = 0; k < kRegs8; k++) {
             const bool neg = (lane + 64 * k + h * kH < alo) != ahi;
-            const uint32_t t = ((neg ? 0u - rv[k] : rv[k]) - wnew[k] + decomp_offset()) ^ decomp_signmask();
-#pragma unroll
-            for (int dg = 0; dg < kL; dg++) {
-                const uint32_t bb = (uint32_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit) & 0xffu;
-                if (k < 4) lo[dg] |= bb << (8 * k);
-                else hi[dg] |= bb << (8 * (k - 4));
-            }
+            dgo[64 * k] = ((neg ? 0u - rv[k] : rv[k]) - wnew[k] + decomp_offset()) ^ decomp_signmask();
         }
-#pragma unroll
-        for (int dg = 0; dg < kL; dg++) r.dig[((out * kL + dg) * 2 + h) * 64 + lane] = make_uint2(lo[dg], hi[dg]);
     };
     // one serial chain per slot: the inverse waves go first whenever they can issue (without it the chain, behind
     // three row waves per SIMD, sets the length of the slot: 5.9 ms per 2 rotations against 4.8)
@@ -521,14 +493,10 @@ __global__ __launch_bounds__(kLlThreads) void blind_rotate_ll2_kernel(
             const int alo = (int)(abar & (kN - 1));
             const bool neg = (ecoef < alo) != ((abar >> kNbit) != 0);
             const int ridx = (ecoef - alo) & (kN - 1);
-            uint8_t* dst = (uint8_t*)rot[x].dig + (hh * 64 + lane) * 8 + rr;
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const uint32_t rv = rot[x].acc[m * kN + ridx];
-                const uint32_t t = ((neg ? 0u - rv : rv) - w[m] + decomp_offset()) ^ decomp_signmask();
-#pragma unroll
-                for (int dg = 0; dg < kL; dg++)
-                    dst[(m * kL + dg) * (2 * 64 * 8)] = (uint8_t)__builtin_amdgcn_sbfe(t, 32u - (dg + 1) * kBgbit, (uint32_t)kBgbit);
+                rot[x].dig[m * kN + ecoef] = ((neg ? 0u - rv : rv) - w[m] + decomp_offset()) ^ decomp_signmask();
             }
         }
     }
