@@ -13,7 +13,7 @@ convolution in 64-bit integers (no transform, no prime, no floating point), writ
   sample extract at index 0           src/bootstrap_gpu.cu:366-381
   key switch                          include/keyswitch_gpu.cuh:13-23 (iksoffsetgen), :83-134 (KeySwitchFromTLWE)
 
-It writes tests/golden/golden_independent_v4.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
+It writes tests/golden/golden_independent_v5.json: on the BASELINE set (n = 630, N = 1024) all ten two-input gates, MUX and
 NMUX on level-0 ciphertexts (blind rotate, then key switch), NAND on level-1 ciphertexts (the other order:
 IdentityKeySwitchPreAdd, then __BlindRotate__; src/bootstrap_gpu.cu:383-400, include/keyswitch_gpu.cuh:136-188), and one
 NAND through the N = 2048 / 64-bit ring (the reference's templates instantiated at lvl02 / lvl20, as DESIGN.md 5a
@@ -23,7 +23,12 @@ kernels, tests/test_gpu_parity.py): runs of abar = 0 (include/gatebootstrapping_
 bare offset), bbar = 2N / N / 1 (:29-52, the three branches of the test vector), input words 0x7FFFFFFF, a key whose first two CMux
 steps are all 0x80000000 and whose other words are drawn from {0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001} (the external
 product's sums closest to the exactness bound), MUX on level-1 ciphertexts (src/bootstrap_gpu.cu:706-743: two key switches, two
-blind rotations, the sum of the two EXTRACTED ciphertexts) and Not / Copy (:681-703).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
+blind rotations, the sum of the two EXTRACTED ciphertexts) and Not / Copy (:681-703).  Since v5 the TRLWE-level primitives of
+src/cufhe_gates_gpu.cu:69-146 on the BASELINE set: CMUXNTT (src/bootstrap_gpu.cu:160-285: decomposition of c1 - c0, external product
+with a TRGSW of arbitrary words, + c0), the bootstrap to a TRLWE without sample extract (__BlindRotateGlobal__, :317-323), sample
+extract + key switch (__SEIandKS__, src/keyswitch_gpu.cu:26-40) and Refresh (:325-364: sample extract, key switch, blind rotation
+with the test vector taken from the key-switched ciphertext -- the reference reads an uninitialised buffer there; the
+oracle and the kernels define it this way).  Keys are uniform random words from a seeded numpy generator (the path is data-independent: any
 key words define a word-level check); the fixture stores the seeds, a sha256 of each generated key, the inputs and the
 expected output words.  Takes a few minutes; run in the build container only:  python tests/golden/make_golden_independent.py
 """
@@ -209,6 +214,42 @@ def key_for(seed, R):
     return bk, ksk, {"seed": seed, "bk_sha256": hashlib.sha256(bk.tobytes()).hexdigest(), "ksk_sha256": hashlib.sha256(ksk.tobytes()).hexdigest()}
 
 
+def digits_of(vals, R):
+    """gadget digits of a polynomial of torus words (TRLWESubAndDecomposition, src/bootstrap_gpu.cu:162-195): list over d of int64 arrays"""
+    offset = sum((1 << (R.Bgbit - 1)) << (R.bits - i * R.Bgbit) for i in range(1, R.l + 1))
+    roundoffset = 1 << (R.bits - R.l * R.Bgbit - 1)
+    digs = [np.zeros(R.N, np.int64) for _ in range(R.l)]
+    for i in range(R.N):
+        temp = (int(vals[i]) + offset + roundoffset) & R.mask
+        for d in range(R.l):
+            digs[d][i] = ((temp >> (R.bits - (d + 1) * R.Bgbit)) & ((1 << R.Bgbit) - 1)) - (1 << (R.Bgbit - 1))
+    return digs
+
+
+def cmux(trgsw, c1, c0, R):
+    """__CMUXNTT__ (src/bootstrap_gpu.cu:197-285): res = c0 + trgsw [x] (c1 - c0).  trgsw: uint32 [(k+1) l][k+1][N] torus words;
+    c1, c0: TRLWEs as [(k+1)][N] python ints"""
+    N, K1 = R.N, R.k + 1
+    rows = K1 * R.l
+    T = np.empty((N, rows * N), np.int64)
+    for j in range(K1):
+        diff = [(int(a) - int(b)) & R.mask for a, b in zip(c1[j], c0[j])]
+        for d, dig in enumerate(digits_of(diff, R)):
+            r = j * R.l + d
+            T[:, r * N:(r + 1) * N] = dig[R.conv_idx] * R.conv_sign
+    out = []
+    for o in range(K1):
+        s = T @ trgsw[:, o, :].reshape(rows * N).astype(np.int64)
+        out.append([(int(x) + int(v)) & R.mask for x, v in zip(c0[o], s)])
+    return out
+
+
+def refresh(trlwe, bk, ksk, R):
+    """Refresh (src/cufhe_gates_gpu.cu:106-124, __SEIandBootstrap2TRLWE__ src/bootstrap_gpu.cu:325-364): sample extract at 0, key
+    switch to lvl0, blind rotation with the test vector mu rotated by the KEY-SWITCHED ciphertext's b, no sample extract"""
+    return blind_rotate(keyswitch(sample_extract0(trlwe, R), ksk, R), bk, R)
+
+
 def gate_mux_level1(inc, in1, in0, bk, ksk, R):
     """__MuxBootstrap__<iksP, brP, mu> on level-1 ciphertexts (src/bootstrap_gpu.cu:706-743): key switch of inc + in1 - mu, blind
     rotation, sample extract; the same for -inc + in0 - mu; the two extracted ciphertexts added, mu added to b"""
@@ -263,7 +304,7 @@ def edge_inputs(irng):
 
 
 def main():
-    out = {"format": 4, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
+    out = {"format": 5, "generator": "tests/golden/make_golden_independent.py (schoolbook, no code shared with oracle/)", "cases": []}
     t0 = time.time()
     irng = np.random.default_rng(777)
     ins0 = [random_words(irng, 631) for _ in range(3)]
@@ -308,6 +349,25 @@ def main():
                          "expected": [(-int(v)) & 0xFFFFFFFF for v in ins0[2]]})
     out["cases"].append({"set": "default", "level": 1, "op": "COPY", "key": key1, "inputs": "level1", "operands": [1],
                          "expected": [int(v) for v in ins1[1]]})
+    # --- TRLWE-level primitives (BASELINE set): operands are TRLWEs [(k+1) N] / a TRGSW [(k+1) l][k+1][N] of uniform words
+    trl = [random_words(irng, 2 * 1024) for _ in range(2)]
+    trgsw = random_words(irng, 6 * 2 * 1024)
+    out["inputs"]["trlwe"] = [x.tolist() for x in trl]
+    out["inputs"]["trgsw"] = [trgsw.tolist()]
+    as_trlwe = lambda x: [[int(v) for v in x[:1024]], [int(v) for v in x[1024:]]]
+    flat = lambda t: [int(v) for comp in t for v in comp]
+    print("CMUXNTT", flush=True)
+    out["cases"].append({"set": "default", "level": 2, "op": "CMUXNTT", "key": key1, "inputs": "trlwe", "operands": [0, 1],
+                         "expected": flat(cmux(trgsw.reshape(6, 2, 1024), as_trlwe(trl[0]), as_trlwe(trl[1]), LVL1))})
+    print("BOOT2TRLWE (lvl0 TLWE -> TRLWE)", flush=True)
+    out["cases"].append({"set": "default", "level": 2, "op": "BOOT2TRLWE", "key": key1, "inputs": "level0", "operands": [2],
+                         "expected": flat(blind_rotate([int(v) for v in ins0[2]], bk, LVL1))})
+    print("SEIKS (TRLWE -> lvl0 TLWE)", flush=True)
+    out["cases"].append({"set": "default", "level": 2, "op": "SEIKS", "key": key1, "inputs": "trlwe", "operands": [0],
+                         "expected": keyswitch(sample_extract0(as_trlwe(trl[0]), LVL1), ksk, LVL1)})
+    print("REFRESH (TRLWE -> TRLWE)", flush=True)
+    out["cases"].append({"set": "default", "level": 2, "op": "REFRESH", "key": key1, "inputs": "trlwe", "operands": [1],
+                         "expected": flat(refresh(as_trlwe(trl[1]), bk, ksk, LVL1))})
     bkx, kskx, keyx = key_extreme(20261008, LVL1)
     print("NAND, default set, level 0, extreme key words", flush=True)
     out["cases"].append({"set": "default", "level": 0, "op": "NAND", "key": keyx, "inputs": "level0", "operands": [0, 1],
@@ -338,7 +398,7 @@ def main():
     out["cases"].append({"set": "lvl2", "level": 0, "op": "NAND", "key": key2, "inputs": "level0", "operands": [0, 1],
                          "expected": gate2("NAND", ins0[0], ins0[1], bk2, ksk2, LVL2)})
     out["seconds"] = round(time.time() - t0, 1)
-    dst = os.path.join(HERE, "golden_independent_v4.json")
+    dst = os.path.join(HERE, "golden_independent_v5.json")
     json.dump(out, open(dst, "w"))
     print("wrote", dst, out["seconds"], "s")
 

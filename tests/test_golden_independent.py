@@ -1,12 +1,13 @@
 """Words of full-size gates against a fixture that shares no code with the oracle or the kernels.
 
-tests/golden/golden_independent_v4.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
+tests/golden/golden_independent_v5.json is written by tests/golden/make_golden_independent.py: pure numpy / Python
 integers, the external product as an exact schoolbook negacyclic convolution (no transform), restated from the
 reference's text.  Both the C oracle (CPU test) and the HIP path (GPU test) must reproduce its words: all ten two-input
 gates, MUX and NMUX on level-0 ciphertexts and NAND on level-1 ciphertexts of the BASELINE set, one NAND through the
 N = 2048 ring, and a few gates on each of the other compiled parameter sets (k = 2 / N = 512; n = 500 / l = 2 / Bg = 2^10); since v4 also
 the corner inputs the oracle tests use (runs of abar = 0, bbar = 2N / N / 1, words 0x7FFFFFFF, a key of extreme words), MUX on level-1
-ciphertexts and Not / Copy.  Keys are regenerated from the fixture's seeds and checked
+ciphertexts and Not / Copy; since v5 the TRLWE-level primitives (CMUXNTT, bootstrap to a TRLWE, sample extract + key switch, Refresh).
+Keys are regenerated from the fixture's seeds and checked
 against its sha256 sums -- a mismatch there is a failure, not a skip."""
 import hashlib
 import json
@@ -17,7 +18,7 @@ import pytest
 
 import oracle_lib as ol
 
-FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v4.json")
+FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v5.json")
 OPS = {n: i for i, n in enumerate(ol.OPS)}
 
 
@@ -71,11 +72,12 @@ def test_fixture_is_what_the_generator_describes():
     assert got == [("default", 0, op) for op in ol.OPS[:12]] + [("default", 1, "NAND"),
                                                                 ("default", 0, "NAND"), ("default", 0, "AND"), ("default", 0, "OR"),      # corner inputs
                                                                 ("default", 1, "MUX"), ("default", 0, "NOT"), ("default", 1, "COPY"),
+                                                                ("default", 2, "CMUXNTT"), ("default", 2, "BOOT2TRLWE"), ("default", 2, "SEIKS"), ("default", 2, "REFRESH"),
                                                                 ("default", 0, "NAND"),                                                   # extreme key words
                                                                 ("k2n512", 0, "NAND"), ("k2n512", 0, "XOR"),
                                                                 ("k2n512", 0, "MUX"), ("k2n512", 1, "NAND"), ("cggi16", 0, "NAND"), ("cggi16", 0, "ORYN"),
                                                                 ("cggi16", 1, "XOR"), ("lvl2", 0, "NAND")]
-    assert [c["inputs"] for c in fx["cases"][13:16]] == ["level0_edge_a", "level0_edge_b", "level0_edge_c"] and fx["cases"][19]["key"]["kind"] == "extreme"
+    assert [c["inputs"] for c in fx["cases"][13:16]] == ["level0_edge_a", "level0_edge_b", "level0_edge_c"] and fx["cases"][23]["key"]["kind"] == "extreme"
     # the corner inputs sit where the generator says (the reference's modswitch, include/gatebootstrapping_gpu.cuh:10-16, on python integers)
     e = {t: [np.array(x, np.uint32).astype(np.int64) for x in fx["inputs"]["level0_edge_" + t]] for t in "abc"}
     ms = lambda v: (int(v) & 0xFFFFFFFF) >> 21
@@ -87,6 +89,9 @@ def test_fixture_is_what_the_generator_describes():
     assert all(ms(cc[i] + (1 << 20)) == 0 for i in range(4)) and 2048 - ms(cc[630] + (1 << 29)) == 1
     for c in fx["cases"]:
         n, N, k = SETS[c["set"]][:3]
+        if c["level"] == 2:          # TRLWE-level primitives: a TRLWE out, except sample extract + key switch
+            assert len(c["expected"]) == (n + 1 if c["op"] == "SEIKS" else (k + 1) * N)
+            continue
         assert len(c["expected"]) == (k * N + 1 if c["level"] else n + 1)
     src = open(os.path.join(ol.ROOT, "tests", "golden", "make_golden_independent.py")).read()
     assert "import oracle" not in src and "cufhe_amd" not in src.split('"""')[2], "the generator must not share code with the oracle or the product"
@@ -96,6 +101,19 @@ def test_oracle_words_match_independent_generator(oracle):
     for case, ins, want in cases():
         bk, ksk = keys_for(case)
         got = np.zeros(want.size, np.uint32)
+        if case["level"] == 2:       # TRLWE-level primitives (oracle/tfhe_oracle.h)
+            ek = oracle.orc_evalkey_create(bk, ksk)
+            if case["op"] == "CMUXNTT":
+                oracle.orc_cmux(got, np.array(fixture()["inputs"]["trgsw"][0], np.uint32), ins[0], ins[1])
+            elif case["op"] == "BOOT2TRLWE":
+                oracle.orc_blind_rotate(ek, got, ins[0], -1)
+            elif case["op"] == "SEIKS":
+                oracle.orc_sample_extract_keyswitch(ek, got, ins[0])
+            else:
+                oracle.orc_refresh(ek, got, ins[0])
+            oracle.orc_evalkey_destroy(ek)
+            assert np.array_equal(got, want), f"oracle words differ from the independent generator: {case['op']}"
+            continue
         op = np.array([OPS[case["op"]]], np.int32)
         third = ins[2].ctypes.data if len(ins) > 2 else None
         second = ins[1].ctypes.data if len(ins) > 1 else None
@@ -136,6 +154,22 @@ for case, ins, want in tg.cases():
         loaded = (name, case["key"]["seed"])
     d = [api.DeviceBuffer(x.size).upload(x) for x in ins]
     out = api.DeviceBuffer(want.size)
+    if case["level"] == 2:           # TRLWE-level primitives through the device-pointer batch entries
+        if case["op"] == "CMUXNTT":
+            trgsw_words = np.array(tg.fixture()["inputs"]["trgsw"][0], np.uint32)
+            dtg = api.DeviceBuffer(trgsw_words.size).upload(trgsw_words)
+            dntt = api.DeviceBuffer(2 * trgsw_words.size)        # NTT-domain doubles: two words each
+            api.trgsw_to_ntt_batch(dtg, dntt, 1)
+            api.cmux_batch(dntt, d[0], d[1], out, 1)
+        elif case["op"] == "BOOT2TRLWE":
+            api.blind_rotate_batch(d[0], out, 1)
+        elif case["op"] == "SEIKS":
+            api.sample_extract_keyswitch_batch(d[0], out, 1)
+        else:
+            api.refresh_batch(d[0], out, 1)
+        eng.Synchronize()
+        assert np.array_equal(out.download(), want), f"HIP words differ from the independent generator: {case['op']}"
+        continue
     second = d[1] if len(d) > 1 else None
     third = d[2] if len(d) > 2 else None
     op = tg.OPS[case["op"]]
