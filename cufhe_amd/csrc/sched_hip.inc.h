@@ -419,14 +419,19 @@ int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cu
  * buffer, a following CMUXNTT does not take an older upload for current. */
 int cufhe_amd_trgsw_to_ntt(int device, void* stream, const uint32_t* trgsw_host, cufhe_amd_ctxt* out)
 {
-    std::lock_guard<std::mutex> lk(g_sched_mu);
-    if (int rc = check_device(device)) return rc;
-    if (!trgsw_host || !out) return fail(-1, "null pointer");
-    sched::Scheduler* S = scheduler();
-    if (int rc = sched_check_ctxt(S, out)) return rc;
-    if (out->level != 3) return fail(-1, "TRGSW2NTT needs a TRGSW holder (ciphertext handle of level 3)");
-    if (int rc = S->before_direct_host_write(out)) return fail(rc, "scheduler: flushing a device ahead of TRGSW2NTT failed");
+    sched::Scheduler* S;
+    {
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        if (int rc = check_device(device)) return rc;
+        if (!trgsw_host || !out) return fail(-1, "null pointer");
+        S = scheduler();
+        if (int rc = sched_check_ctxt(S, out)) return rc;
+        if (out->level != 3) return fail(-1, "TRGSW2NTT needs a TRGSW holder (ciphertext handle of level 3)");
+        if (int rc = S->before_direct_host_write(out)) return fail(rc, "scheduler: flushing a device ahead of TRGSW2NTT failed");
+    }
+    // the conversion takes the library's own lock (ensure_ntt): not under the scheduler's (SetGPUNum nests them the other way round)
     if (int rc = cufhe_amd_trgsw_to_ntt_host(device, stream, trgsw_host, reinterpret_cast<double*>(out->host))) return rc;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
     if (int rc = S->dev(device).record_copy(stream, out, true)) return sched_error(S->dev(device), rc);
     return 0;
 }
