@@ -330,6 +330,8 @@ def ordered_line(res):
         "adder_netlist_gates_per_s": val(api_blk.get("depth_first_netlist"), "gates_per_s"),
         "adder_netlist_without_renaming_gates_per_s": val(api_blk.get("depth_first_netlist_without_renaming"), "gates_per_s"),
         "api_reference_style_latency_ms_per_gate": val(api_blk.get("reference_style"), "latency_ms_per_gate"),
+        "api_single_nand_ms": val(api_blk, "single_nand_call_to_synchronize_ms"),
+        "api_chain16_ms_per_gate": val(api_blk, "chain_of_16_dependent_nand_ms_per_gate"),
         "param_sets_per_s": {k: val(v) for k, v in (ex.get("param_sets") or {}).items()} or None,
         "all_word_checks_pass": None,
     }
@@ -658,6 +660,15 @@ def main():
                     res["api_pcie_inclusive"]["depth_first_netlist_without_renaming"] = lines[2]
                 if len(lines) > 3:
                     res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = lines[3]
+                # one cufhe::Nand on host ciphertexts, call -> Synchronize, and a chain of 16 dependent ones (tools/api_latency.cpp): the
+                # ms/gate a user of the reference's API sees (test/test_api_gpu.cu:140-159 is the chained pattern)
+                lat = subprocess.run([os.path.join(ROOT, "tools", "api_latency")], capture_output=True, text=True, timeout=120,
+                                     env=dict(os.environ, HIP_VISIBLE_DEVICES=str(DEV)) if WORLD > 1 else None)
+                ones = [float(l.split("call + Synchronize")[1].split("ms")[0]) for l in lat.stdout.splitlines() if l.startswith("one Nand")]
+                chains = [float(l.split("=")[1].split("ms")[0]) for l in lat.stdout.splitlines() if l.startswith("chain of 16")]
+                if ones and chains:
+                    res["api_pcie_inclusive"]["single_nand_call_to_synchronize_ms"] = min(ones)
+                    res["api_pcie_inclusive"]["chain_of_16_dependent_nand_ms_per_gate"] = min(chains)
             except Exception as e:      # the figure is auxiliary: never lose the headline line to it
                 res["api_pcie_inclusive"] = {"error": repr(e)}
 
