@@ -228,8 +228,8 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * the numbers below are MI355X's 256 CUs).  A launch is cut into whole
  * rounds of the batch kernel's grid (2048 rotations: two per SIMD, highest throughput) plus a tail, and the
  * tail -- or a whole small launch -- takes the cheapest kernel by measured cost: up to 256 rotations (one per CU) the 16-wave
- * workgroup-per-rotation kernel with split transforms (lowest latency: 2.9 ms for up to 64, 3.3 for 256); up to
- * 1536 rounds of 512 on its two-rotations-per-workgroup form (5.3 ms each) plus a last round of up to 256 on the
+ * workgroup-per-rotation kernel with split transforms (lowest latency: 2.8 ms for one, 2.9 for 64, 3.3 for 256); up to
+ * 1536 rounds of 512 on its two-rotations-per-workgroup form (5.2 ms each) plus a last round of up to 256 on the
  * single form; above that a full round (20.7 ms).  "ll2_threshold" (default -1 = by cost; 0 = never; n = for every
  * launch up to n) governs the paired form; "ll_threshold" / "half_threshold" (default -1 = by cost) force the single
  * form / the batch kernel with one rotation per SIMD up to the given count, "tail_split" 0 launches everything above
