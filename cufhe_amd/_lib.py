@@ -43,7 +43,7 @@ class Profile(ctypes.Structure):
 class PsParams(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32)] + \
                [(k, ctypes.c_uint32) for k in ("n", "N", "nbit", "k", "l", "Bgbit", "t", "basebit", "key_limbs",
-                                               "key_limb_bits", "mu", "lvl0_words", "lvl1_words")] + \
+                                               "key_limb_bits", "mu", "lvl0_words", "lvl1_words", "small_ntt_modulus")] + \
                [(k, ctypes.c_uint64) for k in ("bk_words", "ksk_words", "bk_ntt_bytes")]
 
 

@@ -38,16 +38,63 @@ namespace cufhe_amd {
 struct PsDefault {      // BASELINE.json: n = 630, N = 1024, k = 1
     static constexpr const char* name = "default";
     static constexpr int n = 630, Nbit = 10, k = 1, l = 3, Bgbit = 6, t = 8, basebit = 2, limbs = 1, limb_bits = 32;
+    static constexpr bool small_modulus = false;
 };
 struct PsK2N512 {       // k = 2 over the N = 512 ring (the shape -DUSE_CONCRETE builds in the reference)
     static constexpr const char* name = "k2n512";
     static constexpr int n = 630, Nbit = 9, k = 2, l = 3, Bgbit = 6, t = 8, basebit = 2, limbs = 1, limb_bits = 32;
+    static constexpr bool small_modulus = false;
 };
 struct PsCggi16 {       // the original TFHE 80-bit set (-DUSE_80BIT_SECURITY): l = 2, Bg = 2^10 -> two 16-bit key limbs
     static constexpr const char* name = "cggi16";
     static constexpr int n = 500, Nbit = 10, k = 1, l = 2, Bgbit = 10, t = 8, basebit = 2, limbs = 2, limb_bits = 16;
+    static constexpr bool small_modulus = false;
 };
-constexpr int kParamSets = 3;
+// The BASELINE numbers computed the way -DUSE_SMALL_NTT_MODULUS builds the reference (CMakeLists.txt:12,26-28;
+// include/ntt_gpu/ntt_small_modulus.cuh): the external product is taken modulo P = 625 * 2^20 + 1 on a bootstrapping key whose
+// torus words were switched to the P discretisation (round(a P / 2^32), src/bootstrap_gpu.cu:50-66), and every CMux increment is
+// switched back (round(r 2^32 / P), include/gatebootstrapping_gpu.cuh:236-248).  Approximate by design -- the results are NOT the
+// exact path's -- but deterministic integer arithmetic: the oracle compiled with -DORC_SET_SMALLMOD restates it and the words agree.
+// Here the product mod P is the exact integer product reduced mod P: the switched key is centred (|w| <= P/2 < 2^29), the digits
+// are the same, so the integer sums stay below (k+1) l N (Bg/2) P/2 < 2^46 and the FP64 field of fpfield.h holds them exactly --
+// the transforms, key layout and launch shapes are those of `default`; only the key's preparation and the lift change.
+struct PsSmallMod {
+    static constexpr const char* name = "smallmod";
+    static constexpr int n = 630, Nbit = 10, k = 1, l = 3, Bgbit = 6, t = 8, basebit = 2, limbs = 1, limb_bits = 32;
+    static constexpr bool small_modulus = true;
+};
+constexpr int kParamSets = 4;
+
+// include/ntt_gpu/ntt_small_modulus.cuh:36-68 (constants), :147-177 (the two modulus switches)
+namespace smallmod {
+constexpr uint32_t P = (625u << 20) + 1;                      // 655360001
+constexpr uint64_t INV_MODSWITCH_MUL = (1ull << 63) / P;
+// torus32_to_ntt_mod, centred: the representative of round(a P / 2^32) in (-P/2, P/2]
+__host__ __device__ inline int32_t from_torus_centred(uint32_t a)
+{
+    const uint32_t m = (uint32_t)(((uint64_t)a * P + (1ull << 31)) >> 32);       // in [0, P]
+    return m > P / 2 ? (int32_t)(m - P) : (int32_t)m;
+}
+// ntt_mod_to_torus32 of the residue r in [0, P)
+__host__ __device__ inline uint32_t to_torus(uint32_t r) { return (uint32_t)(((uint64_t)r * INV_MODSWITCH_MUL + (1ull << 30)) >> 31); }
+// a: any representative (|a| < 2^53) mod p of an exact integer sum S, |S| < p/2  ->  to_torus(S mod P)
+__device__ __forceinline__ uint32_t lift(double a)
+{
+    const double c = fpf::reduce(a);                                   // S itself
+    const double q = __builtin_rint(c * (1.0 / (double)P));
+    double r = __builtin_fma(-q, (double)P, c);                        // exact: |q P| < 2^50, |r| <= P/2 + 1
+    r = r < 0.0 ? r + (double)P : r;                                   // the residue in [0, P)
+    return to_torus((uint32_t)(int32_t)r);
+}
+}  // namespace smallmod
+
+// the limb's exact sum -> torus increment: mod 2^32 (the exact path) or switched back from the P discretisation
+template <class PS>
+__device__ __forceinline__ uint32_t ps_lift(double a)
+{
+    if constexpr (PS::small_modulus) return smallmod::lift(a);
+    else return fpf::lift_u32(a);
+}
 
 template <class PS>
 struct PsDims {
@@ -71,6 +118,7 @@ struct PsDims {
     static_assert(ROWS * fpf::after_mulmod(0.5001) < fpf::LIM_WIDE, "row sums exceed 2^53");
     static_assert(PS::l * PS::Bgbit <= 31 && PS::t * PS::basebit <= 32 && PS::Bgbit <= 10, "decomposition out of range");
     static_assert(PS::Nbit == 9 || PS::Nbit == 10, "ring sizes: 512 and 1024");
+    static_assert(!PS::small_modulus || PS::limbs == 1, "the small-modulus product is one exact product of the switched key");
     static_assert(PS::n <= 640, "abar list is sized for n <= 640");
 };
 
@@ -218,7 +266,7 @@ __global__ __launch_bounds__(kNttThreads) void bk_to_ntt_ps_kernel(
     double x[PO::R];
 #pragma unroll
     for (int r = 0; r < PO::R; r++) {
-        int64_t s = (int32_t)bk[poly * D::N + lane + 64 * r];
+        int64_t s = PS::small_modulus ? smallmod::from_torus_centred(bk[poly * D::N + lane + 64 * r]) : (int32_t)bk[poly * D::N + lane + 64 * r];
         if (PS::limbs > 1) {      // balanced limbs: s = sum_i limb_i 2^(i limb_bits), the top limb takes the rest
             int64_t v = 0;
             for (int m = 0; m <= limb; m++) {
@@ -339,7 +387,7 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
             uint32_t* acck = accL + out * N + lane;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t v = fpf::lift_u32(A[r]) << shl;       // the limb's exact sum, shifted, mod 2^32
+                const uint32_t v = ps_lift<PS>(A[r]) << shl;         // the limb's exact sum, shifted, mod 2^32
                 if (PS::limbs == 1) acck[64 * r] += v;
                 else __hip_atomic_fetch_add(acck + 64 * r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -582,7 +630,7 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
                 PO::inverse(A[o], ctx);
                 uint32_t v[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) v[r] = fpf::lift_u32(A[o][r]);       // the limb's exact sum mod 2^32
+                for (int r = 0; r < R; r++) v[r] = ps_lift<PS>(A[o][r]);         // the limb's exact sum mod 2^32
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (PS::limbs == 1) {

@@ -69,6 +69,7 @@ int ps_dispatch(int set, F f)
         case 0: return f(PsDefault{});
         case 1: return f(PsK2N512{});
         case 2: return f(PsCggi16{});
+        case 3: return f(PsSmallMod{});
     }
     return fail(-1, "unknown parameter set");
 }
@@ -243,6 +244,7 @@ int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* p)
         p->lvl0_words = D::lvl0_words; p->lvl1_words = D::lvl1_words;
         p->bk_words = D::bk_words; p->ksk_words = D::ksk_words;
         p->bk_ntt_bytes = (uint64_t)PS::n * D::bk_ntt_step_doubles * sizeof(double);
+        p->small_ntt_modulus = PS::small_modulus ? smallmod::P : 0u;
         return 0;
     });
 }

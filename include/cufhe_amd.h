@@ -311,13 +311,17 @@ int cufhe_amd_lvl2_keyswitch_batch(int device, void* stream, size_t count, const
  * Every set of cufhe_amd/csrc/kernels_ps.hip.h is compiled in and chosen by index: 0 = the default set (the same
  * numbers as cufhe_amd_get_params, computed by the generic kernels), 1 = "k2n512" (k = 2 over the N = 512 ring),
  * 2 = "cggi16" (the original TFHE 80-bit set; its external product exceeds the exact range of the FP64 field, so
- * the key is taken in two 16-bit limbs).  The numeric parameters of TFHEpp's headers are not in the reference tree
+ * the key is taken in two 16-bit limbs), 3 = "smallmod" (the default numbers through the reference's optional small NTT modulus,
+ * CMakeLists.txt:12 -DUSE_SMALL_NTT_MODULUS, include/ntt_gpu/ntt_small_modulus.cuh: the bootstrapping key and every CMux increment are
+ * switched between the 2^32 and the P = 625 * 2^20 + 1 discretisation of the torus -- approximate by design, word-for-word the
+ * reference's arithmetic).  The numeric parameters of TFHEpp's headers are not in the reference tree
  * (SURVEY.md F3): a set is what cufhe_amd_ps_get_params reports.  Gates take and return ciphertexts of the set at
  * either level (n + 1 or k N + 1 words), keys use TFHEpp's layouts with the set's dimensions. */
 typedef struct cufhe_amd_ps_params {
     char name[32];
     uint32_t n, N, nbit, k, l, Bgbit, t, basebit, key_limbs, key_limb_bits, mu;
     uint32_t lvl0_words, lvl1_words;
+    uint32_t small_ntt_modulus;     /* 0: exact products; P: the set runs the reference's -DUSE_SMALL_NTT_MODULUS arithmetic mod P */
     uint64_t bk_words, ksk_words, bk_ntt_bytes;
 } cufhe_amd_ps_params;
 int cufhe_amd_ps_count(void);

@@ -32,6 +32,9 @@
 //   (none)                         the BASELINE set, hand-tuned kernels         n = 630, N = 1024, k = 1, l = 3, Bg = 2^6
 //   -DCUFHE_AMD_PARAM_SET_K2N512   set 1 of cufhe_amd_ps_get_params              n = 630, N = 512,  k = 2, l = 3, Bg = 2^6
 //   -DCUFHE_AMD_PARAM_SET_CGGI16   set 2, the original TFHE 80-bit set          n = 500, N = 1024, k = 1, l = 2, Bg = 2^10
+//   -DCUFHE_AMD_PARAM_SET_SMALLMOD or the reference's own -DUSE_SMALL_NTT_MODULUS (CMakeLists.txt:12,26-28)
+//                                  set 3: the BASELINE numbers through the small NTT modulus P = 625 * 2^20 + 1 with torus
+//                                  discretisation switching (include/ntt_gpu/ntt_small_modulus.cuh) -- approximate, as there
 // Initialize(bk, ..) then loads the keys into that set and switches the per-gate API onto it ("param_set"): Ctxt<lvl0param> has
 // n + 1 words of the set, Ctxt<lvl1param> k N + 1, And ... NMux run blind rotate -> key switch on the first and key switch ->
 // blind rotate on the second (src/bootstrap_gpu.cu:383-421).  The TRLWE-level operations and the N = 2048 ring stay with the
@@ -40,6 +43,8 @@
 #define CUFHE_AMD_PARAM_SET_INDEX 1
 #elif defined(CUFHE_AMD_PARAM_SET_CGGI16)
 #define CUFHE_AMD_PARAM_SET_INDEX 2
+#elif defined(CUFHE_AMD_PARAM_SET_SMALLMOD) || defined(USE_SMALL_NTT_MODULUS)
+#define CUFHE_AMD_PARAM_SET_INDEX 3
 #endif
 
 #ifdef CUFHE_AMD_USE_TFHEPP

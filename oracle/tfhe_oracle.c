@@ -67,6 +67,36 @@ static const double ALPHA1 = ORC_ALPHA1;
 /* ------------------------------------------------------------------ */
 /* Reference NTT prime arithmetic                                     */
 /* ------------------------------------------------------------------ */
+/* the small-modulus constants and switches, include/ntt_gpu/ntt_small_modulus.cuh:36-68,147-177 */
+#define SMALL_P 655360001u                                  /* :44  K * 2^SHIFTAMOUNT + 1, K = 625, SHIFTAMOUNT = 20 */
+#define SMALL_INV_MODSWITCH_MUL (((uint64_t)1 << 63) / SMALL_P)   /* :67 */
+uint32_t orc_smallmod_modulus(void) { return SMALL_P; }
+uint32_t orc_smallmod_from_torus(uint32_t torus_val)        /* torus32_to_ntt_mod :147-154 */
+{
+    uint64_t temp = (uint64_t)torus_val * SMALL_P + ((uint64_t)1 << 31);
+    return (uint32_t)(temp >> 32);
+}
+uint32_t orc_smallmod_to_torus(int32_t ntt_val)             /* ntt_mod_to_torus32 :166-177 */
+{
+    uint32_t a = (ntt_val < 0) ? (uint32_t)(ntt_val + (int32_t)SMALL_P) : (uint32_t)ntt_val;
+    uint64_t temp = (uint64_t)a * SMALL_INV_MODSWITCH_MUL;
+    temp = (temp + ((uint64_t)1 << 30)) >> 31;
+    return (uint32_t)temp;
+}
+
+#ifdef ORC_SMALL_NTT_MODULUS
+/* -DUSE_SMALL_NTT_MODULUS: the transforms of include/ntt_gpu/ntt_small_modulus.cuh:201-300 have the stage structure and
+ * table indexing of the 64-bit ones (the code below), over P with small_mod_mult / small_mod_add / small_mod_sub (:117-140);
+ * psi is found as src/ntt_gpu/ntt_small_modulus.cu:71-110 finds it */
+#define NTT_P ((uint64_t)SMALL_P)
+static uint64_t small_psi(void);
+#define NTT_PSI small_psi()
+uint64_t orc_ntt_modulus(void) { return NTT_P; }
+uint64_t orc_ntt_psi(void) { return NTT_PSI; }
+uint64_t orc_ntt_barrett_mu(void) { return ((uint64_t)1 << 60) / SMALL_P; }     /* BARRETT_MU :52 (unused by the live butterflies) */
+static inline uint64_t barrett_mult(uint64_t a, uint64_t b) { return (a * b) % NTT_P; }   /* small_mod_mult :137-140; a, b <= P */
+uint64_t orc_ntt_mulmod(uint64_t a, uint64_t b) { return barrett_mult(a, b); }
+#else
 #define NTT_P 1152921504606877697ull     /* include/ntt_gpu/ntt_gpuntt.cuh:36 */
 #define NTT_MU 9223372036854530040ull    /* :39  = floor(2^123 / p)           */
 #define NTT_BIT 61                       /* :40                               */
@@ -87,6 +117,7 @@ static inline uint64_t barrett_mult(uint64_t a, uint64_t b)
     return (r >= NTT_P) ? r - NTT_P : r;   /* r < 2p: checked against % in tests/test_oracle.py */
 }
 uint64_t orc_ntt_mulmod(uint64_t a, uint64_t b) { return barrett_mult(a, b); }
+#endif
 static inline uint64_t mod_add(uint64_t a, uint64_t b) /* :184-188 */
 {
     uint64_t s = a + b;
@@ -107,6 +138,16 @@ static uint64_t mod_pow(uint64_t a, uint64_t e)
     }
     return r;
 }
+#ifdef ORC_SMALL_NTT_MODULUS
+/* find_primitive_root, src/ntt_gpu/ntt_small_modulus.cu:71-110: the smallest g >= 3 that is neither a square nor a fifth power
+ * residue generates Z_P^* (P - 1 = 2^20 5^4); psi = g^((P-1)/2048), a primitive 2048-th root (psi^1024 = -1) */
+static uint64_t small_psi(void)
+{
+    uint64_t g = 3;
+    while (mod_pow(g, (NTT_P - 1) / 2) == 1 || mod_pow(g, (NTT_P - 1) / 5) == 1) g++;
+    return mod_pow(g, (NTT_P - 1) / 2048);
+}
+#endif
 static uint32_t bitrev(uint32_t x, int bits)
 {
     uint32_t r = 0;
@@ -195,7 +236,13 @@ static inline uint64_t ffp_from_i32(int32_t a)
 /* centred lift truncated to the torus: include/gatebootstrapping_gpu.cuh:258-281 */
 static inline uint32_t ffp_lift_u32(uint64_t v)
 {
+#ifdef ORC_SMALL_NTT_MODULUS
+    /* include/gatebootstrapping_gpu.cuh:236-248: centred, then switched back to the 2^32 discretisation */
+    const int32_t signed_val = (v > NTT_P / 2) ? (int32_t)((uint32_t)v - SMALL_P) : (int32_t)v;
+    return orc_smallmod_to_torus(signed_val);
+#else
     return (v > NTT_P / 2) ? (uint32_t)((int64_t)v - (int64_t)NTT_P) : (uint32_t)v;
+#endif
 }
 
 void orc_polymul_schoolbook(uint32_t* res, const int32_t* a, const uint32_t* b)
@@ -354,7 +401,11 @@ orc_evalkey* orc_evalkey_create(const uint32_t* bk, const uint32_t* ksk)
     for (long p = 0; p < polys; p++) {
         uint64_t* dst = ek->bkntt + (size_t)p * ORC_N;
         const uint32_t* src = bk + (size_t)p * ORC_N;
+#ifdef ORC_SMALL_NTT_MODULUS
+        for (int i = 0; i < ORC_N; i++) dst[i] = orc_smallmod_from_torus(src[i]);    /* __TRGSW2NTT__, src/bootstrap_gpu.cu:50-66 */
+#else
         for (int i = 0; i < ORC_N; i++) dst[i] = (uint64_t)src[i];
+#endif
         orc_ntt_forward(dst);
     }
     return ek;

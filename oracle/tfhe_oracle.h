@@ -41,6 +41,7 @@ extern "C" {
  *                      shape of src/bootstrap_gpu.cu:413-416 and include/ntt_gpu/ntt_gpuntt.cuh:283-329)
  *   -DORC_SET_CGGI16   n = 500, N = 1024, k = 1, l = 2, Bgbit = 10, t = 8, basebit = 2   (the original
  *                      TFHE 80-bit set, what -DUSE_80BIT_SECURITY selects)
+ *   -DORC_SET_SMALLMOD the default numbers through the reference's small-modulus NTT (-DUSE_SMALL_NTT_MODULUS)
  * The numeric parameters of TFHEpp's headers are not in the reference tree: these sets are
  * defined HERE, and parity for them means oracle == GPU on the same numbers. */
 #if defined(ORC_SET_K2N512)
@@ -65,6 +66,21 @@ extern "C" {
 #define ORC_BASEBIT 2
 #define ORC_ALPHA0 2.44e-5
 #define ORC_ALPHA1 3.73e-9
+#elif defined(ORC_SET_SMALLMOD)
+/* the BASELINE set computed the way -DUSE_SMALL_NTT_MODULUS builds the reference (CMakeLists.txt:12,26-28): NTT modulus
+ * P = 625 * 2^20 + 1, the bootstrapping key and every CMux increment switched between the 2^32 and the P discretisation of the
+ * torus (include/ntt_gpu/ntt_small_modulus.cuh).  Approximate by design; oracle == GPU word for word all the same. */
+#define ORC_SET_NAME "smallmod"
+#define ORC_SMALL_NTT_MODULUS 1
+#define ORC_n 630
+#define ORC_NBIT 10
+#define ORC_K 1
+#define ORC_L 3
+#define ORC_BGBIT 6
+#define ORC_T 8
+#define ORC_BASEBIT 2
+#define ORC_ALPHA0 (1.0 / 32768.0)
+#define ORC_ALPHA1 (1.0 / 33554432.0)
 #else
 #define ORC_SET_NAME "default"
 #define ORC_SET_DEFAULT 1
@@ -131,6 +147,10 @@ uint64_t orc_ntt_psi(void);
 uint64_t orc_ntt_barrett_mu(void);
 uint64_t orc_ntt_n_inverse(void);
 uint64_t orc_ntt_mulmod(uint64_t a, uint64_t b);   /* barrett_mult */
+/* the two modulus switches of include/ntt_gpu/ntt_small_modulus.cuh:147-177 (every build: plain integer formulas) */
+uint32_t orc_smallmod_from_torus(uint32_t torus);   /* torus32_to_ntt_mod: round(a P / 2^32), in [0, P] */
+uint32_t orc_smallmod_to_torus(int32_t centred);    /* ntt_mod_to_torus32: round(a 2^32 / P) */
+uint32_t orc_smallmod_modulus(void);
 
 /* ---- evaluation key in the NTT domain (opaque) ---- */
 typedef struct orc_evalkey orc_evalkey;

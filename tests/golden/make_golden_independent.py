@@ -48,9 +48,10 @@ MU0 = 1 << 29            # lvl0 / lvl1 message scale
 class Ring:
     """the target ring of a blind rotation and the key switch back to lvl0"""
 
-    def __init__(self, N, nbit, l, Bgbit, bits, mu, t, basebit, n=630, k=1):
+    def __init__(self, N, nbit, l, Bgbit, bits, mu, t, basebit, n=630, k=1, small_modulus=False):
         self.N, self.nbit, self.l, self.Bgbit, self.bits, self.mu, self.t, self.basebit = N, nbit, l, Bgbit, bits, mu, t, basebit
         self.n, self.k = n, k                            # lvl0 dimension; mask polynomials of the ring
+        self.small_modulus = small_modulus               # the reference built with -DUSE_SMALL_NTT_MODULUS (below)
         self.mask = (1 << bits) - 1
         i = np.arange(N)[:, None]
         m = np.arange(N)[None, :]
@@ -64,6 +65,24 @@ LVL2 = Ring(N=2048, nbit=11, l=4, Bgbit=9, bits=64, mu=1 << 61, t=7, basebit=2)
 # time, CMakeLists.txt:8-24; k > 1: src/bootstrap_gpu.cu:402-421, include/gatebootstrapping_gpu.cuh:153-224)
 K2N512 = Ring(N=512, nbit=9, l=3, Bgbit=6, bits=32, mu=1 << 29, t=8, basebit=2, n=630, k=2)
 CGGI16 = Ring(N=1024, nbit=10, l=2, Bgbit=10, bits=32, mu=1 << 29, t=8, basebit=2, n=500, k=1)
+# The BASELINE numbers as the reference computes them when built with -DUSE_SMALL_NTT_MODULUS (CMakeLists.txt:12,26-28): the
+# external product is taken modulo SMALL_P on a key switched to the P discretisation of the torus, and each CMux increment is
+# switched back (include/ntt_gpu/ntt_small_modulus.cuh:36-68,147-177; src/bootstrap_gpu.cu:50-66;
+# include/gatebootstrapping_gpu.cuh:133-137,185-193,236-248).  Arithmetic mod P is arithmetic mod P whatever computes it:
+# here the schoolbook sum in exact integers, reduced with Python's %.
+SMALLMOD = Ring(N=1024, nbit=10, l=3, Bgbit=6, bits=32, mu=1 << 29, t=8, basebit=2, small_modulus=True)
+SMALL_P = 625 * 2**20 + 1                        # small_ntt::P
+SMALL_INV_MODSWITCH_MUL = 2**63 // SMALL_P       # small_ntt::INV_MODSWITCH_MUL
+
+
+def torus32_to_ntt_mod(a):
+    """round(a P / 2^32) = (a P + 2^31) >> 32 on an array of torus words (int64 holds a P < 2^62)"""
+    return (a.astype(np.int64) * SMALL_P + (1 << 31)) >> 32
+
+
+def ntt_mod_to_torus32(r):
+    """round(r 2^32 / P) for the residue r in [0, P): (r * (2^63 / P) + 2^30) >> 31, truncated to 32 bits (python integers)"""
+    return ((r * SMALL_INV_MODSWITCH_MUL + (1 << 30)) >> 31) & 0xFFFFFFFF
 
 
 def modswitch(phase32, R):
@@ -116,7 +135,11 @@ def blind_rotate(c, bk, R):
                 T[:, r * N:(r + 1) * N] = dig[R.conv_idx] * R.conv_sign
         key = bk[i]                                          # [rows][k+1][N]
         for o in range(K1):
-            if R.bits == 32:
+            if R.small_modulus:
+                col = torus32_to_ntt_mod(key[:, o, :].reshape(rows * N))  # in [0, P]: |sum| < 6144 * 32 * 2^29.3 < 2^47
+                s = T @ col
+                add = [ntt_mod_to_torus32(int(v) % SMALL_P) for v in s]   # the sum mod P (python's % : in [0, P)), switched back
+            elif R.bits == 32:
                 col = key[:, o, :].reshape(rows * N).astype(np.int64)     # < 2^32: exact in int64, |sum| < 2^53
                 s = T @ col
                 add = [int(v) & R.mask for v in s]
@@ -403,5 +426,43 @@ def main():
     print("wrote", dst, out["seconds"], "s")
 
 
+def main_smallmod():
+    """tests/golden/golden_independent_smallmod_v1.json: the small-modulus mode, a fixture of its own (the cases above keep their
+    file and their words): NAND, XOR and MUX on level-0 ciphertexts, NAND on level-1 ciphertexts, NAND on the corner inputs `a`"""
+    out = {"format": 5, "generator": "tests/golden/make_golden_independent.py smallmod (schoolbook mod P, no code shared with oracle/)", "cases": []}
+    t0 = time.time()
+    irng = np.random.default_rng(778)
+    ins0 = [random_words(irng, 631) for _ in range(3)]
+    ins1 = [random_words(irng, 1025) for _ in range(2)]
+    edges = edge_inputs(irng)
+    out["inputs"] = {"level0": [x.tolist() for x in ins0], "level1": [x.tolist() for x in ins1], "level0_edge_a": [x.tolist() for x in edges[0]]}
+    # the switches at their corners (python integers against the array form)
+    probe = np.array([0, 1, 3, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFE, 0xFFFFFFFF], np.uint32)
+    assert [int(v) for v in torus32_to_ntt_mod(probe)] == [(int(a) * SMALL_P + 2**31) >> 32 for a in probe] and int(torus32_to_ntt_mod(probe)[-1]) == SMALL_P
+    assert ntt_mod_to_torus32(0) == 0 and ntt_mod_to_torus32(SMALL_P - 1) == 0xFFFFFFF9 and abs(ntt_mod_to_torus32(SMALL_P // 2) - 2**31) < 8
+    bk, ksk, key = key_for(20261009, SMALLMOD)
+    R = SMALLMOD
+    for op in ("NAND", "XOR"):
+        print(op, "smallmod, level 0", flush=True)
+        out["cases"].append({"set": "smallmod", "level": 0, "op": op, "key": key, "inputs": "level0", "operands": [0, 1],
+                             "expected": gate2(op, ins0[0], ins0[1], bk, ksk, R)})
+    print("MUX, smallmod, level 0", flush=True)
+    out["cases"].append({"set": "smallmod", "level": 0, "op": "MUX", "key": key, "inputs": "level0", "operands": [0, 1, 2],
+                         "expected": gate_mux(ins0[0], ins0[1], ins0[2], bk, ksk, R)})
+    print("NAND, smallmod, level 1", flush=True)
+    out["cases"].append({"set": "smallmod", "level": 1, "op": "NAND", "key": key, "inputs": "level1", "operands": [0, 1],
+                         "expected": gate2_level1("NAND", ins1[0], ins1[1], bk, ksk, R)})
+    print("NAND, smallmod, level 0, corner inputs a", flush=True)
+    out["cases"].append({"set": "smallmod", "level": 0, "op": "NAND", "key": key, "inputs": "level0_edge_a", "operands": [0, 1],
+                         "expected": gate2("NAND", edges[0][0], edges[0][1], bk, ksk, R)})
+    out["seconds"] = round(time.time() - t0, 1)
+    dst = os.path.join(HERE, "golden_independent_smallmod_v1.json")
+    json.dump(out, open(dst, "w"))
+    print("wrote", dst, out["seconds"], "s")
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["smallmod"]:
+        main_smallmod()
+    else:
+        main()

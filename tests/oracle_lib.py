@@ -31,7 +31,7 @@ def build():
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
 
 
-SETS = ("default", "k2n512", "cggi16")       # parameter sets the oracle is compiled for (oracle/tfhe_oracle.h)
+SETS = ("default", "k2n512", "cggi16", "smallmod")       # parameter sets the oracle is compiled for (oracle/tfhe_oracle.h)
 
 
 def load_set(name):

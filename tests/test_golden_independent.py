@@ -7,6 +7,9 @@ gates, MUX and NMUX on level-0 ciphertexts and NAND on level-1 ciphertexts of th
 N = 2048 ring, and a few gates on each of the other compiled parameter sets (k = 2 / N = 512; n = 500 / l = 2 / Bg = 2^10); since v4 also
 the corner inputs the oracle tests use (runs of abar = 0, bbar = 2N / N / 1, words 0x7FFFFFFF, a key of extreme words), MUX on level-1
 ciphertexts and Not / Copy; since v5 the TRLWE-level primitives (CMUXNTT, bootstrap to a TRLWE, sample extract + key switch, Refresh).
+tests/golden/golden_independent_smallmod_v1.json (the same script, argument `smallmod`) holds the small-modulus mode: the BASELINE
+numbers as the reference computes them when built with -DUSE_SMALL_NTT_MODULUS (include/ntt_gpu/ntt_small_modulus.cuh), the product
+mod P as a schoolbook sum in exact integers reduced with Python's %.
 Keys are regenerated from the fixture's seeds and checked
 against its sha256 sums -- a mismatch there is a failure, not a skip."""
 import hashlib
@@ -19,6 +22,7 @@ import pytest
 import oracle_lib as ol
 
 FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v5.json")
+FIXTURE_SMALLMOD = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_smallmod_v1.json")
 OPS = {n: i for i, n in enumerate(ol.OPS)}
 
 
@@ -32,7 +36,8 @@ _keys = {}
 
 
 # (n, N, k, l, bits, t) of the sets of the fixture: the draw sizes of the generator's key_for()
-SETS = {"default": (630, 1024, 1, 3, 32, 8), "lvl2": (630, 2048, 1, 4, 64, 7), "k2n512": (630, 512, 2, 3, 32, 8), "cggi16": (500, 1024, 1, 2, 32, 8)}
+SETS = {"default": (630, 1024, 1, 3, 32, 8), "lvl2": (630, 2048, 1, 4, 64, 7), "k2n512": (630, 512, 2, 3, 32, 8), "cggi16": (500, 1024, 1, 2, 32, 8),
+        "smallmod": (630, 1024, 1, 3, 32, 8)}
 
 
 def keys_for(case):
@@ -58,12 +63,16 @@ def fixture():
     return json.load(open(FIXTURE))
 
 
+def fixture_smallmod():
+    return json.load(open(FIXTURE_SMALLMOD))
+
+
 def cases():
-    """(case, operand arrays, expected words)"""
-    fx = fixture()
-    for c in fx["cases"]:
-        ins = [np.array(fx["inputs"][c["inputs"]][i], np.uint32) for i in c["operands"]]
-        yield c, ins, np.array(c["expected"], np.uint32)
+    """(case, operand arrays, expected words), both fixtures"""
+    for fx in (fixture(), fixture_smallmod()):
+        for c in fx["cases"]:
+            ins = [np.array(fx["inputs"][c["inputs"]][i], np.uint32) for i in c["operands"]]
+            yield c, ins, np.array(c["expected"], np.uint32)
 
 
 def test_fixture_is_what_the_generator_describes():
@@ -93,6 +102,11 @@ def test_fixture_is_what_the_generator_describes():
             assert len(c["expected"]) == (n + 1 if c["op"] == "SEIKS" else (k + 1) * N)
             continue
         assert len(c["expected"]) == (k * N + 1 if c["level"] else n + 1)
+    fs = fixture_smallmod()
+    assert [(c["set"], c["level"], c["op"], c["inputs"]) for c in fs["cases"]] == [("smallmod", 0, "NAND", "level0"), ("smallmod", 0, "XOR", "level0"),
+                                                                                  ("smallmod", 0, "MUX", "level0"), ("smallmod", 1, "NAND", "level1"),
+                                                                                  ("smallmod", 0, "NAND", "level0_edge_a")]
+    assert all(len(c["expected"]) == (1025 if c["level"] else 631) for c in fs["cases"])
     src = open(os.path.join(ol.ROOT, "tests", "golden", "make_golden_independent.py")).read()
     assert "import oracle" not in src and "cufhe_amd" not in src.split('"""')[2], "the generator must not share code with the oracle or the product"
 

@@ -335,17 +335,19 @@ def test_cpp_gate_api_tfhepp_branch(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
-@pytest.mark.parametrize("name", ["cggi16", "k2n512"])
+@pytest.mark.parametrize("name", ["cggi16", "k2n512", "smallmod"])
 def test_cpp_gate_api_on_a_parameter_set(engine, name):
     """The reference's own test programs (tests/cpp/test_gate_api.cpp: test_gate_gpu.cc on lvl1 ciphertexts, test_gate_gpu_multi.cc on
     lvl0, test_api_gpu.cu's chains, test_intensive.cc, the ripple-carry adders) compiled the way a user picks a set in the reference --
     at build time (CMakeLists.txt:8-24; here -DCUFHE_AMD_PARAM_SET_<SET> for include/cufhe_amd.hpp and -DORC_SET_<SET> for the oracle's
-    key generation and decryption) -- through the cufhe:: API: every gate of both orders decrypts to its truth table."""
+    key generation and decryption) -- through the cufhe:: API: every gate of both orders decrypts to its truth table.  `smallmod` is
+    chosen with the reference's own definition, -DUSE_SMALL_NTT_MODULUS (CMakeLists.txt:26-28)."""
     import os
     import subprocess
     root = ol.ROOT
     exe = os.path.join(root, "tests", "cpp", "test_gate_api_" + name)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DCUFHE_AMD_PARAM_SET_" + name.upper(), "-DORC_SET_" + name.upper(), "-o", exe,
+    select = "-DUSE_SMALL_NTT_MODULUS" if name == "smallmod" else "-DCUFHE_AMD_PARAM_SET_" + name.upper()
+    subprocess.check_call(["g++", "-O2", "-std=c++17", select, "-DORC_SET_" + name.upper(), "-o", exe,
                            os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
                            "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle_" + name,
                            "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])

@@ -181,3 +181,48 @@ def test_fast_cpu_baseline_words_match_oracle(keys, oracle):
         assert oracle.fast_gate_batch(fek, np.array([10], np.int32), 0, 1, out, ins[0].ravel(), ins[1].ravel(), 1) == -1   # MUX: not a two-input op
     finally:
         oracle.fast_evalkey_destroy(fek)
+
+
+def test_small_modulus_oracle():
+    """oracle/liboracle_smallmod.so: the restatement of the reference built with -DUSE_SMALL_NTT_MODULUS (CMakeLists.txt:12;
+    include/ntt_gpu/ntt_small_modulus.cuh).  Pinned here: its constants (P = 625 * 2^20 + 1, :36-68; psi a primitive 2048-th root
+    found as src/ntt_gpu/ntt_small_modulus.cu:71-110 finds it), the two modulus switches against their formulas in Python integers
+    (:147-177), and -- the mode is approximate by design -- that every gate still decrypts to the reference's truth table on both
+    ciphertext levels.  Word level: tests/test_golden_independent.py (schoolbook mod P)."""
+    L = ol.load_set("smallmod")
+    for f in ("orc_ntt_modulus", "orc_ntt_psi", "orc_ntt_n_inverse"):
+        getattr(L, f).restype = ctypes.c_uint64
+    L.orc_smallmod_from_torus.restype = ctypes.c_uint32
+    L.orc_smallmod_from_torus.argtypes = [ctypes.c_uint32]
+    L.orc_smallmod_to_torus.restype = ctypes.c_uint32
+    L.orc_smallmod_to_torus.argtypes = [ctypes.c_int32]
+    P = 625 * 2**20 + 1
+    assert L.orc_ntt_modulus() == P == 655360001 and L.orc_smallmod_modulus() == P
+    psi = L.orc_ntt_psi()
+    assert pow(psi, 1024, P) == P - 1 and pow(psi, 2048, P) == 1
+    g = next(x for x in range(3, 1000) if pow(x, (P - 1) // 2, P) != 1 and pow(x, (P - 1) // 5, P) != 1)
+    assert psi == pow(g, (P - 1) // 2048, P)
+    assert L.orc_ntt_n_inverse() * 1024 % P == 1
+    rng = np.random.default_rng(9)
+    inv = 2**63 // P
+    for a in [0, 1, 2, 3, 0x7FFFFFFF, 0x80000000, 0x80000001, 0xFFFFFFFE, 0xFFFFFFFF] + [int(x) for x in rng.integers(0, 2**32, 200)]:
+        assert L.orc_smallmod_from_torus(a) == (a * P + 2**31) >> 32
+    assert L.orc_smallmod_from_torus(0xFFFFFFFF) == P                 # the one unreduced value: 0 mod P
+    for r in [0, 1, P // 2, P // 2 + 1, P - 1] + [int(x) for x in rng.integers(0, P, 200)]:
+        signed = r - P if r > P // 2 else r                            # the centred value the kernels hand over
+        assert L.orc_smallmod_to_torus(signed) == ((r * inv + 2**30) >> 31) & 0xFFFFFFFF
+        assert abs(((L.orc_smallmod_to_torus(signed) - round(r * 2**32 / P) + 2**31) % 2**32) - 2**31) <= 1
+    K = ol.Keys(L, seed=7)
+    combos = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.uint8)
+    for level in (0, 1):
+        ins = [K.encrypt(combos[:, i], level, seed=700 + 10 * level + i) for i in range(3)]
+        for op in range(14):
+            out = K.gate_batch(op, level, ins[0], ins[1], ins[2])
+            assert list(K.decrypt(out, level)) == [ol.truth(L, op, *c) for c in combos], (ol.OPS[op], level)
+    # and the words are NOT the exact path's (the same keys through liboracle.so): the mode is a different function
+    E = ol.load()
+    KE = ol.Keys(E, seed=7)
+    assert np.array_equal(KE.bk, K.bk)
+    ins = [K.encrypt(combos[:, i], 0, seed=700 + i) for i in range(2)]
+    a, b = K.gate_batch(0, 0, ins[0], ins[1]), KE.gate_batch(0, 0, ins[0], ins[1])
+    assert not np.array_equal(a, b) and np.abs((a.astype(np.int64) - b.astype(np.int64) + 2**31) % 2**32 - 2**31)[:, :-1].max() > 0

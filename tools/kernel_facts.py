@@ -32,7 +32,8 @@ KERNELS = {
     "blind_rotate_lvl2q_kernel": ("blind_rotate_lvl2q_kernel", (), 1, 4, 2, STEPS),
     "blind_rotate_ll2_kernel": ("blind_rotate_ll2_kernel", (), 2, 16, 4, STEPS),
     "blind_rotate_ll_kernel": ("blind_rotate_ll_kernel", (), 1, 16, 4, STEPS),
-    "blind_rotate_ps_batch_kernel<default>": ("blind_rotate_ps_batch_kernel", ("K2N512", "Cggi16"), 8, 8, 2, STEPS),
+    "blind_rotate_ps_batch_kernel<default>": ("blind_rotate_ps_batch_kernel", ("K2N512", "Cggi16", "SmallMod"), 8, 8, 2, STEPS),
+    "blind_rotate_ps_batch_kernel<smallmod>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsSmallMod", (), 8, 8, 2, STEPS),
     "blind_rotate_ps_batch_kernel<k2n512>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsK2N512", (), 8, 8, 2, STEPS),
     "blind_rotate_ps_batch_kernel<cggi16>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsCggi16", (), 8, 8, 2, 500),
     # units per workgroup = ceil(count / 256) <= 16 (capi.hip: ks_auto_per_wg): 16 holds for launches of 4096 ciphertexts, which is
