@@ -2,7 +2,7 @@
 # tools/profile_round.sh TAG -- the rocprofv3 passes behind profiles/<TAG>_* and profiles/kernel_facts.json.
 # Run on the GPU box from the repo root (gpurun -- 'bash tools/profile_round.sh r03').  The profiled command is the default
 # bench run (every workload of the driver line: the headline batch, mux, mixed, the N = 2048 ring, a 512-gate launch on the
-# paired low-latency kernel, the three parameter sets, the key switches): one --stats pass and five --pmc passes, each its own
+# paired low-latency kernel, the four parameter sets, the key switches): one --stats pass and five --pmc passes, each its own
 # process with python3 directly behind `--`, --pmc never combined with --stats / sys traces (MI355X_MICROARCH.md, rocprofv3
 # PMC slots: 8 SQ counters per pass; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -e
