@@ -124,6 +124,7 @@ SIGNATURES = {
     "cufhe_amd_ctxt_words": (ctypes.c_int, [ctypes.c_int]),
     "cufhe_amd_ps_blind_rotate_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, ctypes.c_int]),
     "cufhe_amd_ps_keyswitch_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_ps_trlwe_op_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_int, ctypes.c_size_t, c_void, c_void]),
     "cufhe_amd_lvl2_get_params": (ctypes.c_int, [ctypes.POINTER(Lvl2Params)]),
     "cufhe_amd_lvl2_initialize": (ctypes.c_int, [c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
     "cufhe_amd_lvl2_gate_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_int,

@@ -172,7 +172,7 @@ class Trlwe(Ctxt):
 
     def __init__(self):
         self.level = 2
-        self.tlwehost = np.zeros(2 * PARAMS.N, dtype=np.uint32)
+        self.tlwehost = np.zeros(lib.cufhe_amd_ctxt_words(2), dtype=np.uint32)      # (k+1) N words of the active parameter set
         self.trlwehost = self.tlwehost
         h = ctypes.c_void_p()
         check(lib.cufhe_amd_ctxt_create(2, _ptr(self.tlwehost), ctypes.byref(h)))
@@ -440,3 +440,8 @@ def ps_blind_rotate_batch(ps, tlwe0, acc, count, steps=-1, device=0, stream=None
 
 def ps_keyswitch_batch(ps, tlwe1, tlwe0, count, device=0, stream=None):
     check(lib.cufhe_amd_ps_keyswitch_batch(int(ps), device, stream, count, tlwe1.ptr, tlwe0.ptr))
+
+
+def ps_trlwe_op_batch(ps, op, out, inp, count, device=0, stream=None):
+    """op: TL_BOOTSTRAP (lvl0 TLWEs -> TRLWEs), TL_REFRESH (TRLWEs -> TRLWEs) or TL_SEIKS (TRLWEs -> lvl0 TLWEs), device buffers of the set's sizes"""
+    check(lib.cufhe_amd_ps_trlwe_op_batch(int(ps), device, stream, int(op), count, out.ptr, inp.ptr))

@@ -647,6 +647,7 @@ int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lv
 template <class GetGate>
 int run_gates_ps(int set, int device, void* stream, int level, size_t count, GetGate get);   // paramsets.inc.h
 int ps_ctxt_words(int set, int level);
+int run_trlwe_ops_ps(int set, int device, void* stream, const GateRef* g, size_t n);         // paramsets.inc.h
 // >= 0: the per-gate API (both ciphertext levels, both gate orders) runs on this compiled parameter set -- the reference's build-time
 // choice (CMakeLists.txt:8-24) serves every entry point the same way; ciphertexts then have the set's sizes (cufhe_amd_ctxt_words)
 long g_param_set = -1;
@@ -755,6 +756,7 @@ int run_gates(int device, void* stream, int level, size_t count, GetGate get)
 // as ONE launch sequence: sample extracts, one key-switch launch, one blind-rotate launch, scatter.
 int run_trlwe_ops(int device, void* stream, const GateRef* g, size_t n)
 {
+    if (g_param_set >= 0) return run_trlwe_ops_ps((int)g_param_set, device, stream, g, n);
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     if (n == 0) return 0;

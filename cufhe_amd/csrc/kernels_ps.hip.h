@@ -676,6 +676,22 @@ __global__ __launch_bounds__(64 * kPsbWavesOf<PS>, kPsbWavesOf<PS> / 4) void bli
     }
 }
 
+// __SampleExtractIndex__<P, 0> (src/bootstrap_gpu.cu:366-381) with one descriptor per TRLWE: in0 = the TRLWE ((k+1) N words),
+// out = a lvl1 TLWE (k N + 1 words) -- the first step of __SEIandKS__ / __SEIandBootstrap2TRLWE__ on a set
+template <class PS>
+__global__ __launch_bounds__(256) void sample_extract_ps_kernel(const LinDesc* __restrict__ descs, int count)
+{
+    constexpr int N = 1 << PS::Nbit, KN = PS::k * N;
+    for (int g = blockIdx.x; g < count; g += gridDim.x) {
+        const uint32_t* in = descs[g].in0;
+        uint32_t* o = descs[g].out;
+        for (int e = threadIdx.x; e <= KN; e += blockDim.x) {
+            const int j = e / N, m = e % N;
+            o[e] = e == KN ? in[KN] : (m == 0 ? in[j * N] : 0u - in[j * N + N - m]);
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Key switch lvl1 -> lvl0 with the linear pre-add fused (include/keyswitch_gpu.cuh:83-188), one
 // workgroup (16 waves) per ciphertext: wave w takes a'_j for j in [w kN/16, (w+1) kN/16), lane L the output

@@ -205,11 +205,86 @@ int run_gates_ps(int set, int device, void* stream, int level, size_t count, Get
     return ps_dispatch(set, [&](auto psx) { return ps_run_gates<decltype(psx)>(set, device, stream, level, count, get); });
 }
 
-// words of a level-0 / level-1 ciphertext of a set
+// The TRLWE-level operations of the per-gate API on a set (run_trlwe_ops, capi.hip, over PS): lvl0 TLWE -> TRLWE
+// (__BlindRotateGlobal__, src/bootstrap_gpu.cu:317-323), TRLWE -> TRLWE (__SEIandBootstrap2TRLWE__, :325-364), TRLWE -> lvl0 TLWE
+// (__SEIandKS__, src/keyswitch_gpu.cu:26-40) as one launch sequence.  CMUXNTT stays with the BASELINE set -- the reference's
+// small-modulus build leaves it out as well (src/cufhe_gates_gpu.cu:68-86).
+template <class PS>
+int ps_run_trlwe_ops(int set, int device, void* stream, const GateRef* g, size_t n)
+{
+    using D = PsDims<PS>;
+    if (int rc = use_device(device)) return rc;
+    DeviceState& s = g_dev[device];
+    PsState& ps = ps_state(set, device);
+    if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t trlwe_words = (size_t)D::K1 * D::N;
+    size_t n_se = 0, n_rot = 0, n_t0 = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!g[i].out || !g[i].in0) return fail(-1, "null operand");
+        switch (g[i].op) {
+            case CUFHE_AMD_TL_BOOTSTRAP: n_rot++; break;
+            case CUFHE_AMD_TL_REFRESH: n_se++; n_rot++; n_t0++; break;
+            case CUFHE_AMD_TL_SEIKS: n_se++; break;
+            case CUFHE_AMD_TL_CMUX: return fail(-1, "CMUXNTT runs on the BASELINE parameter set only");
+            default: return fail(-1, "unknown TRLWE-level op");
+        }
+    }
+    Scratch sc;
+    if (int rc = open_scratch(s, st, (n_se * D::lvl1_words + n_t0 * D::lvl0_words + n_rot * trlwe_words) * 4 + (3 * n + 8) * sizeof(LinDesc) + 16384, &sc))
+        return rc;
+    uint32_t *t1 = nullptr, *t0 = nullptr, *dump = nullptr;
+    if (n_se) if (int rc = sc.alloc((void**)&t1, n_se * D::lvl1_words * 4)) return rc;
+    if (n_t0) if (int rc = sc.alloc((void**)&t0, n_t0 * D::lvl0_words * 4)) return rc;
+    if (n_rot) if (int rc = sc.alloc((void**)&dump, n_rot * trlwe_words * 4)) return rc;
+    std::vector<LinDesc> se, ks, rot, scat;
+    size_t i_se = 0, i_t0 = 0, i_rot = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (g[i].op == CUFHE_AMD_TL_BOOTSTRAP) {
+            rot.push_back({g[i].in0, g[i].in0, nullptr, 1, 0, 0u, 0u});
+        } else {
+            uint32_t* a = t1 + i_se++ * D::lvl1_words;
+            se.push_back({g[i].in0, g[i].in0, a, 1, 0, 0u, 0u});
+            if (g[i].op == CUFHE_AMD_TL_SEIKS) {
+                ks.push_back({a, a, g[i].out, 1, 0, 0u, 0u});
+                continue;
+            }
+            uint32_t* b = t0 + i_t0++ * D::lvl0_words;
+            ks.push_back({a, a, b, 1, 0, 0u, 0u});
+            rot.push_back({b, b, nullptr, 1, 0, 0u, 0u});
+        }
+        uint32_t* d = dump + i_rot++ * trlwe_words;
+        scat.push_back({d, d, g[i].out, 1, 0, 0u, 0u});
+    }
+    LinDesc *dse, *dks, *drot, *dscat;
+    if (int rc = upload_descs(s, sc, se, &dse)) return rc;
+    if (int rc = upload_descs(s, sc, ks, &dks)) return rc;
+    if (int rc = upload_descs(s, sc, rot, &drot)) return rc;
+    if (int rc = upload_descs(s, sc, scat, &dscat)) return rc;
+    if (!se.empty()) {
+        hipLaunchKernelGGL(sample_extract_ps_kernel<PS>, dim3((unsigned)(se.size() < 2048 ? se.size() : 2048)), dim3(256), 0, st, dse, (int)se.size());
+        HIP_TRY(hipGetLastError());
+    }
+    if (int rc = ps_launch_keyswitch<PS>(s, ps, st, dks, ks.size())) return rc;
+    if (int rc = ps_launch_blind_rotate<PS>(s, ps, st, drot, rot.size(), PS::n, dump)) return rc;
+    return launch_lincomb(st, dscat, scat.size(), (int)trlwe_words);
+}
+
+int run_trlwe_ops_ps(int set, int device, void* stream, const GateRef* g, size_t n)
+{
+    return ps_dispatch(set, [&](auto psx) { return ps_run_trlwe_ops<decltype(psx)>(set, device, stream, g, n); });
+}
+
+// words of a level-0 / level-1 ciphertext or (level 2) a TRLWE of a set
 int ps_ctxt_words(int set, int level)
 {
     int w = 0;
-    (void)ps_dispatch(set, [&](auto psx) { w = level ? PsDims<decltype(psx)>::lvl1_words : PsDims<decltype(psx)>::lvl0_words; return 0; });
+    (void)ps_dispatch(set, [&](auto psx) {
+        using D = PsDims<decltype(psx)>;
+        w = level == 2 ? D::K1 * D::N : level ? D::lvl1_words : D::lvl0_words;
+        return 0;
+    });
     return w;
 }
 
@@ -336,6 +411,18 @@ int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t co
         if (int rc = upload_descs(s, sc, rot, &d)) return rc;
         return ps_launch_blind_rotate<PS>(s, ps, st, d, count, st_steps, acc);
     });
+}
+
+int cufhe_amd_ps_trlwe_op_batch(int set, int device, void* stream, int op, size_t count, uint32_t* out, const uint32_t* in)
+{
+    if (!out || !in) return fail(-1, "null pointer");
+    if (op != CUFHE_AMD_TL_BOOTSTRAP && op != CUFHE_AMD_TL_REFRESH && op != CUFHE_AMD_TL_SEIKS) return fail(-1, "unknown TRLWE-level op");
+    const size_t w0 = (size_t)ps_ctxt_words(set, 0), wt = (size_t)ps_ctxt_words(set, 2);
+    if (!w0) return fail(-1, "unknown parameter set");
+    const size_t win = op == CUFHE_AMD_TL_BOOTSTRAP ? w0 : wt, wout = op == CUFHE_AMD_TL_SEIKS ? w0 : wt;
+    std::vector<GateRef> g(count);
+    for (size_t i = 0; i < count; i++) g[i] = GateRef{op, out + i * wout, in + i * win, nullptr, nullptr};
+    return run_trlwe_ops_ps(set, device, stream, g.data(), count);
 }
 
 int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1, uint32_t* tlwe0)

@@ -65,7 +65,7 @@ class HipBackend : public sched::Backend {
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
     int words(int level) override
     {
-        if (level <= 1 && g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes
+        if (level <= 2 && g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes (2: a TRLWE)
         return slot_words(level);
     }
     // device slots are carved for the largest ciphertext of any compiled set, so "param_set" may change while ciphertexts live
@@ -343,9 +343,9 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
 
 int cufhe_amd_ctxt_words(int level)
 {
-    if (level < 0 || level > 1) return fail(-1, "level must be 0 or 1");
+    if (level < 0 || level > 2) return fail(-1, "level must be 0, 1 or 2 (a TRLWE)");
     if (g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);
-    return level ? kLvl1Words : kLvl0Words;
+    return level == 2 ? 2 * kN : level ? kLvl1Words : kLvl0Words;
 }
 
 uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)
@@ -406,7 +406,7 @@ int cufhe_amd_enqueue_trlwe_op(int device, void* stream, int op, int copying, cu
     if (int rc = sched_check_ctxt(S, out)) return rc;
     if (int rc = sched_check_ctxt(S, in)) return rc;
     if (in->level != lin || out->level != lout) return fail(-1, "operand levels do not fit the TRLWE-level operation");
-    if (!g_dev[device].keys_ready) return fail(-3, "Initialize(ek) has not been called for this device");
+    if (!g_dev[device].keys_ready && g_param_set < 0) return fail(-3, "Initialize(ek) has not been called for this device");
     cufhe_amd_ctxt* ins[3] = {in, nullptr, nullptr};
     if (int rc = S->dev(device).record_gate(stream, op, copying != 0, out, ins, 2)) return sched_error(S->dev(device), rc);
     return 0;

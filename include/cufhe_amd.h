@@ -249,7 +249,8 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * "lvl2_kernel" (default -1 = by measured cost): blind-rotate kernel of the N = 2048 ring: 1 = four quarter-transform waves per rotation with
  * register sums, two rotations per CU (launches above one rotation per CU); 0 = eight half-transform waves, one rotation per CU.
  * "param_set" (default -1; "lvl0_param_set" is the same option under its old name): index of a cufhe_amd_ps_* parameter set on
- * which the whole per-gate API runs instead -- both ciphertext levels and both gate orders, as the set chosen when the reference
+ * which the whole per-gate API runs instead -- both ciphertext levels and both gate orders, and the three bootstrapping TRLWE-level
+ * operations of cufhe_amd_enqueue_trlwe_op (CMUXNTT stays with the BASELINE set), as the set chosen when the reference
  * is built serves every entry point (CMakeLists.txt:8-24); cufhe_amd_ps_initialize first.  Ciphertexts then have the set's sizes
  * (cufhe_amd_ctxt_words: n + 1 and k N + 1 words; include/cufhe_amd.hpp selects the matching parameter structs with
  * -DCUFHE_AMD_PARAM_SET_K2N512 / -DCUFHE_AMD_PARAM_SET_CGGI16).  Changing it waits for everything recorded.
@@ -327,7 +328,7 @@ typedef struct cufhe_amd_ps_params {
 int cufhe_amd_ps_count(void);
 int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* out);
 int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
-/* words of a level-0 / level-1 ciphertext of the per-gate API as configured now ("param_set") */
+/* words of a level-0 / level-1 ciphertext, or (level 2) of a TRLWE, of the per-gate API as configured now ("param_set") */
 int cufhe_amd_ctxt_words(int level);
 /* the same gates on ciphertexts of `level`: 0 = blind rotate then key switch on n + 1 words, 1 = key switch then blind rotate on
  * k N + 1 words (the reference's two __HomGate__ orders, src/bootstrap_gpu.cu:383-421, Mux :515-588 / :706-780) */
@@ -343,6 +344,10 @@ int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t co
 /* tlwe1[count][kN+1] -> tlwe0[count][n+1] */
 int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1,
                                  uint32_t* tlwe0);
+/* the bootstrapping TRLWE-level operations on a set, device-resident: op = CUFHE_AMD_TL_BOOTSTRAP (in: tlwe0[count][n+1], out:
+ * trlwe[count][(k+1)N]; BootstrapTLWE2TRLWE, src/bootstrap_gpu.cu:806-815), CUFHE_AMD_TL_REFRESH (trlwe -> trlwe; :325-364) or
+ * CUFHE_AMD_TL_SEIKS (trlwe -> tlwe0; SEIandKS, src/keyswitch_gpu.cu:26-40) */
+int cufhe_amd_ps_trlwe_op_batch(int set, int device, void* stream, int op, size_t count, uint32_t* out, const uint32_t* in);
 
 /* ---- measurement ----
  * When enabled, every blind-rotate / key-switch launch is bracketed by HIP events on the

@@ -37,8 +37,8 @@
 //                                  discretisation switching (include/ntt_gpu/ntt_small_modulus.cuh) -- approximate, as there
 // Initialize(bk, ..) then loads the keys into that set and switches the per-gate API onto it ("param_set"): Ctxt<lvl0param> has
 // n + 1 words of the set, Ctxt<lvl1param> k N + 1, And ... NMux run blind rotate -> key switch on the first and key switch ->
-// blind rotate on the second (src/bootstrap_gpu.cu:383-421).  The TRLWE-level operations and the N = 2048 ring stay with the
-// BASELINE set.
+// blind rotate on the second (src/bootstrap_gpu.cu:383-421), GateBootstrappingTLWE2TRLWElvl01NTT / Refresh /
+// SampleExtractAndKeySwitch run on the set as well.  CMUXNTT / TRGSW2NTT and the N = 2048 ring stay with the BASELINE set.
 #if defined(CUFHE_AMD_PARAM_SET_K2N512)
 #define CUFHE_AMD_PARAM_SET_INDEX 1
 #elif defined(CUFHE_AMD_PARAM_SET_CGGI16)
@@ -276,7 +276,10 @@ CUFHE_AMD_GATE3(NMux, CUFHE_AMD_NMUX)
 // reference, results are in the host members after Synchronize() or StreamQuery(st) == true.  TRGSW2NTT completes
 // before returning (the reference waits for its D2H copy too).
 
-#ifndef CUFHE_AMD_PARAM_SET_INDEX      // the TRLWE-level operations run on the BASELINE set only
+// On a build for another parameter set (CUFHE_AMD_PARAM_SET_INDEX) the three bootstrapping ones run on that set; CMUXNTT and
+// TRGSW2NTT are declared for the BASELINE set only -- as the reference's small-modulus build leaves them out
+// (src/cufhe_gates_gpu.cu:68-86, src/bootstrap_gpu.cu:73-95).
+
 /// struct cuFHETRLWElvl1, include/cufhe_gpu.cuh:124-134
 struct cuFHETRLWElvl1 {
     TFHEpp::TRLWE<TFHEpp::lvl1param> trlwehost;
@@ -292,7 +295,9 @@ struct cuFHETRLWElvl1 {
     cuFHETRLWElvl1(const cuFHETRLWElvl1&) = delete;
     cuFHETRLWElvl1& operator=(const cuFHETRLWElvl1&) = delete;
 };
-static_assert(sizeof(TFHEpp::TRLWE<TFHEpp::lvl1param>) == 2 * TFHEpp::lvl1param::n * sizeof(uint32_t), "TRLWE is (k+1) N contiguous words");
+static_assert(sizeof(TFHEpp::TRLWE<TFHEpp::lvl1param>) == (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::n * sizeof(uint32_t), "TRLWE is (k+1) N contiguous words");
+
+#ifndef CUFHE_AMD_PARAM_SET_INDEX
 
 /// struct cuFHETRGSWNTTlvl1, :136-146.  The NTT-domain words are this library's (exact
 /// residues mod a 50-bit prime carried in doubles); like the reference's FFP words they are
@@ -321,6 +326,7 @@ inline void TRGSW2NTT(cuFHETRGSWNTTlvl1& trgswntt, const TFHEpp::TRGSW<TFHEpp::l
 {
     CUFHE_AMD_CHECK(cufhe_amd_trgsw_to_ntt(st.device_id(), st.st(), reinterpret_cast<const uint32_t*>(trgsw.data()), trgswntt.handle));
 }
+#endif  // CUFHE_AMD_PARAM_SET_INDEX
 /// gGateBootstrappingTLWE2TRLWElvl01NTT / GateBootstrappingTLWE2TRLWElvl01NTT, src/cufhe_gates_gpu.cu:86-104
 inline void gGateBootstrappingTLWE2TRLWElvl01NTT(cuFHETRLWElvl1& out, Ctxt<TFHEpp::lvl0param>& in, Stream st)
 {
@@ -351,6 +357,7 @@ inline void SampleExtractAndKeySwitch(Ctxt<TFHEpp::lvl0param>& out, const cuFHET
     gSampleExtractAndKeySwitch(out, in, st);
     CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), out.handle, 0));
 }
+#ifndef CUFHE_AMD_PARAM_SET_INDEX
 /// CMUXNTT, src/cufhe_gates_gpu.cu:68-85: res = cs ? c1 : c0.  Like the reference it uploads cs, c1, c0 from their host
 /// members in stream order, returns at once, and res.trlwehost holds the result after Synchronize() / StreamQuery(st);
 /// operands that are results of earlier recorded operations are picked up by the scheduler's dependence tracking (no

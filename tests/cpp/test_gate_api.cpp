@@ -261,6 +261,38 @@ void MixedAtSize(std::mt19937& eng)
     delete[] st;
 }
 
+// test/test_perf.cc:36-87 on whatever parameter set this build runs on (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt
+// coefficient 0), plus SampleExtractAndKeySwitch: the three TRLWE-level operations every build of the reference has -- the
+// small-modulus one included (src/cufhe_gates_gpu.cu:86-146 are outside its #ifndef)
+void TrlweBootstraps(std::mt19937& eng)
+{
+    using namespace TFHEpp;
+    const int kNum = 12, kStreams = 3;
+    std::vector<Stream> st(kStreams);
+    for (auto& s : st) s.Create();
+    std::vector<Ctxt<lvl0param>> in(kNum), out0(kNum);
+    std::vector<cuFHETRLWElvl1> t(kNum), r(kNum);
+    std::vector<int> bits(kNum);
+    for (int i = 0; i < kNum; i++) {
+        bits[i] = eng() & 1;
+        encrypt(in[i], bits[i]);
+        GateBootstrappingTLWE2TRLWElvl01NTT(t[i], in[i], st[i % kStreams]);
+        Refresh(r[i], t[i], st[i % kStreams]);
+        SampleExtractAndKeySwitch(out0[i], r[i], st[i % kStreams]);
+    }
+    Synchronize();
+    int bad = 0;
+    auto coeff0 = [&](cuFHETRLWElvl1& x) {
+        uint32_t tl[ORC_LVL1_WORDS];
+        orc_sample_extract0(tl, x.trlwehost[0].data());
+        return orc_tlwe_decrypt(1, g_s1.data(), tl);
+    };
+    for (int i = 0; i < kNum; i++) bad += (coeff0(t[i]) != bits[i]) + (coeff0(r[i]) != bits[i]) + (decrypt(out0[i]) != bits[i]);
+    std::printf("bootstrap to TRLWE, Refresh, SampleExtractAndKeySwitch on %d ciphertexts: %s (%d failures)\n", kNum, bad ? "FAIL" : "PASS", bad);
+    g_failures += bad;
+    for (auto& s : st) s.Destroy();
+}
+
 #ifndef CUFHE_AMD_PARAM_SET_INDEX
 // test/test_perf.cc:36-87 (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt coefficient 0)
 // and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch.
@@ -474,6 +506,7 @@ int main(int argc, char** argv)
     Chained(eng);
     Intensive(eng);
     DeviceResident(eng);
+    TrlweBootstraps(eng);
     RippleAdders(eng);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");

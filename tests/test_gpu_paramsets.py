@@ -134,6 +134,64 @@ def test_every_gate_words_and_truth_table(engine, pset, keys, level):
             engine.Initialize(keys.bk, keys.ksk)
 
 
+def test_trlwe_level_operations_over_a_parameter_set(engine, pset):
+    """GateBootstrappingTLWE2TRLWElvl01NTT, Refresh and SampleExtractAndKeySwitch (src/cufhe_gates_gpu.cu:86-146) recorded through the
+    per-gate API on another set -- k + 1 = 3 polynomials of 512 for `k2n512`, the small NTT modulus for `smallmod` (whose build in the
+    reference keeps exactly these three and drops CMUXNTT, :68-86) -- word for word against the set's oracle, chained without a
+    synchronisation in between."""
+    name, idx, L, K = pset
+    api = engine.api
+    api.set_option("param_set", idx)
+    try:
+        count = 6
+        trlwe_words = (K.k + 1) * K.N
+        assert api.Trlwe().trlwehost.size == trlwe_words
+        bits = np.array([g & 1 for g in range(count)], np.uint8)
+        enc = K.encrypt(bits, 0, seed=4100)
+        ins = [api.Ctxt(0) for _ in range(count)]
+        t, r, o = ([api.Trlwe() for _ in range(count)] for _ in range(3))
+        outs = [api.Ctxt(0) for _ in range(count)]
+        sts = [api.Stream() for _ in range(2)]
+        for s in sts:
+            s.Create()
+        for g in range(count):
+            ins[g].tlwehost[:] = enc[g]
+            api.GateBootstrappingTLWE2TRLWElvl01NTT(t[g], ins[g], sts[g % 2])
+            api.Refresh(r[g], t[g], sts[g % 2])
+            api.SampleExtractAndKeySwitch(outs[g], r[g], sts[g % 2])
+        api.Synchronize()
+
+        def extract(acc):
+            tl = np.zeros(K.words[1], np.uint32)
+            L.orc_sample_extract0(tl, np.ascontiguousarray(acc))
+            return tl
+        for g in range(count):
+            want_t = K.blind_rotate(enc[g])
+            assert np.array_equal(t[g].trlwehost, want_t), f"{name}: bootstrap to a TRLWE {g}"
+            want_r = K.blind_rotate(K.keyswitch(extract(want_t)))
+            assert np.array_equal(r[g].trlwehost, want_r), f"{name}: Refresh {g}"
+            want_o = K.keyswitch(extract(want_r))
+            assert np.array_equal(outs[g].tlwehost, want_o), f"{name}: SampleExtractAndKeySwitch {g}"
+            assert K.decrypt(want_o[None, :], 0)[0] == bits[g] and K.decrypt(extract(want_r)[None, :], 1)[0] == bits[g]
+        for s in sts:
+            s.Destroy()
+    finally:
+        api.set_option("param_set", -1)
+    assert api.Trlwe().trlwehost.size == 2 * ol.N
+    # the device-resident batch form of the same three (cufhe_amd_ps_trlwe_op_batch), without "param_set"
+    d_in = _up(engine, enc)
+    d_t, d_r = api.DeviceBuffer(count * trlwe_words), api.DeviceBuffer(count * trlwe_words)
+    d_o = api.DeviceBuffer(count * K.words[0])
+    api.ps_trlwe_op_batch(idx, api.TL_BOOTSTRAP, d_t, d_in, count)
+    api.ps_trlwe_op_batch(idx, api.TL_REFRESH, d_r, d_t, count)
+    api.ps_trlwe_op_batch(idx, api.TL_SEIKS, d_o, d_r, count)
+    assert np.array_equal(d_t.download().reshape(count, -1), np.stack([x.trlwehost for x in t]))
+    assert np.array_equal(d_r.download().reshape(count, -1), np.stack([x.trlwehost for x in r]))
+    assert np.array_equal(d_o.download().reshape(count, -1), np.stack([x.tlwehost for x in outs]))
+    with pytest.raises(Exception):
+        api.ps_trlwe_op_batch(idx, 103, d_r, d_t, 1)          # CMUXNTT: BASELINE set only
+
+
 def test_mixed_batch(engine, pset):
     name, idx, L, K = pset
     count = 48
