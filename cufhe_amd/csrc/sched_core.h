@@ -152,6 +152,7 @@ struct cufhe_amd_ctxt {
         std::vector<uint32_t> snap_own;
     };
     int level = 0;
+    int words = 0;                  // words of the caller's host buffer: those of a level-`level` ciphertext when it was created
     uint32_t* host = nullptr;       // nullptr once the caller destroyed the ciphertext
     void* owner = nullptr;          // the Scheduler that created it
     std::atomic<int> host_reads{0};             // recorded uploads whose copy out of `host` is still to be done
@@ -592,6 +593,7 @@ class Scheduler {
     {
         cufhe_amd_ctxt* c = new cufhe_amd_ctxt();
         c->level = level;
+        c->words = devs_[0]->backend()->words(level);
         c->host = host_words;
         c->d.resize(devs_.size());
         for (size_t d = 0; d < devs_.size(); d++)

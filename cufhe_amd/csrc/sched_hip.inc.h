@@ -358,6 +358,10 @@ static int sched_check_ctxt(sched::Scheduler* S, cufhe_amd_ctxt* c)
 {
     if (c->owner != (void*)S) return fail(-1, "ciphertext was created before SetGPUNum changed the GPU set");
     if (c->destroyed) return fail(-1, "gate on a destroyed ciphertext");
+    // the caller's host buffer has the size of the parameter set that was active when the ciphertext was created ("param_set"):
+    // copies to and from it move the active set's size
+    if (c->words != S->dev(0).backend()->words(c->level))
+        return fail(-1, "ciphertext was created under another parameter set (\"param_set\"): its host buffer has a different size");
     return 0;
 }
 

@@ -253,7 +253,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * operations of cufhe_amd_enqueue_trlwe_op (CMUXNTT stays with the BASELINE set), as the set chosen when the reference
  * is built serves every entry point (CMakeLists.txt:8-24); cufhe_amd_ps_initialize first.  Ciphertexts then have the set's sizes
  * (cufhe_amd_ctxt_words: n + 1 and k N + 1 words; include/cufhe_amd.hpp selects the matching parameter structs with
- * -DCUFHE_AMD_PARAM_SET_K2N512 / -DCUFHE_AMD_PARAM_SET_CGGI16).  Changing it waits for everything recorded.
+ * -DCUFHE_AMD_PARAM_SET_K2N512 / -DCUFHE_AMD_PARAM_SET_CGGI16 / -DCUFHE_AMD_PARAM_SET_SMALLMOD).  Changing it waits for everything
+ * recorded; a ciphertext keeps the host buffer of the set it was created under, and using it while a set with other sizes is active is
+ * refused (-1).
  * "share_devices" (default 0): 1 lets SetGPUNum(G) exceed the visible GPU count, logical devices wrapping around the
  * physical ones (every logical device keeps its own key replica, scheduler, launch thread and streams): the
  * reference's multi-GPU programs (test/test_gate_gpu_multi.cc) rehearsed on fewer GPUs.

@@ -240,3 +240,12 @@ def test_per_gate_api_over_a_parameter_set(engine, pset, level):
     finally:
         api.set_option("param_set", -1)
     assert api.Ctxt(0).tlwehost.size == ol.n + 1
+    if K.words[level] != ol.LVL_WORDS[level]:
+        # a ciphertext keeps the host buffer of the set it was created under: using it under another set is refused, not copied past its end
+        st = api.Stream()
+        st.Create()
+        with pytest.raises(Exception, match="another parameter set"):
+            api.Nand(api.Ctxt(level), cts[0][0], cts[1][0], st)
+        with pytest.raises(Exception, match="another parameter set"):
+            api.CtxtCopyH2D(cts[0][0], st)
+        st.Destroy()
