@@ -526,6 +526,11 @@ def main():
             "launch_ms": br_ms, "rotations_per_launch": rotations, "algorithmic_bytes_per_rotation": bk_bytes,
             "keyswitch_launch_ms": ks_ms, "pmc_source": note,
         }
+        if not l2:
+            # SURVEY.md 8(d), secondary: the reference's radix-2 path does 55 296 modular multiplications per CMux step = 34 836 480 per
+            # rotation; the rate at which this launch gets through that ALGORITHMIC count (the radix-4 kernels here issue fewer)
+            r["reference_modmuls_per_rotation"] = 55296 * 630
+            r["algorithmic_modmuls_per_s"] = 55296 * 630 * rotations / (br_ms * 1e-3) if br_ms > 0 else 0.0
         if facts:
             r["traffic"] = facts["hbm_bytes_per_rotation"] * rotations
             r["traffic_replayed_from"] = replayed_from(("fetch", "tcc"))
