@@ -157,6 +157,24 @@ void user(const TFHEpp::EvalKey& ek) {
 ''')
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"),
                            "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"), str(src)])
+    # the same user with the reference's small-modulus switch defined, as its CMake does (CMakeLists.txt:26-28): Initialize(ek) then
+    # loads parameter set 3; the bootstrapping TRLWE-level calls stay, CMUXNTT / TRGSW2NTT are not declared (src/cufhe_gates_gpu.cu:68-86)
+    small = tmp_path / "user_small.cpp"
+    small.write_text(src.read_text() + '''
+void user2(cufhe::Ctxt<TFHEpp::lvl0param>& in, cufhe::Ctxt<TFHEpp::lvl0param>& out, cufhe::Stream st) {
+    cufhe::cuFHETRLWElvl1 t, r;
+    cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(t, in, st);
+    cufhe::Refresh(r, t, st);
+    cufhe::SampleExtractAndKeySwitch(out, r, st);
+    static_assert(CUFHE_AMD_PARAM_SET_INDEX == 3, "USE_SMALL_NTT_MODULUS selects the small-modulus set");
+}
+''')
+    flags = ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-DUSE_SMALL_NTT_MODULUS", "-I" + os.path.join(root, "include"),
+             "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub")]
+    subprocess.check_call(flags + [str(small)])
+    cm = tmp_path / "user_cmux.cpp"
+    cm.write_text(src.read_text() + "void user3() { cufhe::cuFHETRGSWNTTlvl1 cs; (void)cs; }\n")
+    assert subprocess.run(flags + [str(cm)], capture_output=True).returncode != 0, "CMUXNTT types are declared in a small-modulus build"
 
 
 def test_recorded_pmc_facts_belong_to_the_committed_device_code():
