@@ -178,9 +178,9 @@ template <> struct Poly<9> {
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt512_inverse(x, c); }
 };
 
-// The transforms of the wave-per-rotation kernel (blind_rotate_ps_batch_kernel): for the 1024-point ring the radix-4 passes of
-// ntt_r4.h on the r4 tables in their packed form (the workgroup-per-rotation kernel and the key conversion keep the
-// radix-2 transform and tables above), for the 512-point ring Poly<9> as it is.  DIGIT_MAX = Bg/2.
+// The transforms of both blind-rotate kernels: for the 1024-point ring the radix-4 passes of ntt_r4.h on the r4 tables in their
+// packed form (the key conversion keeps the radix-2 transform and tables above; the spectrum order is the same), for the 512-point
+// ring Poly<9> as it is.  DIGIT_MAX = Bg/2.
 template <int NBIT, int DIGIT_MAX> struct PsbPoly;
 template <int DIGIT_MAX> struct PsbPoly<9, DIGIT_MAX> : Poly<9> {
     static constexpr bool kR4Tables = false;
@@ -223,6 +223,17 @@ template <int DIGIT_MAX> struct PsbPoly<10, DIGIT_MAX> {
     static __device__ __forceinline__ void inverse(double (&x)[R], const Ctx& c) { ntt_inverse_r4<r4::Uniform<501>>(x, c); }
 };
 
+// The transforms of the workgroup-per-rotation kernel: those of the wave-per-rotation kernel (radix-4 passes for the 1024-point ring;
+// one rotation 4.97 -> 4.47 ms on `default`, 3.93 -> 3.70 on `cggi16`, 3.51 -> 3.36 on `k2n512` through the digit form of its
+// 512-point transform: profiles/r05_ps_wg_radix4_ab.txt); -DCUFHE_AMD_PS_WG_RADIX2 (tools/build_variant.py) keeps the radix-2
+// transform the key conversion uses, for A/B runs.
+#ifdef CUFHE_AMD_PS_WG_RADIX2
+constexpr bool kPsWgR4 = false;
+#else
+constexpr bool kPsWgR4 = true;
+#endif
+template <class PS> using PsWgPolyOf = std::conditional_t<kPsWgR4, PsbPolyOf<PS>, Poly<PS::Nbit>>;
+
 // waves of the workgroup-per-rotation kernel: one per TRGSW row where that takes more than 8 (k2n512: 9 rows would
 // otherwise be walked in two passes, the second with one busy wave)
 template <class PS> constexpr int kPsWavesOf = ((PS::k + 1) * PS::l > 8) ? 12 : 8;
@@ -230,7 +241,7 @@ template <class PS> constexpr int kPsWavesOf = ((PS::k + 1) * PS::l > 8) ? 12 : 
 template <class PS>
 struct PsLds {
     using D = PsDims<PS>;
-    using PO = Poly<PS::Nbit>;
+    using PO = PsWgPolyOf<PS>;
     static constexpr int tables = 0;
     static constexpr int tiles = tables + PO::table_bytes;
     static constexpr int waves = kPsWavesOf<PS>;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
     const typename Poly<PS::Nbit>::Tables* __restrict__ gt, int steps, uint32_t* __restrict__ acc_dump)
 {
     using D = PsDims<PS>;
-    using PO = Poly<PS::Nbit>;
+    using PO = PsWgPolyOf<PS>;
     using L = PsLds<PS>;
     constexpr int N = D::N, R = D::R, K1 = D::K1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,14 +349,35 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
     __syncthreads();
     const typename PO::Ctx ctx = PO::ctx(smem, L::tiles + wave * PO::tile_bytes, L::tables, gt, lane);
 
+    // One TRGSW row per wave (waves >= rows).  The key polynomials of the wave's row -- (k+1) x limbs of them, R/2 double2 per lane
+    // each -- are read a whole step ahead: issued after the products of step i, they arrive while the inverse transforms of step i
+    // run on other waves, so the L2 latency of the key stream is off the step's critical path: one rotation 4.47 -> 4.16 ms on
+    // `default`, 3.36 -> 3.03 on `k2n512`, 3.70 -> 3.46 on `cggi16` (profiles/r05_ps_wg_radix4_ab.txt; with every CU busy the
+    // gain is 0 - 3 %).  -DCUFHE_AMD_PS_WG_NO_PREFETCH: loads where they are used, for A/B runs.
+    static_assert(L::waves >= D::ROWS, "one TRGSW row per wave");
+    const bool has_row = wave < D::ROWS;
+    const int row = wave, j = row / PS::l, dg = row % PS::l;
+    double2 kb[D::SUMS][R / 2];
+    auto load_key = [&](int step) {
+        if (!has_row || step >= steps) return;
+#pragma unroll
+        for (int s = 0; s < D::SUMS; s++) {
+            const int out = s / PS::limbs, limb = s % PS::limbs;
+            const double2* kp = (const double2*)(bk_ntt + ((((size_t)step * PS::limbs + (PS::limbs - 1 - limb)) * D::ROWS + row) * K1 + out) * N) + lane;
+#pragma unroll
+            for (int q = 0; q < R / 2; q++) kb[s][q] = kp[q * 64];
+        }
+    };
+#ifndef CUFHE_AMD_PS_WG_NO_PREFETCH
+    load_key(0);
+#endif
+
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
         const uint32_t abar = __builtin_amdgcn_readfirstlane((uint32_t)abar_lds[i]);
         const int alo = (int)(abar & (N - 1));
         const bool ahi = (abar >> PS::Nbit) != 0;
-#pragma unroll 1
-        for (int row = wave; row < D::ROWS; row += L::waves) {
-            const int j = row / PS::l, dg = row % PS::l;
+        if (has_row) {
             const uint32_t* accj = accL + j * N;
             const uint32_t pos = 32 - (dg + 1) * PS::Bgbit;
             double x[R];
@@ -357,24 +389,26 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
                 const uint32_t t = ((neg ? 0u - rot : rot) - accj[e] + ps_decomp_offset<PS>()) ^ ps_decomp_signmask<PS>();
                 x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, pos, (uint32_t)PS::Bgbit);
             }
-            PO::forward(x, ctx);
+            if constexpr (kPsWgR4) PO::forward_digits(x, ctx, typename PO::State{});
+            else PO::forward(x, ctx);
 #pragma unroll
             for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
-#pragma unroll 1
-            for (int s = 0; s < D::SUMS; s++) {      // :206-221, one product per (output component, key limb)
-                const int out = s / PS::limbs, limb = s % PS::limbs;
-                const double2* kp = (const double2*)(bk_ntt + ((((size_t)i * PS::limbs + (PS::limbs - 1 - limb)) * D::ROWS + row) * K1 + out) * N) + lane;
-                double* sp = sumL + s * N + lane;
-                double2 b[R / 2];
+#ifdef CUFHE_AMD_PS_WG_NO_PREFETCH
+            load_key(i);
+#endif
 #pragma unroll
-                for (int q = 0; q < R / 2; q++) b[q] = kp[q * 64];
+            for (int s = 0; s < D::SUMS; s++) {      // :206-221, one product per (output component, key limb)
+                double* sp = sumL + s * N + lane;
 #pragma unroll
                 for (int q = 0; q < R / 2; q++) {
-                    __hip_atomic_fetch_add(sp + (2 * q) * 64, fpf::mulmod(x[2 * q], b[q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(sp + (2 * q + 1) * 64, fpf::mulmod(x[2 * q + 1], b[q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(sp + (2 * q) * 64, fpf::mulmod(x[2 * q], kb[s][q].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(sp + (2 * q + 1) * 64, fpf::mulmod(x[2 * q + 1], kb[s][q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
+#ifndef CUFHE_AMD_PS_WG_NO_PREFETCH
+        load_key(i + 1);
+#endif
         __syncthreads();
 #pragma unroll 1
         for (int s = wave; s < D::SUMS; s += L::waves) {      // :227-284

@@ -10,8 +10,8 @@ namespace {
 
 long g_ps_batch_threshold = -1;    // rotations per launch from which the wave-per-rotation kernel is used (-1: by cost)
 // By cost (tools/ps_latency.py, tools/ps_times.py; blind rotation + key switch, MI355X): the workgroup-per-rotation kernel takes
-// 5.0 / 3.5 / 4.0 ms per started round of one rotation per CU (default / k2n512 / cggi16), a round of the wave-per-rotation kernel
-// (up to eight per CU) 21 / 18.5 / 26 ms: the second wins from the fifth / sixth / seventh started round on.
+// 4.3 / 3.4 / 3.7 ms per started round of one rotation per CU (default / k2n512 / cggi16; 4.2 / 3.0 / 3.5 for a few rotations), a round of the wave-per-rotation kernel
+// (up to eight per CU) 21 / 18.5 / 26 ms: the second wins from the fifth / sixth / seventh started round on (the seventh of cggi16: a tie).
 template <class PS> long ps_auto_batch(int cus) { return (PS::limbs > 1 ? 6L : PS::Nbit == 9 ? 5L : 4L) * std::max(1, cus) + 1; }
 
 struct PsState {
@@ -108,7 +108,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
     } else {
         // one workgroup per rotation (latency shape)
         hipLaunchKernelGGL(blind_rotate_ps_kernel<PS>, dim3((unsigned)count), dim3(PsLds<PS>::threads), PsLds<PS>::bytes, st, d, (int)count,
-                           ps.bk_ntt, ps_tables<PS>(s), steps, dump);
+                           ps.bk_ntt, kPsWgR4 ? ps_tables_batch<PS>(s) : ps_tables<PS>(s), steps, dump);
     }
     HIP_TRY(hipGetLastError());
     return prof_end(s, st, ev, count, false);
