@@ -55,6 +55,8 @@ for ps in range(api.ps_count()):
     e1 = api.DeviceBuffer(x.size).upload(x[::-1].copy())
     eo = api.DeviceBuffer(x.size)
     soak("parameter set " + p.name.decode(), lambda: api.ps_gate_batch(ps, api.NAND, eo, e0, e1, count=4096), eo, 4096, reps // 4)
+    for count in (700, 256, 1):      # the workgroup-per-rotation kernel (key polynomials read a step ahead, LDS sums)
+        soak("parameter set " + p.name.decode(), lambda: api.ps_gate_batch(ps, api.NAND, eo, e0, e1, count=count), eo, count, reps)
 eng.CleanUp()
 print("TOTAL differing launches:", bad)
 sys.exit(1 if bad else 0)
