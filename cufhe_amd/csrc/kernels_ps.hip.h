@@ -371,6 +371,13 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
 #ifndef CUFHE_AMD_PS_WG_NO_PREFETCH
     load_key(0);
 #endif
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    // timing-only (tools/ps_phases.py): cycles this wave spends in each phase of a step
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define CUFHE_AMD_PS_PHASE(k) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tc; tc = tn; }
+#else
+#define CUFHE_AMD_PS_PHASE(k)
+#endif
 
 #pragma unroll 1
     for (int i = 0; i < steps; i++) {
@@ -389,10 +396,12 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
                 const uint32_t t = ((neg ? 0u - rot : rot) - accj[e] + ps_decomp_offset<PS>()) ^ ps_decomp_signmask<PS>();
                 x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, pos, (uint32_t)PS::Bgbit);
             }
+            CUFHE_AMD_PS_PHASE(0)
             if constexpr (kPsWgR4) PO::forward_digits(x, ctx, typename PO::State{});
             else PO::forward(x, ctx);
 #pragma unroll
             for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
+            CUFHE_AMD_PS_PHASE(1)
 #ifdef CUFHE_AMD_PS_WG_NO_PREFETCH
             load_key(i);
 #endif
@@ -405,18 +414,22 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
                     __hip_atomic_fetch_add(sp + (2 * q + 1) * 64, fpf::mulmod(x[2 * q + 1], kb[s][q].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+            CUFHE_AMD_PS_PHASE(2)
         }
 #ifndef CUFHE_AMD_PS_WG_NO_PREFETCH
         load_key(i + 1);
 #endif
         __syncthreads();
+        CUFHE_AMD_PS_PHASE(3)
 #pragma unroll 1
         for (int s = wave; s < D::SUMS; s += L::waves) {      // :227-284
             double* sp = sumL + s * N + lane;
             double A[R];
 #pragma unroll
             for (int r = 0; r < R; r++) { A[r] = fpf::reduce(sp[r * 64]); sp[r * 64] = 0.0; }
+            CUFHE_AMD_PS_PHASE(4)
             PO::inverse(A, ctx);
+            CUFHE_AMD_PS_PHASE(5)
             const int out = s / PS::limbs, shl = (s % PS::limbs) * PS::limb_bits;
             uint32_t* acck = accL + out * N + lane;
 #pragma unroll
@@ -425,14 +438,23 @@ __global__ __launch_bounds__(64 * kPsWavesOf<PS>) void blind_rotate_ps_kernel(
                 if (PS::limbs == 1) acck[64 * r] += v;
                 else __hip_atomic_fetch_add(acck + 64 * r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            CUFHE_AMD_PS_PHASE(6)
         }
         __syncthreads();
+        CUFHE_AMD_PS_PHASE(7)
     }
 
     if (acc_dump) {
         uint32_t* o = acc_dump + (size_t)g * K1 * N;
         for (int e = tid; e < K1 * N; e += L::threads) o[e] = accL[e];
     }
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_PHASES)
+    if (acc_dump && lane == 0 && g == 0) {
+        __syncthreads();
+        unsigned long long* o = (unsigned long long*)acc_dump + 16 + wave * 8;      // overwrites part of the dump: timing only
+        for (int k = 0; k < 8; k++) o[k] = ph[k];
+    }
+#endif
     if (d.out) {   // __SampleExtractIndex__<P,0>: per mask component a'[0] = a[0], a'[m] = -a[N-m]; b' = b[0]
         uint32_t* o = d.out;
         for (int e = tid; e < PS::k * N; e += L::threads) {
