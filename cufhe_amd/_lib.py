@@ -47,6 +47,11 @@ class PsParams(ctypes.Structure):
                [(k, ctypes.c_uint64) for k in ("bk_words", "ksk_words", "bk_ntt_bytes")]
 
 
+class ParamNumbers(ctypes.Structure):
+    """cufhe_amd_param_numbers: the numbers a caller was compiled with (include/cufhe_amd.h)"""
+    _fields_ = [(k, ctypes.c_uint32) for k in ("n", "nbit", "k", "l", "Bgbit", "t", "basebit", "small_ntt_modulus")]
+
+
 class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
@@ -114,6 +119,11 @@ SIGNATURES = {
     "cufhe_amd_probe_clock": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "cufhe_amd_polymul512_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
     "cufhe_amd_bootstrap_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_stream_fence": (ctypes.c_int, [ctypes.c_int, c_void]),
+    "cufhe_amd_find_param_set": (ctypes.c_int, [ctypes.POINTER(ParamNumbers)]),
+    "cufhe_amd_initialize_params": (ctypes.c_int, [ctypes.POINTER(ParamNumbers), c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),
+    "cufhe_amd_ps_trgsw_to_ntt_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_ps_cmux_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void, c_void]),
     "cufhe_amd_ps_count": (ctypes.c_int, []),
     "cufhe_amd_ps_get_params": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(PsParams)]),
     "cufhe_amd_ps_initialize": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),

@@ -462,6 +462,22 @@ void staging_hold(DeviceState& s, PinnedBlock* blk, bool held)
     std::lock_guard<std::mutex> lk(s.staging_mu);
     blk->held = held;
 }
+// The owner of a block between acquire_staging and staging_done_after.  A failing HIP call in between returns early: without this
+// guard the block would stay busy and unrecorded for ever (a pinned-memory leak, and every later call would allocate a new block).
+// On that path the device may still be reading or writing the block, so it is handed back only after the device has drained.
+struct StagingOwner {
+    DeviceState& s;
+    PinnedBlock* b;
+    bool ok = false;
+    void recorded() { ok = true; }
+    ~StagingOwner()
+    {
+        if (!ok) (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(s.staging_mu);
+        b->held = false;
+        if (!ok) { b->busy = false; b->recorded = false; }
+    }
+};
 
 template <class Desc>
 int upload_descs(DeviceState& s, Scratch& sc, const std::vector<Desc>& h, Desc** d)
@@ -472,9 +488,12 @@ int upload_descs(DeviceState& s, Scratch& sc, const std::vector<Desc>& h, Desc**
     if (int rc = sc.alloc((void**)d, bytes)) return rc;
     PinnedBlock* blk = nullptr;
     if (int rc = acquire_staging(s, bytes, &blk)) return rc;
+    StagingOwner owner{s, blk};
     memcpy(blk->host, h.data(), bytes);
     HIP_TRY(hipMemcpyAsync(*d, blk->host, bytes, hipMemcpyHostToDevice, sc.st));
-    return staging_done_after(s, blk, sc.st);
+    if (int rc = staging_done_after(s, blk, sc.st)) return rc;
+    owner.recorded();
+    return 0;
 }
 
 // HIP events around a launch sequence on its own stream (cufhe_amd_profile_enable): begin before, end after
@@ -647,7 +666,11 @@ int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lv
 template <class GetGate>
 int run_gates_ps(int set, int device, void* stream, int level, size_t count, GetGate get);   // paramsets.inc.h
 int ps_ctxt_words(int set, int level);
+// a TRGSW holder's device slot (ciphertext handle of level 3) fits the NTT-domain TRGSW of every compiled set, key limbs included
+template <class PS> constexpr int kTrgswNttWordsOf = (int)(2 * PsDims<PS>::bk_ntt_step_doubles);
+constexpr int kMaxTrgswNttWords = std::max({(int)(2 * kBkStepDoubles), kTrgswNttWordsOf<PsDefault>, kTrgswNttWordsOf<PsK2N512>, kTrgswNttWordsOf<PsCggi16>});
 int run_trlwe_ops_ps(int set, int device, void* stream, const GateRef* g, size_t n);         // paramsets.inc.h
+int ps_trgsw_to_ntt_host(int set, int device, void* stream, const uint32_t* trgsw_host, double* trgsw_ntt_host);
 // >= 0: the per-gate API (both ciphertext levels, both gate orders) runs on this compiled parameter set -- the reference's build-time
 // choice (CMakeLists.txt:8-24) serves every entry point the same way; ciphertexts then have the set's sizes (cufhe_amd_ctxt_words)
 long g_param_set = -1;
@@ -1022,7 +1045,11 @@ int cufhe_amd_stream_destroy(int device, void* stream)
     }
     {
         std::lock_guard<std::mutex> lk(g_sched_mu);
-        if (g_scheduler && device < g_scheduler->gpu_num()) g_scheduler->dev(device).forget_stream(stream);
+        if (g_scheduler && device < g_scheduler->gpu_num()) {
+            (void)g_scheduler->dev(device).retire_external_stream(stream);      // no queued launch may still name the raw handle
+            g_scheduler->dev(device).forget_stream(stream);
+            if (device < (int)g_sched_backends.size()) g_sched_backends[device]->forget_caller_stream(stream);
+        }
     }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return device_fault(device);      // the workspace release above may have waited for the stream
@@ -1045,6 +1072,10 @@ int cufhe_amd_stream_query(int device, void* stream)
 int cufhe_amd_stream_synchronize(int device, void* stream)
 {
     if (int rc = use_device(device)) return rc;
+    if (sched_active()) {       // what was recorded on the stream through the per-gate API: launched, complete, delivered to the tlwehosts
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        if (int rc = g_scheduler->dev(device).stream_synchronize(stream)) return sched_error(g_scheduler->dev(device), rc);
+    }
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return device_fault(device);
 }
@@ -1194,6 +1225,7 @@ int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_
         if (int rc = ensure_ntt(device)) return rc;
     }
     if (!trgsw_host || !trgsw_ntt_host) return fail(-1, "null pointer");
+    if (g_param_set >= 0) return ps_trgsw_to_ntt_host((int)g_param_set, device, stream, trgsw_host, trgsw_ntt_host);     // the active set's sizes and limbs
     DeviceState& s = g_dev[device];
     hipStream_t st = (hipStream_t)stream;
     // torus words in, NTT-domain doubles out: both staged in the stream's grow-only workspace and in recycled pinned
@@ -1208,8 +1240,8 @@ int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_
     if (int rc = sc.alloc((void**)&d_out, out_bytes)) return rc;
     PinnedBlock* blk = nullptr;
     if (int rc = acquire_staging(s, in_bytes + out_bytes, &blk)) return rc;
+    StagingOwner owner{s, blk};          // releases `held`; hands the block back if a call below fails before the event is recorded
     staging_hold(s, blk, true);          // the host reads the result out of the block after the stream has finished with it
-    struct Release { DeviceState& s; PinnedBlock* b; ~Release() { staging_hold(s, b, false); } } release{s, blk};
     memcpy(blk->host, trgsw_host, in_bytes);
     HIP_TRY(hipMemcpyAsync(d_in, blk->host, in_bytes, hipMemcpyHostToDevice, st));
     const unsigned blocks = (unsigned)((kBkPolysPerStep + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
@@ -1219,6 +1251,7 @@ int cufhe_amd_trgsw_to_ntt_host(int device, void* stream, const uint32_t* trgsw_
     char* pin_out = (char*)blk->host + in_bytes;
     HIP_TRY(hipMemcpyAsync(pin_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     if (int rc = staging_done_after(s, blk, st)) return rc;
+    owner.recorded();
     HIP_TRY(hipStreamSynchronize(st));
     memcpy(trgsw_ntt_host, pin_out, out_bytes);
     return device_fault(device);

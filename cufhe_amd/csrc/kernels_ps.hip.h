@@ -749,6 +749,87 @@ __global__ __launch_bounds__(256) void sample_extract_ps_kernel(const LinDesc* _
 }
 
 // ----------------------------------------------------------------------------------------------
+// CMUXNTT on a set (__CMUXNTT__, src/bootstrap_gpu.cu:197-285; TRLWESubAndDecomposition :162-195): res = c0 + trgsw [x] (c1 - c0),
+// one wave per CMUX, operands through descriptors (what the stream scheduler launches for the CMUXNTT calls of one dependence
+// level).  trgsw_ntt is one "step" of bk_to_ntt_ps_kernel's layout: [limb, HIGH first][row][out][R/2][64][2] doubles -- what
+// TRGSW2NTT on the set writes (the reference's template runs on whatever lvl1param the build selected, :75-94).  A set with key
+// limbs walks the rows once per limb; each limb's exact sum is lifted, shifted and added mod 2^32.  res may be c0 or c1: both are
+// read in full before the first word of res is written.
+// ----------------------------------------------------------------------------------------------
+template <class PS>
+__global__ __launch_bounds__(kNttThreads) void cmux_desc_ps_kernel(const CmuxDesc* __restrict__ descs, int count,
+                                                                   const typename Poly<PS::Nbit>::Tables* __restrict__ gt)
+{
+    using D = PsDims<PS>;
+    using PO = Poly<PS::Nbit>;
+    constexpr int N = D::N, R = D::R, K1 = D::K1;
+    static_assert(!PS::small_modulus, "the reference's small-modulus build has no CMUXNTT (src/cufhe_gates_gpu.cu:68-86)");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PO::load_tables(smem, gt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * kNttWavesPerBlock + wave;
+    if (g >= count) return;
+    const typename PO::Ctx ctx = PO::ctx(smem, PO::table_bytes + wave * PO::tile_bytes, 0, gt, lane);
+    const CmuxDesc d = descs[g];
+    uint32_t temp[K1][R], resw[K1][R];
+#pragma unroll
+    for (int j = 0; j < K1; j++)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int e = j * N + lane + 64 * r;
+            const uint32_t a0 = d.c0[e];
+            resw[j][r] = a0;
+            temp[j][r] = (d.c1[e] - a0 + ps_decomp_offset<PS>()) ^ ps_decomp_signmask<PS>();
+        }
+#pragma unroll 1
+    for (int slot = 0; slot < PS::limbs; slot++) {          // storage order: the highest limb first
+        const int limb = PS::limbs - 1 - slot;
+        double A[K1][R];
+#pragma unroll
+        for (int o = 0; o < K1; o++)
+#pragma unroll
+            for (int r = 0; r < R; r++) A[o][r] = 0.0;
+#pragma unroll
+        for (int j = 0; j < K1; j++) {
+#pragma unroll 1
+            for (int dg = 0; dg < PS::l; dg++) {
+                const uint32_t pos = 32 - (dg + 1) * PS::Bgbit;
+                double x[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = (double)(int32_t)__builtin_amdgcn_sbfe(temp[j][r], pos, (uint32_t)PS::Bgbit);
+                PO::forward(x, ctx);
+#pragma unroll
+                for (int r = 0; r < R; r++) x[r] = fpf::reduce(x[r]);
+                // (k+1) l narrow products of reduced factors per sum: below 2^53 unreduced (PsDims: ROWS * after_mulmod(0.5001) < LIM_WIDE)
+                const double2* row = (const double2*)d.trgsw_ntt + ((size_t)(slot * D::ROWS + j * PS::l + dg) * K1) * (N / 2) + lane;
+#pragma unroll
+                for (int o = 0; o < K1; o++)
+#pragma unroll
+                    for (int q = 0; q < R / 2; q++) {
+                        const double2 b = row[(size_t)o * (N / 2) + q * 64];
+                        A[o][2 * q] += fpf::mulmod(x[2 * q], b.x);
+                        A[o][2 * q + 1] += fpf::mulmod(x[2 * q + 1], b.y);
+                    }
+            }
+        }
+        const int shl = limb * PS::limb_bits;
+#pragma unroll
+        for (int o = 0; o < K1; o++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) A[o][r] = fpf::reduce(A[o][r]);
+            PO::inverse(A[o], ctx);
+#pragma unroll
+            for (int r = 0; r < R; r++) resw[o][r] += ps_lift<PS>(A[o][r]) << shl;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K1; j++)
+#pragma unroll
+        for (int r = 0; r < R; r++) d.res[j * N + lane + 64 * r] = resw[j][r];
+}
+
+// ----------------------------------------------------------------------------------------------
 // Key switch lvl1 -> lvl0 with the linear pre-add fused (include/keyswitch_gpu.cuh:83-188), one
 // workgroup (16 waves) per ciphertext: wave w takes a'_j for j in [w kN/16, (w+1) kN/16), lane L the output
 // words L, L + 64, ...; rows straight from L2; the 16 partial sums are added through LDS.

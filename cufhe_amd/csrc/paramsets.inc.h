@@ -207,8 +207,20 @@ int run_gates_ps(int set, int device, void* stream, int level, size_t count, Get
 
 // The TRLWE-level operations of the per-gate API on a set (run_trlwe_ops, capi.hip, over PS): lvl0 TLWE -> TRLWE
 // (__BlindRotateGlobal__, src/bootstrap_gpu.cu:317-323), TRLWE -> TRLWE (__SEIandBootstrap2TRLWE__, :325-364), TRLWE -> lvl0 TLWE
-// (__SEIandKS__, src/keyswitch_gpu.cu:26-40) as one launch sequence.  CMUXNTT stays with the BASELINE set -- the reference's
-// small-modulus build leaves it out as well (src/cufhe_gates_gpu.cu:68-86).
+// (__SEIandKS__, src/keyswitch_gpu.cu:26-40) as one launch sequence, and the CMUXNTT calls of the level (src/bootstrap_gpu.cu:197-285:
+// in the reference the set chosen at build time serves them too; only its small-modulus build leaves them out, src/cufhe_gates_gpu.cu:68-86).
+template <class PS>
+int ps_launch_cmux(DeviceState& s, hipStream_t st, const CmuxDesc* d, size_t count)
+{
+    using PO = Poly<PS::Nbit>;
+    if (count == 0) return 0;
+    const unsigned blocks = (unsigned)((count + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(cmux_desc_ps_kernel<PS>, dim3(blocks), dim3(kNttThreads), PO::table_bytes + kNttWavesPerBlock * PO::tile_bytes, st, d,
+                       (int)count, ps_tables<PS>(s));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <class PS>
 int ps_run_trlwe_ops(int set, int device, void* stream, const GateRef* g, size_t n)
 {
@@ -216,24 +228,42 @@ int ps_run_trlwe_ops(int set, int device, void* stream, const GateRef* g, size_t
     if (int rc = use_device(device)) return rc;
     DeviceState& s = g_dev[device];
     PsState& ps = ps_state(set, device);
-    if (!ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     constexpr size_t trlwe_words = (size_t)D::K1 * D::N;
-    size_t n_se = 0, n_rot = 0, n_t0 = 0;
+    size_t n_se = 0, n_rot = 0, n_t0 = 0, n_cmux = 0;
     for (size_t i = 0; i < n; i++) {
         if (!g[i].out || !g[i].in0) return fail(-1, "null operand");
         switch (g[i].op) {
             case CUFHE_AMD_TL_BOOTSTRAP: n_rot++; break;
             case CUFHE_AMD_TL_REFRESH: n_se++; n_rot++; n_t0++; break;
             case CUFHE_AMD_TL_SEIKS: n_se++; break;
-            case CUFHE_AMD_TL_CMUX: return fail(-1, "CMUXNTT runs on the BASELINE parameter set only");
+            case CUFHE_AMD_TL_CMUX:
+                if (PS::small_modulus) return fail(-1, "CMUXNTT: the small-modulus build of the reference has none (src/cufhe_gates_gpu.cu:68-86)");
+                if (!g[i].in1 || !g[i].in2) return fail(-1, "CMUXNTT: null operand");
+                n_cmux++;
+                break;
             default: return fail(-1, "unknown TRLWE-level op");
         }
     }
+    if (n_cmux < n && !ps.ready) return fail(-3, "cufhe_amd_ps_initialize has not been called for this parameter set and device");
+    if (n_cmux && !s.ntt_ready) return fail(-3, "Initialize() has not been called for this device");
     Scratch sc;
-    if (int rc = open_scratch(s, st, (n_se * D::lvl1_words + n_t0 * D::lvl0_words + n_rot * trlwe_words) * 4 + (3 * n + 8) * sizeof(LinDesc) + 16384, &sc))
+    if (int rc = open_scratch(s, st, (n_se * D::lvl1_words + n_t0 * D::lvl0_words + n_rot * trlwe_words) * 4 + (3 * n + 8) * sizeof(LinDesc) +
+                                         n_cmux * sizeof(CmuxDesc) + 16384, &sc))
         return rc;
+    if (n_cmux) {      // the CMUXNTT calls of this level: independent of its other operations (the scheduler's contract); needs no key
+        if constexpr (!PS::small_modulus) {
+            std::vector<CmuxDesc> cm;
+            cm.reserve(n_cmux);
+            for (size_t i = 0; i < n; i++)
+                if (g[i].op == CUFHE_AMD_TL_CMUX) cm.push_back({g[i].in0, g[i].in1, g[i].out, (const double*)g[i].in2});
+            CmuxDesc* dcm;
+            if (int rc = upload_descs(s, sc, cm, &dcm)) return rc;
+            if (int rc = ps_launch_cmux<PS>(s, st, dcm, cm.size())) return rc;
+        }
+        if (n_cmux == n) return 0;
+    }
     uint32_t *t1 = nullptr, *t0 = nullptr, *dump = nullptr;
     if (n_se) if (int rc = sc.alloc((void**)&t1, n_se * D::lvl1_words * 4)) return rc;
     if (n_t0) if (int rc = sc.alloc((void**)&t0, n_t0 * D::lvl0_words * 4)) return rc;
@@ -241,6 +271,7 @@ int ps_run_trlwe_ops(int set, int device, void* stream, const GateRef* g, size_t
     std::vector<LinDesc> se, ks, rot, scat;
     size_t i_se = 0, i_t0 = 0, i_rot = 0;
     for (size_t i = 0; i < n; i++) {
+        if (g[i].op == CUFHE_AMD_TL_CMUX) continue;
         if (g[i].op == CUFHE_AMD_TL_BOOTSTRAP) {
             rot.push_back({g[i].in0, g[i].in0, nullptr, 1, 0, 0u, 0u});
         } else {
@@ -276,16 +307,55 @@ int run_trlwe_ops_ps(int set, int device, void* stream, const GateRef* g, size_t
     return ps_dispatch(set, [&](auto psx) { return ps_run_trlwe_ops<decltype(psx)>(set, device, stream, g, n); });
 }
 
-// words of a level-0 / level-1 ciphertext or (level 2) a TRLWE of a set
+// words of a level-0 / level-1 ciphertext, (level 2) a TRLWE or (level 3) a TRGSW in the NTT domain (uint32 words: two per double) of a set
 int ps_ctxt_words(int set, int level)
 {
     int w = 0;
     (void)ps_dispatch(set, [&](auto psx) {
         using D = PsDims<decltype(psx)>;
-        w = level == 2 ? D::K1 * D::N : level ? D::lvl1_words : D::lvl0_words;
+        w = level == 3 ? (int)(2 * D::bk_ntt_step_doubles) : level == 2 ? D::K1 * D::N : level ? D::lvl1_words : D::lvl0_words;
         return 0;
     });
     return w;
+}
+
+// TRGSW2NTT on host memory over a set (cufhe_amd_trgsw_to_ntt_host while "param_set" is active): the same staging as the BASELINE
+// path, the set's sizes and key-conversion kernel (limbs included)
+int ps_trgsw_to_ntt_host(int set, int device, void* stream, const uint32_t* trgsw_host, double* trgsw_ntt_host)
+{
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        using PO = Poly<PS::Nbit>;
+        if (PS::small_modulus) return fail(-1, "TRGSW2NTT: the small-modulus build of the reference has none (src/bootstrap_gpu.cu:73-95)");
+        DeviceState& s = g_dev[device];
+        hipStream_t st = (hipStream_t)stream;
+        constexpr size_t in_bytes = D::bk_step_polys * D::N * sizeof(uint32_t), out_bytes = D::bk_ntt_step_doubles * sizeof(double);
+        Scratch sc;
+        if (int rc = open_scratch(s, st, in_bytes + out_bytes + 4096, &sc)) return rc;
+        uint32_t* d_in;
+        double* d_out;
+        if (int rc = sc.alloc((void**)&d_in, in_bytes)) return rc;
+        if (int rc = sc.alloc((void**)&d_out, out_bytes)) return rc;
+        PinnedBlock* blk = nullptr;
+        if (int rc = acquire_staging(s, in_bytes + out_bytes, &blk)) return rc;
+        StagingOwner owner{s, blk};
+        staging_hold(s, blk, true);          // the host reads the result out of the block after the stream has finished with it
+        memcpy(blk->host, trgsw_host, in_bytes);
+        HIP_TRY(hipMemcpyAsync(d_in, blk->host, in_bytes, hipMemcpyHostToDevice, st));
+        const size_t waves = D::bk_step_polys * PS::limbs;
+        hipLaunchKernelGGL(bk_to_ntt_ps_kernel<PS>, dim3((unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock)), dim3(kNttThreads),
+                           PO::table_bytes + kNttWavesPerBlock * PO::tile_bytes, st, d_out, d_in, (size_t)D::bk_step_polys, ps_tables<PS>(s),
+                           balanced(powmod_u64(D::N, fpf::P_U64 - 2)));
+        HIP_TRY(hipGetLastError());
+        char* pin_out = (char*)blk->host + in_bytes;
+        HIP_TRY(hipMemcpyAsync(pin_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        if (int rc = staging_done_after(s, blk, st)) return rc;
+        owner.recorded();
+        HIP_TRY(hipStreamSynchronize(st));
+        memcpy(trgsw_ntt_host, pin_out, out_bytes);
+        return device_fault(device);
+    });
 }
 
 void ps_release(int device)
@@ -373,6 +443,39 @@ int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const 
     });
 }
 
+/* The reference has ONE selector for its parameters: TFHEpp's macro fixes the numbers and every kernel is a template over them
+ * (CMakeLists.txt:8-24, include/bootstrap_gpu.cuh:51-53).  Here the caller hands over the numbers it was compiled with and the
+ * library picks the compiled set that has exactly those -- key SIZES alone do not see Bgbit, and t * 2^(basebit-1) is 16 for both
+ * (8, 2) and (4, 3). */
+int cufhe_amd_find_param_set(const cufhe_amd_param_numbers* q)
+{
+    if (!q) return fail(-1, "null");
+    for (int set = 0; set < kParamSets; set++) {
+        cufhe_amd_ps_params p;
+        if (cufhe_amd_ps_get_params(set, &p)) continue;
+        if (p.n == q->n && p.nbit == q->nbit && p.k == q->k && p.l == q->l && p.Bgbit == q->Bgbit && p.t == q->t && p.basebit == q->basebit &&
+            p.small_ntt_modulus == q->small_ntt_modulus)
+            return set;
+    }
+    char buf[320];
+    snprintf(buf, sizeof buf, "no compiled parameter set has n=%u nbit=%u k=%u l=%u Bgbit=%u t=%u basebit=%u small_ntt_modulus=%u "
+             "(cufhe_amd_ps_get_params lists the compiled sets)", q->n, q->nbit, q->k, q->l, q->Bgbit, q->t, q->basebit, q->small_ntt_modulus);
+    return fail(-1, buf);
+}
+
+int cufhe_amd_initialize_params(const cufhe_amd_param_numbers* numbers, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words)
+{
+    const int set = cufhe_amd_find_param_set(numbers);
+    if (set < 0) return set;
+    if (set == 0) {        // the BASELINE numbers: the hand-scheduled kernels
+        if (int rc = cufhe_amd_initialize(bk, bk_words, ksk, ksk_words)) return rc;
+        return cufhe_amd_set_option("param_set", -1);
+    }
+    if (int rc = cufhe_amd_initialize_ntt()) return rc;
+    if (int rc = cufhe_amd_ps_initialize(set, bk, bk_words, ksk, ksk_words)) return rc;
+    return cufhe_amd_set_option("param_set", set);
+}
+
 int cufhe_amd_ps_gate_batch_level(int set, int device, void* stream, int level, size_t count, const int32_t* ops, int ops_stride,
                                   uint32_t* out, const uint32_t* in0, const uint32_t* in1, const uint32_t* in2, size_t stride_words)
 {
@@ -423,6 +526,62 @@ int cufhe_amd_ps_trlwe_op_batch(int set, int device, void* stream, int op, size_
     std::vector<GateRef> g(count);
     for (size_t i = 0; i < count; i++) g[i] = GateRef{op, out + i * wout, in + i * win, nullptr, nullptr};
     return run_trlwe_ops_ps(set, device, stream, g.data(), count);
+}
+
+/* TRGSW2NTT / CMUXNTT on a set, device-resident (src/bootstrap_gpu.cu:75-94,197-285 instantiated for the set the build selected):
+ * trgsw[count][(k+1)l][k+1][N] torus words -> trgsw_ntt[count][limbs][(k+1)l][k+1][N] doubles; res = c0 + trgsw [x] (c1 - c0) on
+ * TRLWEs [count][(k+1)N].  Needs Initialize() only. */
+int cufhe_amd_ps_trgsw_to_ntt_batch(int set, int device, void* stream, size_t count, const uint32_t* trgsw, double* trgsw_ntt)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (!trgsw || !trgsw_ntt) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        using PO = Poly<PS::Nbit>;
+        if (PS::small_modulus) return fail(-1, "TRGSW2NTT: the small-modulus build of the reference has none (src/bootstrap_gpu.cu:73-95)");
+        const size_t polys = count * D::bk_step_polys, waves = polys * PS::limbs;
+        hipLaunchKernelGGL(bk_to_ntt_ps_kernel<PS>, dim3((unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock)), dim3(kNttThreads),
+                           PO::table_bytes + kNttWavesPerBlock * PO::tile_bytes, (hipStream_t)stream, trgsw_ntt, trgsw, polys,
+                           ps_tables<PS>(g_dev[device]), balanced(powmod_u64(D::N, fpf::P_U64 - 2)));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    });
+}
+
+int cufhe_amd_ps_cmux_batch(int set, int device, void* stream, size_t count, const double* trgsw_ntt, const uint32_t* c1,
+                            const uint32_t* c0, uint32_t* res)
+{
+    if (int rc = use_device(device)) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ntt(device)) return rc;
+    }
+    if (!trgsw_ntt || !c1 || !c0 || !res) return fail(-1, "null pointer");
+    if (count == 0) return 0;
+    return ps_dispatch(set, [&](auto psx) -> int {
+        using PS = decltype(psx);
+        using D = PsDims<PS>;
+        if constexpr (PS::small_modulus) {
+            return fail(-1, "CMUXNTT: the small-modulus build of the reference has none (src/cufhe_gates_gpu.cu:68-86)");
+        } else {
+            DeviceState& s = g_dev[device];
+            hipStream_t st = (hipStream_t)stream;
+            constexpr size_t tw = (size_t)D::K1 * D::N;
+            std::vector<CmuxDesc> cm(count);
+            for (size_t g = 0; g < count; g++) cm[g] = {c1 + g * tw, c0 + g * tw, res + g * tw, trgsw_ntt + g * D::bk_ntt_step_doubles};
+            Scratch sc;
+            if (int rc = open_scratch(s, st, count * sizeof(CmuxDesc) + 4096, &sc)) return rc;
+            CmuxDesc* d;
+            if (int rc = upload_descs(s, sc, cm, &d)) return rc;
+            return ps_launch_cmux<PS>(s, st, d, count);
+        }
+    });
 }
 
 int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1, uint32_t* tlwe0)

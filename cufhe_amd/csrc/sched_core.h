@@ -45,6 +45,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace cufhe_amd {
@@ -95,6 +96,13 @@ class Backend {
     // the address under which the device reads / writes a block from alloc_pinned directly, or nullptr if it cannot: the scheduler
     // then skips the staging copies (h2d / d2h) and lets copy_ctxts work on the pinned block itself
     virtual void* device_alias(void* /*pinned*/) { return nullptr; }
+    // The CALLER's own stream (the raw handle the reference hands out as Stream::st(), include/cufhe_gpu.cuh:183).  In the reference a
+    // gate IS enqueued on that stream (src/cufhe_gates_gpu.cu:148-167), so whatever the caller puts on it afterwards runs behind the
+    // gate and whatever it put there before runs ahead of it; here gates run on internal streams, and these two calls restore that
+    // order when the caller asks for the handle (DeviceSched::stream_fence): the caller's stream waits for one of our events /
+    // internal stream `s` waits for everything the caller's stream holds now.
+    virtual int caller_stream_wait(void* /*caller_stream*/, void* /*ev*/) { return 0; }
+    virtual int wait_for_caller_stream(int /*s*/, void* /*caller_stream*/) { return 0; }
     virtual void* mark(int /*s*/) { return nullptr; }
     virtual float elapsed_ms(void* /*a*/, void* /*b*/) { return 0.0f; }
 };
@@ -132,6 +140,11 @@ struct cufhe_amd_ctxt {
         uint32_t* home = nullptr;
         std::vector<uint32_t> home_deps;
         void* wstream = nullptr;    // caller stream of the newest recorded gate write (completion of that stream must cover the copy back)
+        // caller stream(s) that (re-)uploaded the value SINCE that write (CtxtCopyH2D / a non-g gate's input, recorded or recognised as
+        // already there): completion observed on any of them, too, must find the value in the home buffer
+        void* ustream = nullptr;
+        bool umany = false;         // more than one such stream: every completion restores
+        void note_upload_stream(void* st) { if (!ustream) ustream = st; else if (ustream != st) umany = true; }
         int renamed_idx = -1;       // position in DeviceSched::renamed_
         uint32_t ready = 0;         // depth from which a gate may read `dev` (0: resident since long)
         uint32_t wdepth = 0;        // depth of the newest recorded write of `dev` (0: none on record)
@@ -162,6 +175,8 @@ struct cufhe_amd_ctxt {
     int host_dev = -1;
     uint64_t host_version = 0;
     uint64_t host_token = 0;
+    void* host_stream = nullptr;    // ... recorded on this caller stream,
+    uint32_t host_epoch = 0;        // whose raw handle had been handed out this often by then (DeviceSched::stream_fence)
     std::vector<PerDev> d;
 };
 
@@ -250,6 +265,7 @@ struct Group {                        // consecutive levels flushed together
     GroupTrace trace;
     void* marks[4] = {nullptr, nullptr, nullptr, nullptr};
     bool zero_copy_in = false, zero_copy_out = false;     // dev_in / dev_out alias the pinned blocks: nothing to recycle
+    std::vector<void*> ext_waits;     // caller streams whose own work (enqueued through the raw handle) this group must follow
 };
 
 class Scheduler;
@@ -303,11 +319,31 @@ class DeviceSched {
     }
     int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
     int synchronize();
+    // Stream::st() of the reference hands the caller the stream its gates were ENQUEUED on (include/cufhe_gpu.cuh:183,
+    // src/cufhe_gates_gpu.cu:148-167).  stream_fence gives the raw handle the same meaning at the moment it is handed out: everything
+    // recorded on `stream` is launched (values written on it return to their ciphertexts' own buffers first), the caller's stream is made
+    // to wait for those launches, and from now on work recorded on `stream` waits for what the caller has put on the raw stream.
+    int stream_fence(void* stream);
+    // cudaStreamSynchronize(st.st()) of the reference: returns when everything issued on `stream` is complete AND delivered
+    int stream_synchronize(void* stream);
+    bool is_external(void* stream) const { return ext_streams_.count(stream) != 0; }
     void forget_stream(void* stream)
     {
         streams_.erase(stream);
         cached_stream_ = nullptr;
         cached_ss_ = nullptr;
+    }
+    // the caller destroys its stream: no queued launch may still name the raw handle
+    int retire_external_stream(void* stream)
+    {
+        if (!ext_streams_.count(stream)) return 0;
+        int rc = 0;
+        auto it = streams_.find(stream);
+        if (it != streams_.end() && it->second.max_depth >= base_depth_) rc = flush();
+        wait_worker_idle();
+        ext_streams_.erase(stream);
+        fence_epoch_.erase(stream);
+        return rc;
     }
     // returns once no launch thread of this device is in the middle of reading tlwehost memory
     void copy_fence() { std::lock_guard<std::mutex> lk(copy_mu_); }
@@ -512,7 +548,7 @@ class DeviceSched {
         }
         return true;
     }
-    int resolve_host(cufhe_amd_ctxt* c, bool* need_upload);
+    int resolve_host(cufhe_amd_ctxt* c, bool* need_upload, void* stream);
     void record_upload(cufhe_amd_ctxt* c, void* stream);
     int after_record();
     int launch(Group* g);                       // worker (or inline): submit the group's work
@@ -542,6 +578,14 @@ class DeviceSched {
     std::deque<Plan*> levels_;
     size_t pending_gates_ = 0;
     std::unordered_map<void*, StreamState> streams_;
+    std::unordered_set<void*> ext_streams_;     // caller streams whose raw handle has been handed out (stream_fence)
+    std::unordered_map<void*, uint32_t> fence_epoch_;      // ... and how often
+    uint32_t fence_epoch(void* stream) const
+    {
+        if (fence_epoch_.empty()) return 0;
+        auto it = fence_epoch_.find(stream);
+        return it == fence_epoch_.end() ? 0 : it->second;
+    }
     void* cached_stream_ = nullptr;
     StreamState* cached_ss_ = nullptr;
     std::vector<Plan*> plan_pool_;              // retired levels, vectors keep their capacity
@@ -763,11 +807,14 @@ inline void DeviceSched::release_buffers()
 // device in stream order.  If an earlier result is still travelling to that `tlwehost`, the value
 // is that result: it is the device buffer itself when nothing overwrote the buffer since (the
 // normal chain Nand(c, ..) ; Or(d, c, ..)); otherwise the host copy has to land first.
-inline int DeviceSched::resolve_host(cufhe_amd_ctxt* c, bool* need_upload)
+inline int DeviceSched::resolve_host(cufhe_amd_ctxt* c, bool* need_upload, void* stream)
 {
     cufhe_amd_ctxt::PerDev& pd = c->d[device_];
     if (c->host_dev >= 0) {
-        if (c->host_dev == device_ && c->host_version == pd.version) {
+        // (the device buffer stands for the travelling result only while the caller cannot have written it itself through the raw
+        // handle of the stream that produced it: the reference's upload would bring the RESULT back, src/cufhe_gates_gpu.cu:148-158)
+        if (c->host_dev == device_ && c->host_version == pd.version && fence_epoch(c->host_stream) == c->host_epoch) {
+            pd.note_upload_stream(stream);       // the reference would upload here: completion on this stream finds the value in the home buffer
             *need_upload = false;
             return 0;
         }
@@ -779,12 +826,15 @@ inline int DeviceSched::resolve_host(cufhe_amd_ctxt* c, bool* need_upload)
     // is not copied again: shared inputs (test/test_intensive.cc) stay pure reads.  While that upload has
     // not retired the caller cannot have changed the memory (it has not observed completion of the gates
     // reading it); afterwards the words are compared with a copy kept for inputs that were re-used.
-    if (pd.snap_version == pd.version) {
+    // (not while the caller holds a raw stream handle: it may have written the device buffer itself, and the reference's non-g gate
+    // uploads tlwehost whatever the buffer holds)
+    if (pd.snap_version == pd.version && ext_streams_.empty()) {
         const bool same = pd.snap_plan != nullptr ||
                           (pd.snap_owned && c->host && !memcmp(pd.snap_own.data(), c->host, (size_t)be_->words(c->level) * 4));
         if (same) {
             pd.snap_hits++;
             stats_.uploads_shared++;
+            pd.note_upload_stream(stream);       // as far as this stream's completion goes, the value was uploaded here
             *need_upload = false;
             return 0;
         }
@@ -820,6 +870,7 @@ inline void DeviceSched::record_upload(cufhe_amd_ctxt* c, void* stream)
     pd.snap_hits = 0;
     pd.snap_owned = false;
     pd.last_upload = U;
+    pd.note_upload_stream(stream);   // the newest write of the value: completion observed on THIS stream, too, must find it in the home buffer
     note_stream(p, stream, U);       // completion of the stream implies this level has retired: tlwehost may be edited again
     stats_.uploads++;
 }
@@ -838,7 +889,7 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
             for (int j = 0; j < i; j++) seen = seen || ins[j] == ins[i];
             if (seen) continue;
             if (!ins[i]->host) return fail(-1, "gate on a destroyed ciphertext");
-            if (int rc = resolve_host(ins[i], &need_up[i])) return rc;
+            if (int rc = resolve_host(ins[i], &need_up[i], stream)) return rc;
         }
     if (copying)
         if (int rc = owner_->before_host_write(out, device_)) return fail(rc, "scheduler: flushing another device failed");
@@ -910,6 +961,8 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     po.snap_plan = nullptr;
     po.snap_owned = false;
     po.wstream = stream;
+    po.ustream = nullptr;
+    po.umany = false;
     use(po, D);
     p.gates[kind].push_back(GateRef{op, po.dev, in_dev[0], in_dev[1], in_dev[2]});
     if (copying) {
@@ -921,6 +974,8 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
         out->host_dev = device_;
         out->host_version = po.version;
         out->host_token = token;
+        out->host_stream = stream;
+        out->host_epoch = fence_epoch(stream);
         stats_.downloads++;
     }
     note_stream(p, stream, D);
@@ -935,7 +990,7 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
     if (to_device) {     // CtxtCopyH2D, include/cufhe_gpu.cuh:193-199
         if (!c->host) return fail(-1, "copy of a destroyed ciphertext");
         bool need = false;
-        if (int rc = resolve_host(c, &need)) return rc;
+        if (int rc = resolve_host(c, &need, stream)) return rc;
         if (need) record_upload(c, stream);
         return 0;
     }
@@ -954,6 +1009,8 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
     c->host_dev = device_;
     c->host_version = pd.version;
     c->host_token = token;
+    c->host_stream = stream;
+    c->host_epoch = fence_epoch(stream);
     stats_.downloads++;
     note_stream(p, stream, D);
     return 0;
@@ -967,7 +1024,7 @@ inline int DeviceSched::restore_homes(void* only_stream)
     for (size_t k = 0; k < renamed_.size();) {
         cufhe_amd_ctxt* c = renamed_[k];
         cufhe_amd_ctxt::PerDev& pd = c->d[device_];
-        if (only_stream && pd.wstream != only_stream) { k++; continue; }
+        if (only_stream && !pd.umany && pd.wstream != only_stream && pd.ustream != only_stream) { k++; continue; }
         uint32_t D = std::max(base_depth_, pd.ready);
         D = std::max(D, max_depth_of(pd.home_deps) + 1);
         Plan& p = plan_at(D);
@@ -983,6 +1040,7 @@ inline int DeviceSched::restore_homes(void* only_stream)
         clear_readers(pd);
         pd.last_use = D;
         note_stream(p, pd.wstream, D);
+        if (pd.ustream) note_stream(p, pd.ustream, D);
         pending_gates_++;
         stats_.home_copies++;
         forget_renamed(c);             // swaps the last entry into k
@@ -1062,6 +1120,10 @@ inline int DeviceSched::flush(size_t max_levels)
             StreamState& ss = streams_[st];
             if (ss.open.empty() || ss.open.back() != g->id) ss.open.push_back(g->id);
         }
+    if (!ext_streams_.empty())
+        for (Plan* p : g->plans)
+            for (void* st : p->streams)
+                if (ext_streams_.count(st) && std::find(g->ext_waits.begin(), g->ext_waits.end(), st) == g->ext_waits.end()) g->ext_waits.push_back(st);
     g->done = std::make_shared<EventHolder>(be_);
     g->trace.id = g->id;
     g->trace.levels = (uint32_t)k;
@@ -1126,6 +1188,8 @@ inline int DeviceSched::launch(Group* g)
     step(be_->event_create(&g->done->ev));
     for (auto& e : g->deps)
         if (e->ev && rc == 0) step(be_->stream_wait(s, e->ev));
+    for (void* cs : g->ext_waits)
+        if (rc == 0) step(be_->wait_for_caller_stream(s, cs));
     g->marks[0] = be_->mark(s);
     // Staging.  A backend whose pinned memory is visible to the device (device_alias) needs no copy engine at all: the scatter
     // kernel reads the pinned block over the bus and the gather kernel writes the results straight into it (zero_copy).  The
@@ -1346,6 +1410,58 @@ inline int DeviceSched::stream_query(void* stream)
     }
     forget_stream(stream);
     return 1;
+}
+
+inline int DeviceSched::stream_fence(void* stream)
+{
+    ext_streams_.insert(stream);
+    fence_epoch_[stream]++;
+    if (streams_.find(stream) == streams_.end()) return 0;      // nothing of this stream is recorded or in flight
+    restore_homes(stream);
+    StreamState& ss = streams_[stream];
+    if (ss.max_depth >= base_depth_)
+        if (int rc = flush()) return rc;
+    wait_worker_idle();                                          // every flushed group is submitted: its completion event is recorded
+    be_->bind_thread();
+    for (uint64_t id : ss.open) {
+        Group* g = nullptr;
+        for (Group* x : live_)
+            if (x->id == id) g = x;
+        if (!g || g->state.load(std::memory_order_acquire) == 2 || g->error || !g->done->ev) continue;
+        if (int rc = be_->caller_stream_wait(stream, g->done->ev)) return fail(rc, be_->error_text());
+    }
+    return 0;
+}
+
+inline int DeviceSched::stream_synchronize(void* stream)
+{
+    if (streams_.find(stream) == streams_.end()) return 0;
+    restore_homes(stream);
+    {
+        StreamState& ss = streams_[stream];
+        if (ss.max_depth >= base_depth_)
+            if (int rc = flush()) return rc;
+    }
+    wait_worker_idle();
+    be_->bind_thread();
+    int rc = 0;
+    const std::vector<uint64_t> open = streams_[stream].open;     // retire() deletes groups: look each one up afresh
+    for (uint64_t id : open) {
+        Group* g = nullptr;
+        for (Group* x : live_)
+            if (x->id == id) g = x;
+        if (!g || g->state.load(std::memory_order_acquire) == 2) continue;
+        if (g->done->ev && !g->error)
+            if (int r = be_->event_sync(g->done->ev)) {
+                rc = rc ? rc : r;
+                err_ = be_->error_text();
+            }
+        if (int r = retire(g)) rc = rc ? rc : r;
+    }
+    if (sticky_error_ && !rc) rc = sticky_error_;
+    sticky_error_ = 0;
+    forget_stream(stream);
+    return rc;
 }
 
 }  // namespace sched

@@ -65,13 +65,13 @@ class HipBackend : public sched::Backend {
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
     int words(int level) override
     {
-        if (level <= 2 && g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes (2: a TRLWE)
-        return slot_words(level);
+        if (g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes (2: a TRLWE, 3: a TRGSW in the NTT domain)
+        return level == 3 ? (int)(2 * kBkStepDoubles) : slot_words(level);
     }
     // device slots are carved for the largest ciphertext of any compiled set, so "param_set" may change while ciphertexts live
     int slot_words(int level) override
     {
-        return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : level == 2 ? 2 * kN : (int)(2 * kBkStepDoubles);     // 3: TRGSW, NTT domain (doubles)
+        return level == 0 ? kLvl0Words : level == 1 ? kLvl1Words : level == 2 ? 2 * kN : kMaxTrgswNttWords;     // 3: TRGSW, NTT domain (doubles, two words each)
     }
     int alloc_device(size_t bytes, void** p) override { return chk(hipMalloc(p, bytes), "hipMalloc"); }
     int free_device(void* p) override { return chk(hipFree(p), "hipFree"); }
@@ -160,6 +160,36 @@ class HipBackend : public sched::Backend {
         std::lock_guard<std::mutex> lk(mu_);
         return err_;
     }
+    // the caller's own stream (Stream::st()) behind one of our completion events / an internal stream behind the caller's stream
+    int caller_stream_wait(void* caller_stream, void* ev) override
+    {
+        return chk(hipStreamWaitEvent((hipStream_t)caller_stream, (hipEvent_t)ev, 0), "hipStreamWaitEvent (caller's stream)");
+    }
+    int wait_for_caller_stream(int s, void* caller_stream) override
+    {
+        hipStream_t st;
+        if (int rc = stream(s, &st)) return rc;
+        // an event may be re-recorded while an earlier wait on it is pending: that wait keeps the state it captured
+        hipEvent_t e;
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);
+            auto it = caller_ev_.find(caller_stream);
+            if (it == caller_ev_.end()) {
+                if (int rc = chk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return rc;
+                caller_ev_[caller_stream] = e;
+            } else e = it->second;
+        }
+        if (int rc = chk(hipEventRecord(e, (hipStream_t)caller_stream), "hipEventRecord (caller's stream)")) return rc;
+        return chk(hipStreamWaitEvent(st, e, 0), "hipStreamWaitEvent");
+    }
+    void forget_caller_stream(void* caller_stream)
+    {
+        std::lock_guard<std::mutex> lk(st_mu_);
+        auto it = caller_ev_.find(caller_stream);
+        if (it == caller_ev_.end()) return;
+        (void)hipEventDestroy(it->second);
+        caller_ev_.erase(it);
+    }
     // hipHostMalloc memory is mapped into the device's address space: the scatter / gather kernels use it in place
     void* device_alias(void* pinned) override
     {
@@ -202,6 +232,8 @@ class HipBackend : public sched::Backend {
             (void)hipStreamDestroy(st);
         }
         st_.clear();
+        for (auto& kv : caller_ev_) (void)hipEventDestroy(kv.second);
+        caller_ev_.clear();
     }
 
    private:
@@ -238,6 +270,7 @@ class HipBackend : public sched::Backend {
         return 0;
     }
     int device_;
+    std::unordered_map<void*, hipEvent_t> caller_ev_;     // one event per caller stream whose raw handle is out (guarded by st_mu_)
     std::vector<hipStream_t> st_;
     std::mutex mu_, st_mu_;
     std::string err_;
@@ -343,9 +376,9 @@ int cufhe_amd_ctxt_destroy(cufhe_amd_ctxt* c)
 
 int cufhe_amd_ctxt_words(int level)
 {
-    if (level < 0 || level > 2) return fail(-1, "level must be 0, 1 or 2 (a TRLWE)");
+    if (level < 0 || level > 3) return fail(-1, "level must be 0, 1, 2 (a TRLWE) or 3 (a TRGSW in the NTT domain)");
     if (g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);
-    return level == 2 ? 2 * kN : level ? kLvl1Words : kLvl0Words;
+    return level == 3 ? (int)(2 * kBkStepDoubles) : level == 2 ? 2 * kN : level ? kLvl1Words : kLvl0Words;
 }
 
 uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device)
@@ -494,6 +527,17 @@ int cufhe_amd_sched_stream_query(int device, void* stream)
     const int q = g_scheduler->dev(device).stream_query(stream);
     if (q < 0) return sched_error(g_scheduler->dev(device), q);
     return q;
+}
+
+/* Stream::st() (include/cufhe_gpu.cuh:183): the raw handle is about to be handed to the caller */
+int cufhe_amd_stream_fence(int device, void* stream)
+{
+    if (int rc = use_device(device)) return rc;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (!stream) return 0;                       // the default stream is never handed out by class Stream
+    sched::Scheduler* S = scheduler();
+    if (int rc = S->dev(device).stream_fence(stream)) return sched_error(S->dev(device), rc);
+    return 0;
 }
 
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)

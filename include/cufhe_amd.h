@@ -73,7 +73,17 @@ int cufhe_amd_synchronize(void);                        /* Synchronize  cufhe_gp
 int cufhe_amd_stream_create(int device, void** stream);
 int cufhe_amd_stream_destroy(int device, void* stream);
 int cufhe_amd_stream_query(int device, void* stream);   /* 1 = idle, 0 = busy, <0 = error */
+/* cudaStreamSynchronize(st.st()) of a reference program: everything issued on `stream` -- recorded gates included -- is launched,
+ * complete and delivered to the tlwehosts on return. */
 int cufhe_amd_stream_synchronize(int device, void* stream);
+/* What makes the raw handle mean what it means in the reference, where a gate IS enqueued on st.st() at the call
+ * (src/cufhe_gates_gpu.cu:148-167): called when the handle is handed to the caller (Stream::st() of include/cufhe_amd.hpp does).
+ * Everything recorded on `stream` so far is launched -- values it wrote return to the ciphertexts' own buffers (tlwedevices) first --
+ * and the raw stream is made to wait for it: a hipMemcpyAsync / hipEventRecord / hipStreamSynchronize the caller issues on the handle
+ * afterwards is ordered behind those gates; and from now on gates recorded on `stream` wait for what the caller has put on the raw
+ * stream before them (an upload into tlwedevices, a hipStreamWaitEvent).  Host results (tlwehost) are delivered by the completion
+ * calls: cufhe_amd_stream_synchronize / _stream_query / _synchronize. */
+int cufhe_amd_stream_fence(int device, void* stream);
 
 /* ---- ciphertext storage: ctxtInitialize/ctxtDelete include/cufhe_gpu.cuh:76-95,
  *      CtxtCopyH2D/D2H :193-207 ---- */
@@ -250,8 +260,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * register sums, two rotations per CU (launches above one rotation per CU); 0 = eight half-transform waves, one rotation per CU.
  * "param_set" (default -1; "lvl0_param_set" is the same option under its old name): index of a cufhe_amd_ps_* parameter set on
  * which the whole per-gate API runs instead -- both ciphertext levels and both gate orders, and the three bootstrapping TRLWE-level
- * operations of cufhe_amd_enqueue_trlwe_op (CMUXNTT stays with the BASELINE set), as the set chosen when the reference
- * is built serves every entry point (CMakeLists.txt:8-24); cufhe_amd_ps_initialize first.  Ciphertexts then have the set's sizes
+ * operations of cufhe_amd_enqueue_trlwe_op, CMUXNTT and TRGSW2NTT (cufhe_amd_enqueue_cmux / cufhe_amd_trgsw_to_ntt; not on the
+ * small-modulus set, as in the reference), as the set chosen when the reference is built serves every entry point
+ * (CMakeLists.txt:8-24); cufhe_amd_ps_initialize first (cufhe_amd_initialize_params does both).  Ciphertexts then have the set's sizes
  * (cufhe_amd_ctxt_words: n + 1 and k N + 1 words; include/cufhe_amd.hpp selects the matching parameter structs with
  * -DCUFHE_AMD_PARAM_SET_K2N512 / -DCUFHE_AMD_PARAM_SET_CGGI16 / -DCUFHE_AMD_PARAM_SET_SMALLMOD).  Changing it waits for everything
  * recorded; a ciphertext keeps the host buffer of the set it was created under, and using it while a set with other sizes is active is
@@ -327,10 +338,24 @@ typedef struct cufhe_amd_ps_params {
     uint32_t small_ntt_modulus;     /* 0: exact products; P: the set runs the reference's -DUSE_SMALL_NTT_MODULUS arithmetic mod P */
     uint64_t bk_words, ksk_words, bk_ntt_bytes;
 } cufhe_amd_ps_params;
+/* The numbers a caller was compiled with (TFHEpp's lvl0param::n; lvl1param::nbit, k, l, Bgbit; lvl10param::t, basebit) and whether it
+ * was built with the reference's -DUSE_SMALL_NTT_MODULUS (then small_ntt_modulus = 625 * 2^20 + 1, else 0).
+ * cufhe_amd_find_param_set: index of the compiled set with exactly these numbers, or -1 (text names the numbers).
+ * cufhe_amd_initialize_params: Initialize(const EvalKey&) (src/cufhe_gates_gpu.cu:42-47) with the reference's single selector -- the
+ * set is FOUND from the numbers, its keys are loaded on every device and the whole per-gate API runs on it (set 0 takes the
+ * hand-scheduled kernels of cufhe_amd_initialize, the others cufhe_amd_ps_initialize + "param_set").  A caller whose Bgbit, t or
+ * basebit differ from every compiled set is refused here instead of being served by kernels of other numbers that happen to have
+ * keys of the same size.  include/cufhe_amd.hpp calls nothing else, and derives the same match at compile time. */
+typedef struct cufhe_amd_param_numbers {
+    uint32_t n, nbit, k, l, Bgbit, t, basebit, small_ntt_modulus;
+} cufhe_amd_param_numbers;
+int cufhe_amd_find_param_set(const cufhe_amd_param_numbers* numbers);
+int cufhe_amd_initialize_params(const cufhe_amd_param_numbers* numbers, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
 int cufhe_amd_ps_count(void);
 int cufhe_amd_ps_get_params(int set, cufhe_amd_ps_params* out);
 int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const uint32_t* ksk, size_t ksk_words);
-/* words of a level-0 / level-1 ciphertext, or (level 2) of a TRLWE, of the per-gate API as configured now ("param_set") */
+/* words of a level-0 / level-1 ciphertext, (level 2) of a TRLWE or (level 3) of a TRGSW holder in the NTT domain (uint32 words: two per
+ * double; the active set's key limbs included), of the per-gate API as configured now ("param_set") */
 int cufhe_amd_ctxt_words(int level);
 /* the same gates on ciphertexts of `level`: 0 = blind rotate then key switch on n + 1 words, 1 = key switch then blind rotate on
  * k N + 1 words (the reference's two __HomGate__ orders, src/bootstrap_gpu.cu:383-421, Mux :515-588 / :706-780) */
@@ -346,6 +371,13 @@ int cufhe_amd_ps_blind_rotate_batch(int set, int device, void* stream, size_t co
 /* tlwe1[count][kN+1] -> tlwe0[count][n+1] */
 int cufhe_amd_ps_keyswitch_batch(int set, int device, void* stream, size_t count, const uint32_t* tlwe1,
                                  uint32_t* tlwe0);
+/* TRGSW2NTT / CMUXNTT on a set, device-resident (src/bootstrap_gpu.cu:75-94,197-285: in the reference the set chosen at build time
+ * serves them too; the small-modulus set has none, :73-95): trgsw[count][(k+1)l][k+1][N] torus words -> trgsw_ntt[count][key_limbs]
+ * [(k+1)l][k+1][N] doubles (cufhe_amd_ctxt_words(3) / 2 per TRGSW while the set is active); res = c0 + trgsw [x] (c1 - c0) on TRLWEs
+ * [count][(k+1)N], res may be c0 or c1.  Need Initialize() only, like the reference. */
+int cufhe_amd_ps_trgsw_to_ntt_batch(int set, int device, void* stream, size_t count, const uint32_t* trgsw, double* trgsw_ntt);
+int cufhe_amd_ps_cmux_batch(int set, int device, void* stream, size_t count, const double* trgsw_ntt, const uint32_t* c1,
+                            const uint32_t* c0, uint32_t* res);
 /* the bootstrapping TRLWE-level operations on a set, device-resident: op = CUFHE_AMD_TL_BOOTSTRAP (in: tlwe0[count][n+1], out:
  * trlwe[count][(k+1)N]; BootstrapTLWE2TRLWE, src/bootstrap_gpu.cu:806-815), CUFHE_AMD_TL_REFRESH (trlwe -> trlwe; :325-364) or
  * CUFHE_AMD_TL_SEIKS (trlwe -> tlwe0; SEIandKS, src/keyswitch_gpu.cu:26-40) */

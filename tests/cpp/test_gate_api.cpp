@@ -12,6 +12,10 @@
 #include <random>
 #include <vector>
 
+#ifdef CUFHE_AMD_TEST_HIP      // the caller's side of Stream::st(): plain HIP runtime calls on the raw handle (StreamOrdering below)
+#include <hip/hip_runtime_api.h>
+#endif
+
 #include "../../include/cufhe_amd.hpp"
 #include "../../oracle/tfhe_oracle.h"
 #include "../../oracle/tfhe_oracle_lvl2.h"
@@ -171,6 +175,83 @@ void DeviceResident(std::mt19937& eng)
     st.Destroy();
 }
 
+// What Stream::st() means.  In the reference a gate IS enqueued on st.st() at the call (src/cufhe_gates_gpu.cu:148-167,
+// include/cufhe_gpu.cuh:183), so a caller may put its own work on that stream and rely on stream order.  The idioms, word for word
+// against the oracle's gate:
+//   (a) gNand(out, ..); StreamSynchronize(st);                    then a plain copy out of out.tlwedevices[d]
+//   (b) gNand(out, ..); hipMemcpyAsync(host, out.tlwedevices[d], .., st.st()); hipStreamSynchronize(st.st())
+//   (c) hipMemcpyAsync(in.tlwedevices[d], words, .., st.st()); gNand(out, in, ..)   -- the gate runs behind the caller's upload
+//   (d) hipEventRecord(ev, st.st()) after a gate; hipEventSynchronize(ev)         -- the event completes behind the gate
+//   (e) Nand(out, ..); StreamSynchronize(st)                      tlwehost holds the result (cudaStreamSynchronize(st.st()) in the reference)
+void StreamOrdering(std::mt19937& eng)
+{
+    using P = TFHEpp::lvl0param;
+    orc_evalkey* ek = nullptr;
+    {
+        std::vector<uint32_t> bk(ORC_BK_WORDS), ksk(ORC_KSK_WORDS);
+        orc_bkgen(1001, g_s0.data(), g_s1.data(), bk.data());
+        orc_kskgen(2001, g_s0.data(), g_s1.data(), ksk.data());
+        ek = orc_evalkey_create(bk.data(), ksk.data());
+    }
+    int bad = 0, total = 0;
+    Stream st;
+    st.Create();
+    const int d = st.device_id();
+    constexpr size_t kBytes = sizeof(TFHEpp::TLWE<P>);
+    auto want = [&](int op, const TFHEpp::TLWE<P>& x, const TFHEpp::TLWE<P>& y) {
+        TFHEpp::TLWE<P> w{};
+        orc_gate(ek, op, 0, w.data(), x.data(), y.data(), nullptr);
+        return w;
+    };
+    for (int rep = 0; rep < 3; rep++) {
+        Ctxt<P> a, b, out, out2, out3, out4, out5;
+        encrypt(a, eng() & 1); encrypt(b, eng() & 1);
+        CtxtCopyH2D(a, st); CtxtCopyH2D(b, st);
+        // (a)
+        gNand(out, a, b, st);
+        StreamSynchronize(st);
+        TFHEpp::TLWE<P> got{};
+        CUFHE_AMD_CHECK(cufhe_amd_memcpy_d2h(d, nullptr, got.data(), out.tlwedevices[d], kBytes));
+        CUFHE_AMD_CHECK(cufhe_amd_stream_synchronize(d, nullptr));
+        bad += got != want(ORC_NAND, a.tlwehost, b.tlwehost); total++;
+#ifdef CUFHE_AMD_TEST_HIP
+        // (b): a chain of two recorded gates, then the caller's own copy and wait on the raw handle
+        gXor(out2, out, b, st);
+        gAnd(out3, out2, a, st);
+        TFHEpp::TLWE<P> got2{}, got3{};
+        hipStream_t raw = st.st();
+        bad += hipMemcpyAsync(got3.data(), out3.tlwedevices[d], kBytes, hipMemcpyDeviceToHost, raw) != hipSuccess;
+        bad += hipMemcpyAsync(got2.data(), out2.tlwedevices[d], kBytes, hipMemcpyDeviceToHost, raw) != hipSuccess;
+        bad += hipStreamSynchronize(raw) != hipSuccess;
+        const auto w2 = want(ORC_XOR, got, b.tlwehost), w3 = want(ORC_AND, w2, a.tlwehost);
+        bad += got2 != w2; total++;
+        bad += got3 != w3; total++;
+        // (c): the caller uploads fresh words into a ciphertext's own device buffer through the handle, then a g-gate reads it
+        TFHEpp::TLWE<P> fresh{};
+        orc_tlwe_encrypt(&g_rng, 0, g_s0.data(), (int)(eng() & 1), fresh.data());
+        bad += hipMemcpyAsync(out2.tlwedevices[d], fresh.data(), kBytes, hipMemcpyHostToDevice, st.st()) != hipSuccess;
+        gOr(out4, out2, b, st);
+        // (d): an event behind the gate
+        hipEvent_t ev;
+        bad += hipEventCreate(&ev) != hipSuccess;
+        bad += hipEventRecord(ev, st.st()) != hipSuccess;
+        bad += hipEventSynchronize(ev) != hipSuccess;
+        TFHEpp::TLWE<P> got4{};
+        bad += hipMemcpy(got4.data(), out4.tlwedevices[d], kBytes, hipMemcpyDeviceToHost) != hipSuccess;
+        bad += got4 != want(ORC_OR, fresh, b.tlwehost); total++;
+        (void)hipEventDestroy(ev);
+#endif
+        // (e)
+        Nand(out5, a, b, st);
+        StreamSynchronize(st);
+        bad += out5.tlwehost != want(ORC_NAND, a.tlwehost, b.tlwehost); total++;
+    }
+    std::printf("Stream::st() ordering (StreamSynchronize, copies / events / uploads on the raw handle): %s (%d/%d failures)\n", bad ? "FAIL" : "PASS", bad, total);
+    g_failures += bad;
+    st.Destroy();
+    orc_evalkey_destroy(ek);
+}
+
 // A real circuit through the per-gate API: 16 independent 8-bit ripple-carry adders, one per
 // stream, every gate depending on earlier ones (the scheduler must cut the recorded gates into
 // dependence levels and still batch across the 16 adders).
@@ -293,9 +374,11 @@ void TrlweBootstraps(std::mt19937& eng)
     for (auto& s : st) s.Destroy();
 }
 
-#ifndef CUFHE_AMD_PARAM_SET_INDEX
+#ifndef CUFHE_AMD_SMALL_NTT_MODULUS
 // test/test_perf.cc:36-87 (GateBootstrappingTLWE2TRLWElvl01NTT then Refresh, decrypt coefficient 0)
-// and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch.
+// and test/test_cmux.cc:36-150 (CMUXNTT on TRLWE/TRGSW), plus SampleExtractAndKeySwitch -- on whatever parameter set this build runs
+// on: in the reference the set TFHEpp selects serves CMUXNTT / TRGSW2NTT too (src/bootstrap_gpu.cu:75-94,197-285); only its
+// small-modulus build has none (src/cufhe_gates_gpu.cu:68-86).
 void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
 {
     using namespace TFHEpp;
@@ -322,7 +405,8 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         // CMUX: the bootstrapping key row i is a TRGSW encryption of s0[i]
         const int i = eng() % ORC_n;
         TRGSW<lvl1param> trgsw;
-        std::memcpy(trgsw.data(), bk.data() + (size_t)i * ORC_BK_ROWS * 2 * ORC_N, sizeof(trgsw));
+        static_assert(sizeof(trgsw) == (size_t)ORC_BK_ROWS * (ORC_K + 1) * ORC_N * sizeof(uint32_t), "TRGSW<lvl1param> is one step of the oracle's key");
+        std::memcpy(trgsw.data(), bk.data() + (size_t)i * ORC_BK_ROWS * (ORC_K + 1) * ORC_N, sizeof(trgsw));
         cuFHETRGSWNTTlvl1 cs;
         TRGSW2NTT(cs, trgsw, st);
         Ctxt<lvl0param> other;
@@ -340,11 +424,11 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
         // must find them there (t, t_other are on the device since the operations above)
         cuFHETRLWElvl1 res3;
         gCMUXNTT(res3, cs, t, t_other, st);
-        CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.st(), res3.handle, 0));
+        CUFHE_AMD_CHECK(cufhe_amd_enqueue_copy(st.device_id(), st.raw(), res3.handle, 0));
         // the holder refilled between two unsynchronised CMUXNTT calls: the first must use the old selector, the second the new
-        const int i2 = (i + 1 + (int)(eng() % 600)) % 630;
+        const int i2 = (i + 1 + (int)(eng() % (ORC_n - 30))) % ORC_n;
         TRGSW<lvl1param> trgsw2;
-        std::memcpy(trgsw2.data(), bk.data() + (size_t)i2 * ORC_BK_ROWS * 2 * ORC_N, sizeof(trgsw2));
+        std::memcpy(trgsw2.data(), bk.data() + (size_t)i2 * ORC_BK_ROWS * (ORC_K + 1) * ORC_N, sizeof(trgsw2));
         cuFHETRLWElvl1 res4, res5;
         CMUXNTT(res4, cs, t, t_other, st);         // s0[i]  ? t : t_other
         TRGSW2NTT(cs, trgsw2, st);
@@ -358,7 +442,9 @@ void TrlwePrimitives(std::mt19937& eng, const std::vector<uint32_t>& bk)
     g_failures += bad;
     st.Destroy();
 }
+#endif  // CUFHE_AMD_SMALL_NTT_MODULUS
 
+#ifdef ORC_SET_DEFAULT
 // test/test_perf.cc:36-87 at size: 4096 x GateBootstrappingTLWE2TRLWElvl01NTT, then 4096 x Refresh on 800 streams
 void RefreshAtSize(std::mt19937& eng)
 {
@@ -440,7 +526,7 @@ void Lvl2Gates(std::mt19937& eng)
     CUFHE_AMD_CHECK(cufhe_amd_set_option("lvl0_ring", 1024));
 }
 
-#endif  // CUFHE_AMD_PARAM_SET_INDEX
+#endif  // ORC_SET_DEFAULT
 
 // Source written against the reference's header touches its public globals and the stream type directly
 // (include/cufhe_gpu.cuh:44-46 `extern int _gpuNum; extern int streamCount;`, :154-165 the default Stream constructor,
@@ -499,19 +585,25 @@ int main(int argc, char** argv)
     ReferenceGlobals(gpus);
     AllGates<TFHEpp::lvl1param>(kNumSMs, kNumTests, eng);   // test_gate_gpu.cc
     AllGates<TFHEpp::lvl0param>(kNumSMs, kNumTests, eng);   // test_gate_gpu_multi.cc
-#ifdef CUFHE_AMD_PARAM_SET_INDEX
-    // a build on another parameter set (-DCUFHE_AMD_PARAM_SET_... with the oracle compiled for the same set, -DORC_SET_...): the
-    // gate tests above ran key switch -> blind rotate on lvl1 ciphertexts and blind rotate -> key switch on lvl0 ciphertexts of
-    // that set; then the programs that only need gates
+#ifndef ORC_SET_DEFAULT
+    // a build on another parameter set (TFHEpp's structs -- or the stand-ins selected by -DCUFHE_AMD_PARAM_SET_... -- with the oracle
+    // compiled for the same set, -DORC_SET_...): the header FOUND the library's set from the structs' numbers.  The gate tests above ran
+    // key switch -> blind rotate on lvl1 ciphertexts and blind rotate -> key switch on lvl0 ciphertexts of that set; then the programs
+    // that only need gates and the TRLWE-level operations
+    static_assert(kParamSetIndex > 0, "a non-default oracle build belongs to a non-default parameter set");
     Chained(eng);
     Intensive(eng);
     DeviceResident(eng);
     TrlweBootstraps(eng);
+#ifndef CUFHE_AMD_SMALL_NTT_MODULUS
+    TrlwePrimitives(eng, bk);
+#endif
     RippleAdders(eng);
     CleanUp();
     std::printf("%s\n", g_failures ? "FAILED" : "ALL PASS");
     return g_failures ? 1 : 0;
 #else
+    static_assert(kParamSetIndex == 0, "the BASELINE numbers are the library's set 0");
     if (getenv("CUFHE_AMD_TEST_QUICK")) {                   // the gate tests and the lvl2 keys only (the USE_TFHEPP build's run)
         Lvl2Gates(eng);
         CleanUp();
@@ -522,6 +614,7 @@ int main(int argc, char** argv)
     Intensive(eng);
     DeviceResident(eng);
     TrlwePrimitives(eng, bk);
+    StreamOrdering(eng);
     RippleAdders(eng);
     if (!getenv("CUFHE_AMD_TEST_SKIP_AT_SIZE")) {           // the parts at size do not depend on the variant of the run (tests/test_gpu_parity.py)
         RefreshAtSize(eng);

@@ -9,16 +9,48 @@
 #include <array>
 #include <cstdint>
 
+// Like TFHEpp, the stand-in takes its numbers from the macro the build defines (CMakeLists.txt:8-24 of the reference passes
+// USE_80BIT_SECURITY / USE_CONCRETE ... on to TFHEpp): the two alternative shapes the library has compiled sets for, and -- for the
+// tests that a build on numbers NO compiled set has is refused -- single numbers overridden with -DTFHEPP_STUB_BGBIT / _T / _BASEBIT.
+#if defined(USE_80BIT_SECURITY)
+#define TFHEPP_STUB_N0 500
+#define TFHEPP_STUB_NBIT 10
+#define TFHEPP_STUB_K 1
+#define TFHEPP_STUB_L 2
+#define TFHEPP_STUB_BGBIT_DEFAULT 10
+#elif defined(USE_CONCRETE)
+#define TFHEPP_STUB_N0 630
+#define TFHEPP_STUB_NBIT 9
+#define TFHEPP_STUB_K 2
+#define TFHEPP_STUB_L 3
+#define TFHEPP_STUB_BGBIT_DEFAULT 6
+#else
+#define TFHEPP_STUB_N0 630
+#define TFHEPP_STUB_NBIT 10
+#define TFHEPP_STUB_K 1
+#define TFHEPP_STUB_L 3
+#define TFHEPP_STUB_BGBIT_DEFAULT 6
+#endif
+#ifndef TFHEPP_STUB_BGBIT
+#define TFHEPP_STUB_BGBIT TFHEPP_STUB_BGBIT_DEFAULT
+#endif
+#ifndef TFHEPP_STUB_T
+#define TFHEPP_STUB_T 8
+#endif
+#ifndef TFHEPP_STUB_BASEBIT
+#define TFHEPP_STUB_BASEBIT 2
+#endif
+
 namespace TFHEpp {
 struct lvl0param {
     using T = uint32_t;
-    static constexpr uint32_t n = 630, k = 1;
+    static constexpr uint32_t n = TFHEPP_STUB_N0, k = 1;
     static constexpr T mu = 1u << 29;
     static constexpr T μ = mu;
 };
 struct lvl1param {
     using T = uint32_t;
-    static constexpr uint32_t nbit = 10, n = 1u << nbit, k = 1, l = 3, Bgbit = 6, Bg = 1u << Bgbit;
+    static constexpr uint32_t nbit = TFHEPP_STUB_NBIT, n = 1u << nbit, k = TFHEPP_STUB_K, l = TFHEPP_STUB_L, Bgbit = TFHEPP_STUB_BGBIT, Bg = 1u << Bgbit;
     static constexpr T mu = 1u << 29;
     static constexpr T μ = mu;
 };
@@ -32,7 +64,7 @@ struct lvl01param { using domainP = lvl0param; using targetP = lvl1param; };
 struct lvl02param { using domainP = lvl0param; using targetP = lvl2param; };
 struct lvl10param {
     using domainP = lvl1param; using targetP = lvl0param;
-    static constexpr uint32_t t = 8, basebit = 2;
+    static constexpr uint32_t t = TFHEPP_STUB_T, basebit = TFHEPP_STUB_BASEBIT;
 };
 struct lvl20param {
     using domainP = lvl2param; using targetP = lvl0param;

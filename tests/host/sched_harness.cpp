@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <random>
 
 #include "../../cufhe_amd/csrc/sched_core.h"
@@ -88,7 +89,24 @@ class FakeBackend : public Backend {
         return 0;
     }
     int event_create(void** ev) override { *ev = new FakeEvent(); return 0; }
-    int event_destroy(void* ev) override { delete (FakeEvent*)ev; return 0; }
+    int event_destroy(void* ev) override
+    {
+        // as in HIP, a wait that was enqueued on the event stays valid when the event object goes: the scheduler only destroys
+        // completed events, so such a wait is satisfied
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = (FakeEvent*)ev;
+        auto release = [&](std::deque<Op>& q) {
+            for (Op& op : q)
+                if (op.wait == e) {
+                    if (e->completed < op.target) { fprintf(stderr, "stub device: an event with a pending, unsatisfied wait was destroyed\n"); abort(); }
+                    op.wait = nullptr;
+                }
+        };
+        for (auto& q : q_) release(q);
+        for (auto& kv : cq_) release(kv.second);
+        delete e;
+        return 0;
+    }
     int event_record(int s, void* ev) override
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -121,6 +139,32 @@ class FakeBackend : public Backend {
         return 0;
     }
     std::string error_text() override { return "stub"; }
+    // the caller's own streams (raw handles of Stream::st()): queues like the internal ones, filled by the test itself
+    int caller_stream_wait(void* cs, void* ev) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = (FakeEvent*)ev;
+        caller_waits++;
+        cq_[cs].push_back({[] {}, e, e->submitted});
+        return 0;
+    }
+    int wait_for_caller_stream(int s, void* cs) override
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        FakeEvent* e = new FakeEvent();
+        owned_.push_back(e);
+        e->submitted++;
+        cq_[cs].push_back({[e] { e->completed++; }, nullptr, 0});
+        q_[s].push_back({[] {}, e, e->submitted});
+        return 0;
+    }
+    void push_caller(void* cs, std::function<void()> fn)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        cq_[cs].push_back({std::move(fn), nullptr, 0});
+    }
+    ~FakeBackend() override { for (FakeEvent* e : owned_) delete e; }
+    uint64_t caller_waits = 0;
     void drain()
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -137,18 +181,23 @@ class FakeBackend : public Backend {
     }
     bool pump_one()
     {
-        std::vector<int> ready;
-        for (size_t s = 0; s < q_.size(); s++)
-            if (!q_[s].empty() && (!q_[s].front().wait || q_[s].front().wait->completed >= q_[s].front().target)) ready.push_back((int)s);
+        std::vector<std::deque<Op>*> ready;
+        auto is_ready = [](std::deque<Op>& q) { return !q.empty() && (!q.front().wait || q.front().wait->completed >= q.front().target); };
+        for (auto& q : q_)
+            if (is_ready(q)) ready.push_back(&q);
+        for (auto& kv : cq_)
+            if (is_ready(kv.second)) ready.push_back(&kv.second);
         if (ready.empty()) return false;
-        const int s = ready[rng_() % ready.size()];
-        Op op = std::move(q_[s].front());
-        q_[s].pop_front();
+        std::deque<Op>* q = ready[rng_() % ready.size()];
+        Op op = std::move(q->front());
+        q->pop_front();
         op.fn();
         return true;
     }
     std::mutex mu_;
     std::vector<std::deque<Op>> q_;
+    std::map<void*, std::deque<Op>> cq_;
+    std::vector<FakeEvent*> owned_;
     std::mt19937_64 rng_;
 };
 
@@ -171,7 +220,18 @@ struct Test {
         cufhe_amd_ctxt* h; std::vector<uint32_t> host; ModelCtxt m; void* last_host_writer_stream = nullptr; bool alive = true;
         std::vector<uint32_t*> home;                   // the device pointers as of creation: what the reference publishes as tlwedevices
         std::vector<void*> last_dev_writer_stream;     // per device: the caller stream of the newest gate that wrote the device value
+        std::vector<void*> last_dev_upload_stream;     // per device: the caller stream of an upload that is the NEWEST write of the device value (nullptr: a gate's write is)
+        std::vector<void*> only_stream;                // per device: the one caller stream all recorded accesses were issued on (nullptr: none yet, kMany: several)
+        // a ciphertext the program only ever touches on ONE stream of one device: what a caller may read and write through that stream's raw
+        // handle with a defined outcome (across streams the reference orders nothing)
+        void* priv_stream = nullptr;
+        int priv_dev = -1;
     };
+    static void* many() { return (void*)(uintptr_t)-1; }
+    static void touch(C* c, int dev, void* st) { void*& o = c->only_stream[dev]; o = (o == nullptr || o == st) ? st : many(); }
+    // reads the caller enqueued on a raw handle: what the buffer must hold when the read executes
+    struct CallerRead { std::vector<uint32_t> got, want; bool done = false; };
+    std::vector<std::shared_ptr<CallerRead>> caller_reads;
     std::vector<C*> ct;
     int failures = 0;
 
@@ -203,53 +263,104 @@ struct Test {
         c->m.dev_defined.assign(G, false);
         for (int d = 0; d < G; d++) c->home.push_back(c->h->d[d].dev);
         c->last_dev_writer_stream.assign(G, nullptr);
+        c->only_stream.assign(G, nullptr);
+        c->last_dev_upload_stream.assign(G, nullptr);
         ct.push_back(c);
         return c;
     }
+    bool trace = getenv("SCHED_HARNESS_TRACE") != nullptr;
+    int idx(C* c) { for (size_t i = 0; i < ct.size(); i++) if (ct[i] == c) return (int)i; return -1; }
     void gate(int dev, void* st, int op, bool copying, C* out, C* a, C* b, C* c3)
     {
+        if (trace) printf("T gate dev %d st %p op %d %s out %d in %d %d %d\n", dev, st, op, copying ? "copying" : "g", idx(out), idx(a), b ? idx(b) : -1, c3 ? idx(c3) : -1);
         C* ins[3] = {a, b, c3};
         cufhe_amd_ctxt* hs[3] = {a->h, b ? b->h : nullptr, c3 ? c3->h : nullptr};
         if (int rc = S->dev(dev).record_gate(st, op, copying, out->h, hs, op >= TL_BOOT ? 2 : -1)) { fprintf(stderr, "record_gate rc %d: %s\n", rc, S->dev(dev).error_text().c_str()); abort(); }
+        for (C* i : ins)
+            if (i) touch(i, dev, st);
+        touch(out, dev, st);
         // model, in issue order
         if (copying)
             for (C* i : ins)
-                if (i) { i->m.dev[dev] = i->m.host; i->m.dev_defined[dev] = true; }
+                if (i) { i->m.dev[dev] = i->m.host; i->m.dev_defined[dev] = true; i->last_dev_upload_stream[dev] = st; }
         std::vector<uint32_t> r(kWords[out->m.level]);
         toy_gate(op, out->m.level, r.data(), a->m.dev[dev].data(), b ? b->m.dev[dev].data() : nullptr, c3 ? c3->m.dev[dev].data() : nullptr);
         out->m.dev[dev] = r;
         out->m.dev_defined[dev] = true;
         out->last_dev_writer_stream[dev] = st;
+        out->last_dev_upload_stream[dev] = nullptr;
         if (copying) { out->m.host = r; out->last_host_writer_stream = st; }
     }
     void copy(int dev, void* st, C* c, bool to_device)
     {
+        if (trace) printf("T copy dev %d st %p %s ctxt %d\n", dev, st, to_device ? "H2D" : "D2H", idx(c));
         if (int rc = S->dev(dev).record_copy(st, c->h, to_device)) { fprintf(stderr, "record_copy rc %d\n", rc); abort(); }
-        if (to_device) { c->m.dev[dev] = c->m.host; c->m.dev_defined[dev] = true; }
+        touch(c, dev, st);
+        if (to_device) { c->m.dev[dev] = c->m.host; c->m.dev_defined[dev] = true; c->last_dev_upload_stream[dev] = st; }
         else { c->m.host = c->m.dev[dev]; c->last_host_writer_stream = st; }
+    }
+    // Stream::st(): the raw handle is handed out (stream_fence), then the caller puts its own work on it.
+    // A read of a ciphertext's OWN device buffer (the published tlwedevices pointer) must see what the gates issued on `st` before
+    // the call left there; a write into it must be seen by the g-gates issued on `st` afterwards (src/cufhe_gates_gpu.cu:148-167: in
+    // the reference all of this is one stream's order).
+    void caller_read(int dev, void* st, C* c)
+    {
+        if (trace) printf("T caller_read dev %d st %p ctxt %d\n", dev, st, idx(c));
+        if (int rc = S->dev(dev).stream_fence(st)) { fprintf(stderr, "stream_fence rc %d\n", rc); abort(); }
+        auto r = std::make_shared<CallerRead>();
+        r->want = c->m.dev[dev];
+        const uint32_t* home = c->home[dev];
+        const int words = kWords[c->m.level];
+        be[dev]->push_caller(st, [r, home, words] { r->got.assign(home, home + words); r->done = true; });
+        caller_reads.push_back(r);
+    }
+    void caller_write(int dev, void* st, C* c)
+    {
+        if (trace) printf("T caller_write dev %d st %p ctxt %d\n", dev, st, idx(c));
+        if (int rc = S->dev(dev).stream_fence(st)) { fprintf(stderr, "stream_fence rc %d\n", rc); abort(); }
+        std::vector<uint32_t> w(kWords[c->m.level]);
+        for (auto& x : w) x = (uint32_t)rng();
+        uint32_t* home = c->home[dev];
+        be[dev]->push_caller(st, [w, home] { memcpy(home, w.data(), w.size() * 4); });
+        c->m.dev[dev] = w;
+        c->m.dev_defined[dev] = true;
+        c->last_dev_writer_stream[dev] = st;
+        c->last_dev_upload_stream[dev] = nullptr;
+        touch(c, dev, st);
+    }
+    void check_caller_reads()
+    {
+        for (auto& r : caller_reads) {
+            if (!r->done) { failures++; printf("FAIL a read on the caller's stream never ran\n"); continue; }
+            if (r->got != r->want) { failures++; printf("FAIL a read on the caller's stream (raw handle of Stream::st()) saw stale words\n"); }
+        }
+        caller_reads.clear();
     }
     void check_host(C* c, const char* when)
     {
         if (c->host != c->m.host) {
             failures++;
-            printf("FAIL host mismatch (%s) ctxt %p level %d\n", when, (void*)c, c->m.level);
+            printf("FAIL host mismatch (%s) ctxt %p [%d] level %d\n", when, (void*)c, idx(c), c->m.level);
         }
     }
     // StreamQuery(st) returned true: what gates on st wrote must be in the ciphertexts' OWN device buffers (the pointers
-    // published at creation), renaming or not.  Uploads do not count: copy() / copying gates write the device value too,
-    // but only a gate's write can have been renamed away.
+    // published at creation), renaming or not -- and so must a value that an upload on st refreshed after a gate on ANOTHER stream
+    // had renamed the ciphertext away from its buffer (the upload lands in the renamed buffer).
     void check_home_after_query(int dev, void* st)
     {
         for (auto* b : be) b->drain();
         for (C* c : ct) {
-            if (!c->alive || c->last_dev_writer_stream[dev] != st || !c->m.dev_defined[dev]) continue;
+            if (!c->alive || !c->m.dev_defined[dev]) continue;
+            if (c->last_dev_upload_stream[dev] ? c->last_dev_upload_stream[dev] != st : c->last_dev_writer_stream[dev] != st) continue;
             if (c->h->d[dev].dev != c->home[dev]) { failures++; printf("FAIL ctxt %p still renamed after StreamQuery\n", (void*)c); }
         }
     }
     void sync_and_check(bool check_dev)
     {
+        if (trace) printf("T synchronize\n");
         if (int rc = S->synchronize_all()) { fprintf(stderr, "synchronize rc %d\n", rc); abort(); }
         for (auto* b : be) b->drain();
+        check_caller_reads();
         for (C* c : ct) {
             if (!c->alive) continue;
             check_host(c, "after Synchronize");
@@ -257,7 +368,7 @@ struct Test {
                 for (int d = 0; d < G; d++)
                     if (c->m.dev_defined[d] && (c->h->d[d].dev != c->home[d] || memcmp(c->home[d], c->m.dev[d].data(), kWords[c->m.level] * 4))) {
                         failures++;
-                        printf("FAIL device mismatch ctxt %p dev %d%s\n", (void*)c, d, c->h->d[d].dev != c->home[d] ? " (value not in the ciphertext's own buffer)" : "");
+                        printf("FAIL device mismatch ctxt %p [%d] dev %d%s\n", (void*)c, idx(c), d, c->h->d[d].dev != c->home[d] ? " (value not in the ciphertext's own buffer)" : "");
                     }
         }
     }
@@ -272,27 +383,50 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
         t.S->dev(d).total_flush_gates = 30 + prng() % 200;
     }
     const int kStreams = 6;
+    const bool use_raw_handles = seed % 3 == 0;     // (a handle that is out switches the shared-upload shortcut off: not in every program)
     auto stream_handle = [&](int dev, int s) { return (void*)(uintptr_t)(0x1000 + dev * 64 + s); };
     for (int i = 0; i < 30; i++) t.make(i % 5 == 4 ? 2 : i % 3 == 0 ? 1 : 0);
+    if (use_raw_handles)
+        for (int i = 0; i < 12; i++) {
+            Test::C* c = t.make(i % 3 == 0 ? 1 : 0);
+            c->priv_dev = (int)(prng() % gpus);
+            c->priv_stream = stream_handle(c->priv_dev, (int)(prng() % 2));     // two streams per device carry the private ciphertexts
+        }
     const int steps = 300 + (int)(prng() % 500);
+    int cur_dev = 0;
+    void* cur_st = nullptr;
+    auto usable = [&](Test::C* c) { return c->alive && (!c->priv_stream || (c->priv_stream == cur_st && c->priv_dev == cur_dev)); };
     auto pick = [&](int level) {
         for (;;) {
             Test::C* c = t.ct[prng() % t.ct.size()];
-            if (c->alive && c->m.level == level) return c;
+            if (usable(c) && c->m.level == level) return c;
         }
     };
     auto pick_defined = [&](int level, int dev) -> Test::C* {
         for (int tries = 0; tries < 64; tries++) {
             Test::C* c = t.ct[prng() % t.ct.size()];
-            if (c->alive && c->m.level == level && c->m.dev_defined[dev]) return c;
+            if (usable(c) && c->m.level == level && c->m.dev_defined[dev]) return c;
         }
         return nullptr;
     };
     for (int step = 0; step < steps; step++) {
         const int dev = (int)(prng() % gpus);
         void* st = stream_handle(dev, (int)(prng() % kStreams));
+        cur_dev = dev;
+        cur_st = st;
         const int level = prng() % 4 == 0 ? 1 : 0;
         const unsigned r = (unsigned)(prng() % 100);
+        if (use_raw_handles && prng() % 16 == 0) {  // the caller takes the raw handle of the stream and reads / writes a device buffer on it
+            Test::C* c = nullptr;
+            for (int tries = 0; tries < 64 && !c; tries++) {
+                Test::C* x = t.ct[prng() % t.ct.size()];
+                if (x->alive && x->priv_stream == st && x->priv_dev == dev && x->m.dev_defined[dev]) c = x;
+            }
+            if (!c) continue;
+            if (prng() % 2) t.caller_read(dev, st, c);
+            else t.caller_write(dev, st, c);
+            continue;
+        }
         if (r < 8) {                                // TRLWE-level operation (copying or device-resident)
             const int op = TL_BOOT + (int)(prng() % 3);
             const bool copying = prng() % 2 == 0;
@@ -344,9 +478,14 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
             t.check_host(c, "before a direct host write");      // a result that was on its way has landed
             for (auto& w : c->host) w = (uint32_t)prng();
             c->m.host = c->host;
+        } else if (r < 97) {                        // StreamSynchronize(st): everything issued on st is complete and delivered
+            if (int rc = t.S->dev(dev).stream_synchronize(st)) { fprintf(stderr, "stream_synchronize rc %d\n", rc); abort(); }
+            for (Test::C* c : t.ct)
+                if (c->alive && c->last_host_writer_stream == st) t.check_host(c, "after StreamSynchronize");
+            t.check_home_after_query(dev, st);
         } else if (r < 98) {                        // a ciphertext goes out of scope while work on it is recorded
             Test::C* c = t.ct[prng() % t.ct.size()];
-            if (!c->alive) continue;
+            if (!c->alive || c->priv_stream) continue;
             t.S->ctxt_destroy(c->h);
             c->alive = false;
             for (auto& w : c->host) w = 0xDEADBEEFu;      // the caller's memory is gone: nobody may read it any more
@@ -532,6 +671,12 @@ int main(int argc, char** argv)
     g_rename = argc > 4 ? atoi(argv[4]) != 0 : false;
     g_zero_copy = argc > 5 ? atoi(argv[5]) != 0 : false;
     int failures = 0;
+    if (const char* one = getenv("SCHED_HARNESS_SEED")) {      // one random program, for debugging: SCHED_HARNESS_SEED=1038 sched_harness 0 3 1
+        const int sd = atoi(one);
+        const int f = random_program(sd, 1 + ((sd - 1000) % gpus), threaded);
+        printf("seed %d: %d mismatches\n", sd, f);
+        return f ? 1 : 0;
+    }
     for (int s = 1; s <= seeds; s++) {
         const int f = random_program(1000 + s, 1 + (s % gpus), threaded);
         if (f) printf("FAIL random program seed %d: %d mismatches\n", 1000 + s, f);

@@ -135,11 +135,8 @@ def test_shim_compiles_with_the_tfhepp_branch(tmp_path):
     about it, it keeps the branch from rotting).  The reference's own test programs (tests/cpp/test_gate_api.cpp) compile and link
     in that configuration; tests/test_gpu_parity.py runs the binary on the GPU."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "test_gate_api_tfhepp")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-DCUFHE_AMD_USE_TFHEPP", "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"),
-                           "-o", exe, os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
-                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle",
-                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    import cpp_build
+    cpp_build.build_gate_api("test_gate_api_tfhepp", tfhepp=True, opt="-O1", extra=["-Wall"])
     # and a translation unit that uses nothing but the reference's own spellings
     src = tmp_path / "user.cpp"
     src.write_text('''#define CUFHE_AMD_USE_TFHEPP
@@ -166,7 +163,7 @@ void user2(cufhe::Ctxt<TFHEpp::lvl0param>& in, cufhe::Ctxt<TFHEpp::lvl0param>& o
     cufhe::GateBootstrappingTLWE2TRLWElvl01NTT(t, in, st);
     cufhe::Refresh(r, t, st);
     cufhe::SampleExtractAndKeySwitch(out, r, st);
-    static_assert(CUFHE_AMD_PARAM_SET_INDEX == 3, "USE_SMALL_NTT_MODULUS selects the small-modulus set");
+    static_assert(cufhe::kParamSetIndex == 3, "USE_SMALL_NTT_MODULUS selects the small-modulus set");
 }
 ''')
     flags = ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-DUSE_SMALL_NTT_MODULUS", "-I" + os.path.join(root, "include"),
@@ -191,3 +188,56 @@ def test_recorded_pmc_facts_belong_to_the_committed_device_code():
     for k in ("blind_rotate_kernel", "blind_rotate_lvl2_kernel", "blind_rotate_ll2_kernel", "keyswitch_kernel",
               "blind_rotate_ps_batch_kernel<default>", "blind_rotate_ps_batch_kernel<k2n512>", "blind_rotate_ps_batch_kernel<cggi16>"):
         assert facts["kernels"][k]["valu_insts_per_rotation"] > 0
+
+
+def test_one_selector_for_the_parameter_set(tmp_path):
+    """The reference has ONE selector: the numbers of TFHEpp's parameter structs (CMakeLists.txt:8-24, include/bootstrap_gpu.cuh:51-53).
+    include/cufhe_amd.hpp derives the library's compiled set from those numbers at compile time: TFHEpp built for another shape needs
+    nothing naming a set of this library, and numbers NO compiled set has -- Bgbit 7; (t, basebit) = (4, 3), whose key-switching key has
+    the SIZE of (8, 2) -- do not compile, with a message that names the numbers.  At run time cufhe_amd_initialize_params repeats the
+    match inside the library (tests/test_gpu_paramsets.py: refused before any device work)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "cpp", "tfhepp_stub")
+    src = tmp_path / "which.cpp"
+    src.write_text('#define CUFHE_AMD_USE_TFHEPP\n#include "cufhe_amd.hpp"\n#ifndef WANT\n#define WANT 0\n#endif\n'
+                   'static_assert(cufhe::kParamSetIndex == WANT, "wrong set");\n'
+                   '#ifndef USE_SMALL_NTT_MODULUS\nvoid f() { cufhe::cuFHETRGSWNTTlvl1 cs; static_assert(sizeof(cs.trgswhost) == '
+                   'sizeof(double) * cufhe::kKeyLimbs * (TFHEpp::lvl1param::k + 1) * (TFHEpp::lvl1param::k + 1) * TFHEpp::lvl1param::l * TFHEpp::lvl1param::n, "holder"); }\n#endif\n')
+    base = ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), "-I" + stub, str(src)]
+    for flags, want in (([], 0), (["-DUSE_CONCRETE"], 1), (["-DUSE_80BIT_SECURITY"], 2), (["-DUSE_SMALL_NTT_MODULUS"], 3)):
+        subprocess.check_call(base + flags + ["-DWANT=%d" % want])
+    for flags in (["-DTFHEPP_STUB_BGBIT=7"], ["-DTFHEPP_STUB_T=4", "-DTFHEPP_STUB_BASEBIT=3"], ["-DUSE_80BIT_SECURITY", "-DUSE_SMALL_NTT_MODULUS"]):
+        r = subprocess.run(base + flags, capture_output=True, text=True)
+        assert r.returncode != 0 and "no parameter set compiled into libcufhe_amd.so" in r.stderr, (flags, r.stderr[-1500:])
+    # level_of<P>() goes by TYPE: a third parameter struct is refused, whatever its n
+    bad = tmp_path / "level.cpp"
+    bad.write_text('#include "cufhe_amd.hpp"\nstruct other { using T = uint32_t; static constexpr uint32_t n = 630, k = 1; };\n'
+                   'int f() { return cufhe::detail::level_of<other>(); }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(root, "include"), str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "specialised for P = TFHEpp::lvl0param and TFHEpp::lvl1param" in r.stderr
+
+
+def test_header_table_of_sets_matches_the_library():
+    """detail::kCompiledSets of include/cufhe_amd.hpp (what the compile-time match runs on) == cufhe_amd_ps_get_params of the library,
+    set by set; cufhe_amd_find_param_set finds each and refuses near misses with the numbers in the text."""
+    from cufhe_amd import _lib
+    from cufhe_amd._lib import PsParams
+    lib = _lib.lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "cufhe_amd.hpp")).read()
+    table = text[text.index("constexpr SetNumbers kCompiledSets[] = {"):]
+    table = table[:table.index("};")]
+    rows = [tuple(int(v.replace("kSmallNttP", str((625 << 20) + 1))) for v in re.findall(r"\{([^}]*)\}", line)[0].split(","))
+            for line in table.splitlines()[1:] if "{" in line]
+    assert len(rows) == lib.cufhe_amd_ps_count()
+    for i, row in enumerate(rows):
+        p = PsParams()
+        assert lib.cufhe_amd_ps_get_params(i, ctypes.byref(p)) == 0
+        assert row == (p.n, p.nbit, p.k, p.l, p.Bgbit, p.t, p.basebit, p.key_limbs, p.small_ntt_modulus), (i, row)
+        q = _lib.ParamNumbers(p.n, p.nbit, p.k, p.l, p.Bgbit, p.t, p.basebit, p.small_ntt_modulus)
+        assert lib.cufhe_amd_find_param_set(ctypes.byref(q)) == i
+    for miss in (_lib.ParamNumbers(630, 10, 1, 3, 7, 8, 2, 0), _lib.ParamNumbers(630, 10, 1, 3, 6, 4, 3, 0)):
+        assert lib.cufhe_amd_find_param_set(ctypes.byref(miss)) == -1
+        assert b"no compiled parameter set has n=630" in lib.cufhe_amd_last_error()
+    buf = (ctypes.c_uint32 * 4)()
+    assert lib.cufhe_amd_initialize_params(ctypes.byref(miss), buf, 4, buf, 4) == -1      # refused before the keys are looked at

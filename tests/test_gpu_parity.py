@@ -293,13 +293,8 @@ def test_cpp_gate_api_mirror(engine):
     compiled with plain g++ (host code stays C++)."""
     import os
     import subprocess
-    src = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api.cpp")
-    exe = os.path.join(ol.ROOT, "tests", "cpp", "test_gate_api")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src,
-                           "-L" + os.path.join(ol.ROOT, "cufhe_amd"), "-lcufhe_amd",
-                           "-L" + os.path.join(ol.ROOT, "oracle"), "-loracle",
-                           "-Wl,-rpath," + os.path.join(ol.ROOT, "cufhe_amd"),
-                           "-Wl,-rpath," + os.path.join(ol.ROOT, "oracle")])
+    import cpp_build
+    exe = cpp_build.build_gate_api("test_gate_api")
     engine.CleanUp()                      # the C++ program owns the device state while it runs
     try:
         out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
@@ -317,12 +312,8 @@ def test_cpp_gate_api_tfhepp_branch(engine):
     keys handed over as a TFHEpp::EvalKey (Initialize(ek), lvl2::Initialize(ek)), every gate of both levels decrypt-checked."""
     import os
     import subprocess
-    root = ol.ROOT
-    exe = os.path.join(root, "tests", "cpp", "test_gate_api_tfhepp")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DCUFHE_AMD_USE_TFHEPP", "-I" + os.path.join(root, "tests", "cpp", "tfhepp_stub"),
-                           "-o", exe, os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
-                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle",
-                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    import cpp_build
+    exe = cpp_build.build_gate_api("test_gate_api_tfhepp", tfhepp=True)
     engine.CleanUp()
     try:
         out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, CUFHE_AMD_TEST_QUICK="1"))
@@ -335,22 +326,25 @@ def test_cpp_gate_api_tfhepp_branch(engine):
         engine.Initialize(k.bk, k.ksk)
 
 
-@pytest.mark.parametrize("name", ["cggi16", "k2n512", "smallmod"])
+@pytest.mark.parametrize("name", ["cggi16", "k2n512", "smallmod", "cggi16-tfhepp", "k2n512-tfhepp"])
 def test_cpp_gate_api_on_a_parameter_set(engine, name):
     """The reference's own test programs (tests/cpp/test_gate_api.cpp: test_gate_gpu.cc on lvl1 ciphertexts, test_gate_gpu_multi.cc on
-    lvl0, test_api_gpu.cu's chains, test_intensive.cc, the ripple-carry adders) compiled the way a user picks a set in the reference --
-    at build time (CMakeLists.txt:8-24; here -DCUFHE_AMD_PARAM_SET_<SET> for include/cufhe_amd.hpp and -DORC_SET_<SET> for the oracle's
-    key generation and decryption) -- through the cufhe:: API: every gate of both orders decrypts to its truth table.  `smallmod` is
-    chosen with the reference's own definition, -DUSE_SMALL_NTT_MODULUS (CMakeLists.txt:26-28)."""
+    lvl0, test_api_gpu.cu's chains, test_intensive.cc, the ripple-carry adders, test_perf.cc's bootstraps to a TRLWE and -- except on
+    the small-modulus build, as in the reference -- test_cmux.cc's CMUXNTT / TRGSW2NTT) on another parameter set, chosen the way the
+    reference chooses: ONE selector, the numbers of the parameter structs (CMakeLists.txt:8-24, include/bootstrap_gpu.cuh:51-53).
+    include/cufhe_amd.hpp finds the library's set from those numbers.  `<set>`: the stand-in structs of the header take the set's
+    numbers (-DCUFHE_AMD_PARAM_SET_<SET>; `smallmod` with the reference's own -DUSE_SMALL_NTT_MODULUS, CMakeLists.txt:26-28);
+    `<set>-tfhepp`: -DCUFHE_AMD_USE_TFHEPP over tests/cpp/tfhepp_stub built with TFHEpp's own macro (USE_80BIT_SECURITY / USE_CONCRETE)
+    and NOTHING naming a set of this library.  -DORC_SET_<SET> selects the oracle's key generation and decryption."""
     import os
     import subprocess
-    root = ol.ROOT
-    exe = os.path.join(root, "tests", "cpp", "test_gate_api_" + name)
-    select = "-DUSE_SMALL_NTT_MODULUS" if name == "smallmod" else "-DCUFHE_AMD_PARAM_SET_" + name.upper()
-    subprocess.check_call(["g++", "-O2", "-std=c++17", select, "-DORC_SET_" + name.upper(), "-o", exe,
-                           os.path.join(root, "tests", "cpp", "test_gate_api.cpp"),
-                           "-L" + os.path.join(root, "cufhe_amd"), "-lcufhe_amd", "-L" + os.path.join(root, "oracle"), "-loracle_" + name,
-                           "-Wl,-rpath," + os.path.join(root, "cufhe_amd"), "-Wl,-rpath," + os.path.join(root, "oracle")])
+    import cpp_build
+    base = name.split("-")[0]
+    if name.endswith("-tfhepp"):
+        defines = ["-DUSE_80BIT_SECURITY" if base == "cggi16" else "-DUSE_CONCRETE", "-DORC_SET_" + base.upper()]
+    else:
+        defines = ["-DUSE_SMALL_NTT_MODULUS" if base == "smallmod" else "-DCUFHE_AMD_PARAM_SET_" + base.upper(), "-DORC_SET_" + base.upper()]
+    exe = cpp_build.build_gate_api("test_gate_api_" + name.replace("-", "_"), defines=defines, oracle="oracle_" + base, tfhepp=name.endswith("-tfhepp"))
     engine.CleanUp()
     try:
         out = subprocess.run([exe], capture_output=True, text=True, timeout=900)

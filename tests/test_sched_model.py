@@ -65,6 +65,13 @@ def test_random_programs_with_zero_copy_staging(harness):
     _run(harness, 60, 2, 0, zero_copy=1)
 
 
+def test_random_programs_on_one_device_without_workers(harness):
+    """One device, launches on the issuing thread: the configuration in which a caller's own work on a raw stream handle (Stream::st():
+    reads and writes of a ciphertext's device buffer between recorded gates) meets the densest program."""
+    _run(harness, 200, 1, 0)
+    _run(harness, 200, 2, 0, rename=1, zero_copy=1)
+
+
 def test_sanitizers(harness, tmp_path):
     """The same run under AddressSanitizer + UBSan (CPU build only), worker threads on."""
     exe = str(tmp_path / "sched_harness_asan")
@@ -83,3 +90,36 @@ def test_thread_sanitizer(harness, tmp_path):
         out = subprocess.run([exe, "12", "3", "1", rename, zero_copy], capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
         assert "ThreadSanitizer" not in out.stderr, out.stderr[:4000]
+
+
+# (what is broken, the exact source text, its replacement, harness arguments under which the break must show)
+MUTATIONS = [
+    ("the caller's stream no longer waits for the gates issued before Stream::st()",
+     "if (int rc = be_->caller_stream_wait(stream, g->done->ev)) return fail(rc, be_->error_text());", ";", ["120", "3", "1", "1", "0"]),
+    ("gates no longer wait for what the caller put on the raw handle before them",
+     "if (rc == 0) step(be_->wait_for_caller_stream(s, cs));", ";", ["200", "1", "0", "0", "0"]),
+    ("a device buffer the caller may have rewritten through the raw handle still stands for the result on its way to tlwehost",
+     "fence_epoch(c->host_stream) == c->host_epoch", "true", ["200", "1", "0", "0", "0"]),
+    ("a flush no longer waits for the flush on another internal stream that produces its inputs",
+     "g->deps.push_back(dg->done);", ";", ["120", "3", "1", "0", "0"]),
+    ("a write no longer follows the recorded readers of the buffer it overwrites",
+     "if (has_readers(po)) D = std::max(D, max_reader(po) + 1);         // write after read", ";", ["120", "3", "1", "0", "0"]),
+    ("a renamed value refreshed by an upload on another stream is not copied home for that stream's StreamQuery",
+     "pd.wstream != only_stream && pd.ustream != only_stream", "pd.wstream != only_stream", ["150", "3", "1", "1", "0"]),
+]
+
+
+@pytest.mark.parametrize("what,old,new,args", MUTATIONS, ids=[m[0][:40] for m in MUTATIONS])
+def test_harness_notices_a_broken_scheduler(tmp_path, what, old, new, args):
+    """The harness is only worth something if a scheduler with one ordering edge removed FAILS it: each mutation deletes one edge of
+    sched_core.h (a copy; the tree is not touched) and the random programs must report mismatches."""
+    core = open(os.path.join(ROOT, "cufhe_amd", "csrc", "sched_core.h")).read()
+    assert core.count(old) == 1, "mutation target moved: " + old
+    (tmp_path / "cufhe_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "tests" / "host").mkdir(parents=True)
+    (tmp_path / "cufhe_amd" / "csrc" / "sched_core.h").write_text(core.replace(old, new))
+    (tmp_path / "tests" / "host" / "sched_harness.cpp").write_text(open(SRC).read())
+    exe = str(tmp_path / "mutant")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, str(tmp_path / "tests" / "host" / "sched_harness.cpp")])
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0 and "FAIL" in out.stdout, "the harness passed a scheduler in which " + what
