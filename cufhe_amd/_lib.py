@@ -119,6 +119,8 @@ SIGNATURES = {
     "cufhe_amd_probe_clock": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "cufhe_amd_polymul512_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void, c_void]),
     "cufhe_amd_bootstrap_batch": (ctypes.c_int, [ctypes.c_int, c_void, ctypes.c_size_t, c_void, c_void]),
+    "cufhe_amd_device_cus": (ctypes.c_int, [ctypes.c_int]),
+    "cufhe_amd_device_mem_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "cufhe_amd_stream_fence": (ctypes.c_int, [ctypes.c_int, c_void]),
     "cufhe_amd_find_param_set": (ctypes.c_int, [ctypes.POINTER(ParamNumbers)]),
     "cufhe_amd_initialize_params": (ctypes.c_int, [ctypes.POINTER(ParamNumbers), c_void, ctypes.c_size_t, c_void, ctypes.c_size_t]),

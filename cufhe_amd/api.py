@@ -54,6 +54,18 @@ def device_identity(device=0):
     return dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
 
+def device_cus(device=0):
+    """compute units of a logical device ("cus_override" included): the unit of the launch-shape and flush rules"""
+    return check(lib.cufhe_amd_device_cus(int(device)))
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of the device (hipMemGetInfo)"""
+    f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib.cufhe_amd_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
+
+
 def Initialize(bk=None, ksk=None):
     """Initialize() / Initialize(ek): bk, ksk are the torus-domain keys as uint32 arrays."""
     if bk is None:
@@ -274,7 +286,8 @@ NMux, gNMux = _make3(NMUX, True), _make3(NMUX, False)
 def gate_batch(ops, level, out, in0, in1=None, in2=None, count=None, device=0, stream=None):
     """ops: one op code or an int array of `count` codes; operands are DeviceBuffers holding
     `count` contiguous ciphertexts."""
-    words = LVL_WORDS[level] if level in (0, 1) else 1     # a bad level is rejected by the library
+    # n + 1 / k N + 1 words of the set the gate entry points run on NOW ("param_set"): the library dispatches level 0 and 1 to that set
+    words = lib.cufhe_amd_ctxt_words(level) if level in (0, 1) else 1     # a bad level is rejected by the library
     if count is None:
         count = out.words // words
     if np.isscalar(ops):
@@ -445,3 +458,13 @@ def ps_keyswitch_batch(ps, tlwe1, tlwe0, count, device=0, stream=None):
 def ps_trlwe_op_batch(ps, op, out, inp, count, device=0, stream=None):
     """op: TL_BOOTSTRAP (lvl0 TLWEs -> TRLWEs), TL_REFRESH (TRLWEs -> TRLWEs) or TL_SEIKS (TRLWEs -> lvl0 TLWEs), device buffers of the set's sizes"""
     check(lib.cufhe_amd_ps_trlwe_op_batch(int(ps), device, stream, int(op), count, out.ptr, inp.ptr))
+
+
+def ps_trgsw_to_ntt_batch(ps, trgsw, trgsw_ntt, count, device=0, stream=None):
+    """TRGSW2NTT on a set: trgsw[count][(k+1)l][k+1][N] torus words -> trgsw_ntt[count][limbs][(k+1)l][k+1][N] doubles (2 words each)"""
+    check(lib.cufhe_amd_ps_trgsw_to_ntt_batch(int(ps), device, stream, count, trgsw.ptr, trgsw_ntt.ptr))
+
+
+def ps_cmux_batch(ps, trgsw_ntt, c1, c0, res, count, device=0, stream=None):
+    """CMUXNTT on a set: res = c0 + trgsw [x] (c1 - c0) on TRLWEs of (k+1) N words"""
+    check(lib.cufhe_amd_ps_cmux_batch(int(ps), device, stream, count, trgsw_ntt.ptr, c1.ptr, c0.ptr, res.ptr))

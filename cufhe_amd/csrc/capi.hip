@@ -88,6 +88,10 @@ struct DeviceState {
     std::mutex staging_mu;
 };
 
+// "cus_override" > 0: every launch-shape and flush rule behaves as on a device with that many CUs (a partitioned device, another
+// chip; the rules are all in CU units) -- what tests use to check that nothing is tied to MI355X's 256
+long g_cus_override = 0;
+int cus_of(const struct DeviceState& s);
 int g_gpu_num = 1;
 int g_device_base = 0;         // physical HIP device of logical device 0 (one process per GPU: LOCAL_RANK)
 long g_share_devices = 0;      // 1: logical devices beyond the visible GPUs wrap around (SetGPUNum(G) rehearsed on fewer GPUs)
@@ -121,6 +125,9 @@ int ks_auto_per_wg(size_t count, int cus)
 }
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
+// "br_shape": 0 = by the rules of launch_blind_rotate; 1 / 2 / 3 = every launch whole on the batch kernel (8 rotations per workgroup) / the
+// paired low-latency kernel (2 per workgroup) / the single one.  thread_local: the scheduler's launch worker picks a shape per launch.
+thread_local long g_br_shape = 0;
 long g_tail_split = 1;         // 1: launches above one grid round are cut into full rounds + a tail that takes the cheapest kernel
 // N = 2048 blind rotation: 1 = four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h); 0 = eight half waves, one
 // rotation per CU (kernels_lvl2.hip.h); -1 = by measured cost: a launch that leaves CUs with a single rotation (<= one per CU) is
@@ -130,6 +137,7 @@ long g_lvl2_kernel = -1;
 long g_lvl0_ring = 1024;       // ring through which gates on lvl0 ciphertexts bootstrap: 1024 (lvl01/lvl10) or 2048 (lvl02/lvl20)
 constexpr int kMaxLogicalDevices = 64;    // SetGPUNum bound (per-device tables of fixed size: paramsets.inc.h)
 std::deque<DeviceState> g_dev(1);    // re-created only while no device is initialised (SetGPUNum)
+int cus_of(const DeviceState& s) { return g_cus_override > 0 ? (int)g_cus_override : s.cus; }
 std::mutex g_mu;
 
 // ---- exact host arithmetic for the tables ----
@@ -320,6 +328,18 @@ std::string device_local_cpulist(int phys)
     std::string out(ok ? line : "");
     while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
     return out;
+}
+
+// Device allocations of the Initialize entry points go through here: "test_fail_alloc" n makes the (n+1)-th one fail like an exhausted
+// device (then disarms itself), so that the error paths -- the old keys stay loaded and usable, nothing leaks -- can be exercised
+long g_fail_alloc_countdown = -1;
+hipError_t init_malloc(void** p, size_t bytes)
+{
+    if (g_fail_alloc_countdown >= 0 && g_fail_alloc_countdown-- == 0) {
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(p, bytes);
 }
 
 int check_device(int device)
@@ -536,7 +556,7 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     // rotation, 3.3 ms per started round of one rotation per CU), its paired form (two per CU, 5.3 - 5.8 ms), the batch
     // kernel with one rotation per SIMD (~12 ms per round of four per CU), a full round.  All variants compute identical
     // words.  Every rule below is in units of the device's CU count (MI355X: 256; the measured milliseconds are that chip's).
-    const size_t cu = (size_t)std::max(1, s.cus);
+    const size_t cu = (size_t)std::max(1, cus_of(s));
     const size_t kRound = cu * kBrWavesPerBlock;
     auto launch_batch = [&](const LinDesc* dd, size_t n, int active, uint32_t* dump) {
         const unsigned blocks = (unsigned)((n + active - 1) / active);
@@ -591,6 +611,20 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
             launch_batch(dd, n, kBrWavesPerBlock, dump);
         }
     };
+    if (g_br_shape > 0) {
+        // a caller that places launches itself (the two-lane scheduler, tools/two_lane_probe.py): the whole launch on one kernel
+        if (g_br_shape == 1) launch_batch(d, count, kBrWavesPerBlock, acc_dump);
+        else if (g_br_shape == 2) launch_ll2(d, count, acc_dump);
+        else launch_ll(d, count, acc_dump);
+        HIP_TRY(hipGetLastError());
+        if (s.profiling) {
+            HIP_TRY(hipEventRecord(ev.b, st));
+            ev.units = count;
+            std::lock_guard<std::mutex> lk(s.staging_mu);
+            s.br_events.push_back(ev);
+        }
+        return 0;
+    }
     const size_t tail = count % kRound;
     const long tail_max = std::max(auto_half ? (long)(4 * cu) : g_half_threshold, auto_ll ? (long)((g_ll2_threshold < 0 ? 6 : 5) * cu) : g_ll_threshold);
     if (g_tail_split && count > kRound && tail != 0 && (long)tail <= tail_max) {
@@ -622,8 +656,8 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
         s.ks_lds_opt_in = true;
     }
-    const long split_max = g_ks_split_threshold < 0 ? ks_auto_split(s.cus) : g_ks_split_threshold;
-    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(s.cus) : g_ks_wg_threshold;
+    const long split_max = g_ks_split_threshold < 0 ? ks_auto_split(cus_of(s)) : g_ks_split_threshold;
+    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(cus_of(s)) : g_ks_wg_threshold;
     if ((long)count <= split_max) {
         hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
         hipLaunchKernelGGL(keyswitch_split_kernel, dim3((unsigned)count * kKsSplit), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
@@ -631,7 +665,7 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
         // as few ciphertexts per workgroup as still fit one grid round of 256 workgroups (g_ks_per_wg: -1 by count, else 1..16)
-        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, s.cus);
+        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, cus_of(s));
         const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg);
         hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk, per_wg);
     }
@@ -666,6 +700,7 @@ int run_gates_lvl2(int device, void* stream, size_t count, GetGate get);   // lv
 template <class GetGate>
 int run_gates_ps(int set, int device, void* stream, int level, size_t count, GetGate get);   // paramsets.inc.h
 int ps_ctxt_words(int set, int level);
+void lvl2_release_host_key();          // lvl2.inc.h
 // a TRGSW holder's device slot (ciphertext handle of level 3) fits the NTT-domain TRGSW of every compiled set, key limbs included
 template <class PS> constexpr int kTrgswNttWordsOf = (int)(2 * PsDims<PS>::bk_ntt_step_doubles);
 constexpr int kMaxTrgswNttWords = std::max({(int)(2 * kBkStepDoubles), kTrgswNttWordsOf<PsDefault>, kTrgswNttWordsOf<PsK2N512>, kTrgswNttWordsOf<PsCggi16>});
@@ -902,6 +937,25 @@ int cufhe_amd_device_identity(int device, char* buf, size_t len)
     return 0;
 }
 
+int cufhe_amd_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+    if (int rc = use_device(device)) return rc;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
+int cufhe_amd_device_cus(int device)
+{
+    if (int rc = check_device(device)) return rc;
+    if (g_cus_override > 0) return (int)g_cus_override;
+    int n = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, phys_device(device)));
+    return n;
+}
+
 int cufhe_amd_set_gpu_num(int gpu_num)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -940,34 +994,53 @@ int cufhe_amd_initialize(const uint32_t* bk, size_t bk_words, const uint32_t* ks
     if (!bk || !ksk) return fail(-1, "null key pointer");
     if (bk_words != want_bk) return fail(-1, "bootstrapping key has the wrong size for this parameter set");
     if (ksk_words != want_ksk) return fail(-1, "key-switching key has the wrong size for this parameter set");
+    // Build first, swap last: the new keys of EVERY device are allocated and converted beside whatever is loaded; only when all of that
+    // has succeeded do they replace the old ones.  A failure on the way (a full device: 104 MB per replica) frees what this call
+    // allocated and leaves every device with the keys -- and the results -- it had.
+    struct Built { double* bk_ntt = nullptr; uint32_t* ksk = nullptr; uint32_t* d_bk = nullptr; };
+    std::vector<Built> built((size_t)g_gpu_num);
+    struct Undo {
+        std::vector<Built>& b; bool armed = true;
+        ~Undo()
+        {
+            for (size_t i = 0; i < b.size(); i++) {
+                if (!b[i].bk_ntt && !b[i].ksk && !b[i].d_bk) continue;
+                (void)hipSetDevice(phys_device((int)i));
+                (void)hipFree(b[i].d_bk);
+                if (armed) { (void)hipFree(b[i].bk_ntt); (void)hipFree(b[i].ksk); }
+            }
+        }
+    } undo{built};
     for (int i = 0; i < g_gpu_num; i++) {
         if (int rc = ensure_ntt(i)) return rc;
         DeviceState& s = g_dev[i];
+        Built& b = built[(size_t)i];
         HIP_TRY(hipSetDevice(phys_device(i)));
-        if (s.keys_ready) {
-            HIP_TRY(hipFree(s.bk_ntt));
-            HIP_TRY(hipFree(s.ksk));
-            s.keys_ready = false;
-        }
-        HIP_TRY(hipMalloc((void**)&s.bk_ntt, want_bk * sizeof(double)));
+        HIP_TRY(init_malloc((void**)&b.bk_ntt, want_bk * sizeof(double)));
         const size_t ksk_rows = want_ksk / kKsRowWords;
-        HIP_TRY(hipMalloc((void**)&s.ksk, ksk_rows * kKsRowPad * sizeof(uint32_t)));
-        uint32_t* d_bk = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_bk, want_bk * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(init_malloc((void**)&b.ksk, ksk_rows * kKsRowPad * sizeof(uint32_t)));
+        HIP_TRY(init_malloc((void**)&b.d_bk, want_bk * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(b.d_bk, bk, want_bk * sizeof(uint32_t), hipMemcpyHostToDevice));
         // KeySwitchingKeyToDevice (src/keyswitch_gpu.cu:6-16), rows padded 631 -> 640 words
-        HIP_TRY(hipMemset(s.ksk, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy2D(s.ksk, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
+        HIP_TRY(hipMemset(b.ksk, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy2D(b.ksk, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
                             kKsRowWords * sizeof(uint32_t), ksk_rows, hipMemcpyHostToDevice));
         const size_t polys = want_bk / kN;
         const unsigned blocks = (unsigned)((polys + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
-        hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, 0, s.bk_ntt, d_bk,
+        hipLaunchKernelGGL(bk_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttLdsBytes, 0, b.bk_ntt, b.d_bk,
                            polys, s.tables, n_inverse_balanced());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(d_bk));
+        HIP_TRY(hipDeviceSynchronize());        // also: nothing on this device still reads the keys that are about to go
+    }
+    for (int i = 0; i < g_gpu_num; i++) {
+        DeviceState& s = g_dev[i];
+        (void)hipSetDevice(phys_device(i));
+        if (s.keys_ready) { (void)hipFree(s.bk_ntt); (void)hipFree(s.ksk); }
+        s.bk_ntt = built[(size_t)i].bk_ntt;
+        s.ksk = built[(size_t)i].ksk;
         s.keys_ready = true;
     }
+    undo.armed = false;        // the guard still frees the torus-domain staging copies
     return 0;
 }
 
@@ -989,7 +1062,7 @@ int cufhe_amd_cleanup(void)
         }
         if (s.keys_ready) { HIP_TRY(hipFree(s.bk_ntt)); HIP_TRY(hipFree(s.ksk)); }
         ps_release(i);
-        if (s.keys2_ready) { HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.bk2q_ntt)); HIP_TRY(hipFree(s.ksk2)); }
+        if (s.keys2_ready) { if (s.bk2_ntt) HIP_TRY(hipFree(s.bk2_ntt)); HIP_TRY(hipFree(s.bk2q_ntt)); HIP_TRY(hipFree(s.ksk2)); }
         if (s.tables2) HIP_TRY(hipFree(s.tables2));
         if (s.tables2q) HIP_TRY(hipFree(s.tables2q));
         s.keys2_ready = s.br2_lds_opt_in = s.br2q_lds_opt_in = s.ks2_lds_opt_in = false;
@@ -1005,6 +1078,7 @@ int cufhe_amd_cleanup(void)
         s.tables = nullptr; s.tables_r4 = nullptr; s.tables512 = nullptr; s.bk_ntt = nullptr; s.ksk = nullptr;
         s.prof = cufhe_amd_profile{};
     }
+    lvl2_release_host_key();
     return 0;
 }
 
@@ -1126,6 +1200,10 @@ int cufhe_amd_gate_batch(int device, void* stream, int level, size_t count, cons
                          size_t stride_words)
 {
     if (!ops) return fail(-1, "null ops");
+    // the kernels move the ciphertext size of the set the entry point runs on ("param_set" / "lvl0_ring"): a smaller stride would make
+    // neighbouring ciphertexts overlap and the last one run past the buffer
+    if (count > 1 && (level == 0 || level == 1) && (long)stride_words < (long)cufhe_amd_ctxt_words(level))
+        return fail(-1, "stride_words is smaller than a ciphertext of the active parameter set (cufhe_amd_ctxt_words)");
     return run_gates(device, stream, level, count, [&](size_t g) {
         return GateRef{ops[g * (size_t)ops_stride], out + g * stride_words, in0 ? in0 + g * stride_words : nullptr,
                        in1 ? in1 + g * stride_words : nullptr, in2 ? in2 + g * stride_words : nullptr};
@@ -1378,21 +1456,23 @@ int cufhe_amd_set_option(const char* key, long value)
     }
     if (!strcmp(key, "sched_level_gates") || !strcmp(key, "sched_total_gates")) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
-        if (value < 1) return fail(-1, "value out of range");
+        if (value < 1 && !(key[6] == 'l' && value == -1)) return fail(-1, "value out of range (sched_level_gates: -1 = two grid rounds of the device)");
         (key[6] == 'l' ? g_sched_level_gates : g_sched_total_gates) = value;
-        if (g_scheduler)
-            for (int d = 0; d < g_scheduler->gpu_num(); d++) {
-                g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
-                g_scheduler->dev(d).idle_flush_gates = (size_t)std::min(g_sched_level_gates, 2048L);
-                g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
-            }
+        sched_apply_settings();
+        return 0;
+    }
+    if (!strcmp(key, "test_fail_alloc")) { g_fail_alloc_countdown = value; return 0; }
+    if (!strcmp(key, "cus_override")) {
+        if (value < 0 || value > 4096) return fail(-1, "cus_override must be 0 (the device's own CU count) or a CU count");
+        g_cus_override = value;
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        sched_apply_settings();        // the scheduler's flush rules are in grid rounds of 8 rotations per CU
         return 0;
     }
     if (!strcmp(key, "sched_rename")) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
         g_sched_rename = value != 0;
-        if (g_scheduler)
-            for (int d = 0; d < g_scheduler->gpu_num(); d++) g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
+        sched_apply_settings();
         return 0;
     }
     if (!strcmp(key, "sched_affinity")) { g_sched_affinity = value != 0; return 0; }
@@ -1401,6 +1481,11 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "ll_threshold")) { g_ll_threshold = value; return 0; }
     if (!strcmp(key, "half_threshold")) { g_half_threshold = value; return 0; }
     if (!strcmp(key, "tail_split")) { g_tail_split = value; return 0; }
+    if (!strcmp(key, "br_shape")) {
+        if (value < 0 || value > 3) return fail(-1, "br_shape must be 0 (rules), 1 (batch kernel), 2 (paired low-latency kernel) or 3 (single)");
+        g_br_shape = value;        // of the calling thread
+        return 0;
+    }
     if (!strcmp(key, "ks_wg_threshold")) { g_ks_wg_threshold = value; return 0; }
     if (!strcmp(key, "ks_split_threshold")) { g_ks_split_threshold = value; return 0; }
     if (!strcmp(key, "ps_batch_threshold")) { g_ps_batch_threshold = value; return 0; }

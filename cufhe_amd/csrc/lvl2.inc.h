@@ -70,6 +70,40 @@ int ensure_tables_lvl2(int device)
     return 0;
 }
 
+// The half-transform kernel's layout of the key (495 MB) is built on first use: the quarter-transform kernel serves every launch above
+// one rotation per CU, so a process that only ever runs batches never pays for the second layout.  The torus-domain key is kept on the
+// HOST for that (165 MB of ordinary memory, once per process), not on the devices.
+std::vector<uint64_t> g_bk2_host;
+std::mutex g_bk2_mu;
+int ensure_bk2_half_layout(DeviceState& s)
+{
+    std::lock_guard<std::mutex> lk(g_bk2_mu);
+    if (s.bk2_ntt) return 0;
+    if (g_bk2_host.empty()) return fail(-3, "cufhe_amd_lvl2_initialize has not been called");
+    const size_t want_bk = g_bk2_host.size();
+    uint64_t* d_bk = nullptr;
+    double* half = nullptr;
+    struct Undo { uint64_t*& d; double*& h; bool armed = true; ~Undo() { (void)hipFree(d); if (armed) (void)hipFree(h); } } undo{d_bk, half};
+    HIP_TRY(init_malloc((void**)&half, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
+    HIP_TRY(init_malloc((void**)&d_bk, want_bk * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(d_bk, g_bk2_host.data(), want_bk * sizeof(uint64_t), hipMemcpyHostToDevice));
+    const size_t polys = want_bk / k2N, waves = polys * k2Limbs;
+    const unsigned blocks = (unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
+    hipLaunchKernelGGL(bk2_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttWavesPerBlock * kTileBytes, 0,
+                       half, d_bk, polys, s.tables2, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());        // complete before any stream's kernel reads it
+    undo.armed = false;
+    s.bk2_ntt = half;
+    return 0;
+}
+
+void lvl2_release_host_key()
+{
+    std::lock_guard<std::mutex> lk(g_bk2_mu);
+    std::vector<uint64_t>().swap(g_bk2_host);
+}
+
 int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, size_t count, int steps, uint64_t* acc_dump)
 {
     if (count == 0) return 0;
@@ -79,7 +113,7 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    const bool quarters = g_lvl2_kernel < 0 ? (long)count > (s.cus > 0 ? s.cus : 256) : g_lvl2_kernel == 1;
+    const bool quarters = g_lvl2_kernel < 0 ? (long)count > (cus_of(s) > 0 ? cus_of(s) : 256) : g_lvl2_kernel == 1;
     if (quarters) {
         // four quarter waves per rotation, two rotations per CU (kernels_lvl2q.hip.h)
         if (!s.br2q_lds_opt_in) {
@@ -89,6 +123,7 @@ int launch_blind_rotate_lvl2(DeviceState& s, hipStream_t st, const RotDesc2* d, 
         hipLaunchKernelGGL(blind_rotate_lvl2q_kernel, dim3((unsigned)count), dim3(kQThreads), kQLdsBytes, st, d, (int)count,
                            s.bk2q_ntt, s.tables2q, steps, acc_dump);
     } else {
+        if (int rc = ensure_bk2_half_layout(s)) return rc;
         if (!s.br2_lds_opt_in) {
             HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_lvl2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3LdsBytes));
             s.br2_lds_opt_in = true;
@@ -117,7 +152,7 @@ int launch_keyswitch_lvl2(DeviceState& s, hipStream_t st, const LinDesc64* d, si
     }
     // a workgroup per ciphertext costs 2.1 us per ciphertext (8.5 ms per 4096 on 256 CUs), the shared-table kernel 3.1 ms per launch:
     // the first up to 1400 = 5.5 ciphertexts per CU
-    if ((long)count <= (g_ks_wg_threshold < 0 ? 11L * std::max(1, s.cus) / 2 : g_ks_wg_threshold)) {
+    if ((long)count <= (g_ks_wg_threshold < 0 ? 11L * std::max(1, cus_of(s)) / 2 : g_ks_wg_threshold)) {
         // a workgroup per ciphertext, rows from L2: lowest latency for small and middle-sized launches
         hipLaunchKernelGGL(keyswitch_lvl2_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk2);
     } else {
@@ -230,56 +265,58 @@ int cufhe_amd_lvl2_initialize(const uint64_t* bk, size_t bk_words, const uint32_
     if (!bk || !ksk) return fail(-1, "null key pointer");
     if (bk_words != want_bk) return fail(-1, "lvl02 bootstrapping key has the wrong size for this parameter set");
     if (ksk_words != want_ksk) return fail(-1, "lvl20 key-switching key has the wrong size for this parameter set");
+    // build first, swap last (as cufhe_amd_initialize): the quarter-transform layout and the key-switching key of every device beside
+    // what is loaded; the half-transform layout follows on first use (ensure_bk2_half_layout)
+    struct Built { double* bk2q = nullptr; uint32_t* ksk2 = nullptr; uint64_t* d_bk = nullptr; };
+    std::vector<Built> built((size_t)g_gpu_num);
+    struct Undo {
+        std::vector<Built>& b; bool armed = true;
+        ~Undo()
+        {
+            for (size_t i = 0; i < b.size(); i++) {
+                if (!b[i].bk2q && !b[i].ksk2 && !b[i].d_bk) continue;
+                (void)hipSetDevice(phys_device((int)i));
+                (void)hipFree(b[i].d_bk);
+                if (armed) { (void)hipFree(b[i].bk2q); (void)hipFree(b[i].ksk2); }
+            }
+        }
+    } undo{built};
     for (int i = 0; i < g_gpu_num; i++) {
         if (int rc = ensure_tables_lvl2(i)) return rc;
         DeviceState& s = g_dev[i];
+        Built& b = built[(size_t)i];
         HIP_TRY(hipSetDevice(phys_device(i)));
-        if (s.keys2_ready) {
-            HIP_TRY(hipDeviceSynchronize());
-            s.keys2_ready = false;
-            (void)hipFree(s.bk2_ntt);
-            (void)hipFree(s.bk2q_ntt);
-            (void)hipFree(s.ksk2);
-            s.bk2_ntt = s.bk2q_ntt = nullptr;
-            s.ksk2 = nullptr;
-        }
-        // about 1 GB per device (the key in both kernel layouts): whatever was allocated goes again if a later step fails -- keys2_ready
-        // stays false then, and cleanup only frees what is marked ready
-        uint64_t* d_bk = nullptr;
-        struct Undo {
-            DeviceState& s; uint64_t*& d_bk; bool armed = true;
-            ~Undo()
-            {
-                (void)hipFree(d_bk);
-                if (!armed) return;
-                (void)hipFree(s.bk2_ntt); (void)hipFree(s.bk2q_ntt); (void)hipFree(s.ksk2);
-                s.bk2_ntt = s.bk2q_ntt = nullptr;
-                s.ksk2 = nullptr;
-            }
-        } undo{s, d_bk};
-        HIP_TRY(hipMalloc((void**)&s.bk2_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&s.bk2q_ntt, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
+        HIP_TRY(init_malloc((void**)&b.bk2q, (size_t)kLvl0N * k2BkStepDoubles * sizeof(double)));
         const size_t ksk_rows = want_ksk / kKsRowWords;
-        HIP_TRY(hipMalloc((void**)&s.ksk2, ksk_rows * kKsRowPad * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(s.ksk2, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy2D(s.ksk2, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
+        HIP_TRY(init_malloc((void**)&b.ksk2, ksk_rows * kKsRowPad * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(b.ksk2, 0, ksk_rows * kKsRowPad * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy2D(b.ksk2, kKsRowPad * sizeof(uint32_t), ksk, kKsRowWords * sizeof(uint32_t),
                             kKsRowWords * sizeof(uint32_t), ksk_rows, hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void**)&d_bk, want_bk * sizeof(uint64_t)));
-        HIP_TRY(hipMemcpy(d_bk, bk, want_bk * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(init_malloc((void**)&b.d_bk, want_bk * sizeof(uint64_t)));
+        HIP_TRY(hipMemcpy(b.d_bk, bk, want_bk * sizeof(uint64_t), hipMemcpyHostToDevice));
         const size_t polys = want_bk / k2N;
         const size_t waves = polys * k2Limbs;
         const unsigned blocks = (unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
-        hipLaunchKernelGGL(bk2_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttWavesPerBlock * kTileBytes, 0,
-                           s.bk2_ntt, d_bk, polys, s.tables2, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
-        HIP_TRY(hipGetLastError());
-        // the same key in the layout of the quarter-transform kernel (both are kept: "lvl2_kernel" selects at run time)
         hipLaunchKernelGGL(bk2q_to_ntt_kernel, dim3(blocks), dim3(kNttThreads), kNttWavesPerBlock * kTile512Bytes, 0,
-                           s.bk2q_ntt, d_bk, polys, s.tables2q, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
+                           b.bk2q, b.d_bk, polys, s.tables2q, balanced(powmod_u64(k2N, fpf::P_U64 - 2)));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
-        undo.armed = false;          // d_bk is freed by the guard
-        s.keys2_ready = true;
+        HIP_TRY(hipDeviceSynchronize());        // also: nothing on this device still reads the keys that are about to go
     }
+    {
+        std::lock_guard<std::mutex> lk2(g_bk2_mu);
+        g_bk2_host.assign(bk, bk + want_bk);
+        for (int i = 0; i < g_gpu_num; i++) {
+            DeviceState& s = g_dev[i];
+            (void)hipSetDevice(phys_device(i));
+            if (s.keys2_ready) { (void)hipFree(s.bk2q_ntt); (void)hipFree(s.ksk2); }
+            (void)hipFree(s.bk2_ntt);          // the half layout of the OLD key, if it was ever built
+            s.bk2_ntt = nullptr;
+            s.bk2q_ntt = built[(size_t)i].bk2q;
+            s.ksk2 = built[(size_t)i].ksk2;
+            s.keys2_ready = true;
+        }
+    }
+    undo.armed = false;        // the guard still frees the torus-domain staging copies
     return 0;
 }
 

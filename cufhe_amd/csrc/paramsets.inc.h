@@ -32,7 +32,7 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
     if (count == 0) return 0;
     EventPair ev{};
     if (int rc = prof_begin(s, st, ev)) return rc;
-    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(s.cus) : g_ks_wg_threshold;
+    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(cus_of(s)) : g_ks_wg_threshold;
     if ((long)count > wg_max && ps.ksk_padded) {
         // 16 ciphertexts per workgroup, table rows through LDS
         const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
@@ -41,7 +41,7 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
                 HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
                 s.ks_lds_opt_in = true;
             }
-            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, s.cus);
+            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, cus_of(s));
             hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count,
                                ps.ksk_padded, per_wg);
         } else {
@@ -100,7 +100,7 @@ int ps_launch_blind_rotate(DeviceState& s, PsState& ps, hipStream_t st, const Li
         HIP_TRY(hipFuncSetAttribute((const void*)blind_rotate_ps_batch_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsbLds<PS>::bytes));
         ps.lds_opt_in = true;
     }
-    if ((long)count >= (g_ps_batch_threshold < 0 ? ps_auto_batch<PS>(s.cus) : g_ps_batch_threshold)) {
+    if ((long)count >= (g_ps_batch_threshold < 0 ? ps_auto_batch<PS>(cus_of(s)) : g_ps_batch_threshold)) {
         // one wave per rotation, 8 rotations per workgroup share the key rows (throughput shape)
         const unsigned blocks = (unsigned)((count + PsbLds<PS>::waves - 1) / PsbLds<PS>::waves);
         hipLaunchKernelGGL(blind_rotate_ps_batch_kernel<PS>, dim3(blocks), dim3(PsbLds<PS>::threads), PsbLds<PS>::bytes, st, d, (int)count,
@@ -404,41 +404,58 @@ int cufhe_amd_ps_initialize(int set, const uint32_t* bk, size_t bk_words, const 
         using PO = Poly<PS::Nbit>;
         if (bk_words != D::bk_words) return fail(-1, "bootstrapping key has the wrong size for this parameter set");
         if (ksk_words != D::ksk_words) return fail(-1, "key-switching key has the wrong size for this parameter set");
+        // build first, swap last (as cufhe_amd_initialize): a failure leaves every device with the keys of this set it had
+        std::vector<PsState> built((size_t)g_gpu_num);
+        std::vector<uint32_t*> d_bk((size_t)g_gpu_num, nullptr);
+        struct Undo {
+            std::vector<PsState>& b; std::vector<uint32_t*>& d; bool armed = true;
+            ~Undo()
+            {
+                for (size_t i = 0; i < b.size(); i++) {
+                    if (!d[i] && !b[i].bk_ntt && !b[i].ksk && !b[i].ksk_padded) continue;
+                    (void)hipSetDevice(phys_device((int)i));
+                    (void)hipFree(d[i]);
+                    if (armed) { (void)hipFree(b[i].bk_ntt); (void)hipFree(b[i].ksk); (void)hipFree(b[i].ksk_padded); }
+                }
+            }
+        } undo{built, d_bk};
         for (int i = 0; i < g_gpu_num; i++) {
             if (int rc = ensure_ntt(i)) return rc;
             DeviceState& s = g_dev[i];
-            PsState& ps = ps_state(set, i);
+            PsState& ps = built[(size_t)i];
             HIP_TRY(hipSetDevice(phys_device(i)));
-            if (ps.ready) {
-                HIP_TRY(hipDeviceSynchronize());
-                HIP_TRY(hipFree(ps.bk_ntt));
-                HIP_TRY(hipFree(ps.ksk));
-                if (ps.ksk_padded) HIP_TRY(hipFree(ps.ksk_padded));
-                ps = PsState{};
-            }
-            HIP_TRY(hipMalloc((void**)&ps.bk_ntt, (size_t)PS::n * D::bk_ntt_step_doubles * sizeof(double)));
-            HIP_TRY(hipMalloc((void**)&ps.ksk, D::ksk_words * sizeof(uint32_t)));
+            HIP_TRY(init_malloc((void**)&ps.bk_ntt, (size_t)PS::n * D::bk_ntt_step_doubles * sizeof(double)));
+            HIP_TRY(init_malloc((void**)&ps.ksk, D::ksk_words * sizeof(uint32_t)));
             HIP_TRY(hipMemcpy(ps.ksk, ksk, D::ksk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
             {      // the same table with rows padded to a multiple of 64 words, for the shared-table kernels
                 constexpr size_t w0 = D::lvl0_words, pad = PsKs<PS>::row_pad;
                 const size_t ksk_rows = D::ksk_words / w0;
-                HIP_TRY(hipMalloc((void**)&ps.ksk_padded, ksk_rows * pad * sizeof(uint32_t)));
+                HIP_TRY(init_malloc((void**)&ps.ksk_padded, ksk_rows * pad * sizeof(uint32_t)));
                 HIP_TRY(hipMemset(ps.ksk_padded, 0, ksk_rows * pad * sizeof(uint32_t)));
                 HIP_TRY(hipMemcpy2D(ps.ksk_padded, pad * sizeof(uint32_t), ksk, w0 * sizeof(uint32_t), w0 * sizeof(uint32_t), ksk_rows,
                                     hipMemcpyHostToDevice));
             }
-            uint32_t* d_bk = nullptr;
-            HIP_TRY(hipMalloc((void**)&d_bk, D::bk_words * sizeof(uint32_t)));
-            HIP_TRY(hipMemcpy(d_bk, bk, D::bk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(init_malloc((void**)&d_bk[(size_t)i], D::bk_words * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpy(d_bk[(size_t)i], bk, D::bk_words * sizeof(uint32_t), hipMemcpyHostToDevice));
             const size_t polys = D::bk_words / D::N, waves = polys * PS::limbs;
             const unsigned blocks = (unsigned)((waves + kNttWavesPerBlock - 1) / kNttWavesPerBlock);
             hipLaunchKernelGGL(bk_to_ntt_ps_kernel<PS>, dim3(blocks), dim3(kNttThreads), PO::table_bytes + kNttWavesPerBlock * PO::tile_bytes, 0,
-                               ps.bk_ntt, d_bk, polys, ps_tables<PS>(s), balanced(powmod_u64(D::N, fpf::P_U64 - 2)));
+                               ps.bk_ntt, d_bk[(size_t)i], polys, ps_tables<PS>(s), balanced(powmod_u64(D::N, fpf::P_U64 - 2)));
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(d_bk));
+            HIP_TRY(hipDeviceSynchronize());        // also: nothing on this device still reads the keys that are about to go
+        }
+        for (int i = 0; i < g_gpu_num; i++) {
+            PsState& ps = ps_state(set, i);
+            (void)hipSetDevice(phys_device(i));
+            if (ps.ready) {
+                (void)hipFree(ps.bk_ntt);
+                (void)hipFree(ps.ksk);
+                if (ps.ksk_padded) (void)hipFree(ps.ksk_padded);
+            }
+            ps = built[(size_t)i];
             ps.ready = true;
         }
+        undo.armed = false;
         return 0;
     });
 }

@@ -72,6 +72,9 @@ class Backend {
     // returns the number of CPUs the thread was pinned to (0: left to the OS)
     virtual int bind_worker_thread() { bind_thread(); return 0; }
     virtual int num_streams() = 0;
+    // gates of one full-throughput launch of this device (a grid round: 8 rotations per compute unit on the HIP backend); the
+    // scheduler's flush rules are multiples of it
+    virtual size_t round_gates() { return 2048; }
     virtual int words(int level) = 0;                                 // words of a level-`level` ciphertext (what copies move)
     virtual int slot_words(int level) { return words(level); }        // words a device slot must hold (>= words(level) at any time)
     virtual int alloc_device(size_t bytes, void** p) = 0;
@@ -276,6 +279,7 @@ class DeviceSched {
         : owner_(owner), device_(device), be_(be), threaded_(threaded)
     {
         nstreams_ = std::max(1, be_->num_streams());
+        set_round_gates(be_->round_gates());
         if (threaded_) worker_ = std::thread([this] { worker_loop(); });
     }
     ~DeviceSched()
@@ -381,9 +385,22 @@ class DeviceSched {
     // A front level this full is launched at once: two rounds of the blind-rotate grid while the device still has work (102.5 k
     // gates/s per launch against 100.3 k for one round; 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s), ONE round when
     // the device is idle -- nothing to overlap the recording of the second round with (4096 gates: 43.7 ms against 44.5 - 50).
-    size_t level_flush_gates = 4096;
-    size_t idle_flush_gates = 2048;
+    // Both in grid rounds of the device (Backend::round_gates; MI355X: 8 rotations on each of its 256 CUs), set by set_round_gates.
+    size_t level_flush_gates = 0;
+    size_t idle_flush_gates = 0;
     size_t total_flush_gates = 32768;  // bound on the recorded program
+    void set_round_gates(size_t round)
+    {
+        round_gates_ = std::max<size_t>(8, round);
+        level_flush_gates = 2 * round_gates_;
+        idle_flush_gates = round_gates_;
+    }
+    void set_level_flush_gates(size_t gates)       // an explicit flush size ("sched_level_gates"); the idle rule never exceeds it
+    {
+        level_flush_gates = std::max<size_t>(1, gates);
+        idle_flush_gates = std::min(level_flush_gates, round_gates_);
+    }
+    size_t round_gates() const { return round_gates_; }
     // Renaming: an output whose device buffer still has recorded users (an earlier write not yet superseded, readers of
     // the old value) takes a FRESH buffer instead of waiting for them, so that only true data dependences order the
     // program (a temporary re-used down a ripple-carry chain no longer serialises the adders' independent gates).  The
@@ -567,6 +584,7 @@ class DeviceSched {
     Backend* be_;
     bool threaded_;
     int nstreams_ = 1;
+    size_t round_gates_ = 2048;
     int rr_ = 0;
     uint64_t worker_cpus_ = 0;
     std::deque<GroupTrace> trace_;
@@ -1058,7 +1076,8 @@ inline int DeviceSched::after_record()
     // level waits for the caller's Synchronize, up to eight rounds.
     if (!levels_.empty()) {
         const size_t front = levels_.front()->gate_count();
-        if (front >= idle_flush_gates && front < level_flush_gates && (front - idle_flush_gates) % 256 == 0 && levels_.size() == 1 && device_idle())
+        // (the idle check polls events: only once per workgroup-per-CU's worth of gates)
+        if (front >= idle_flush_gates && front < level_flush_gates && (front - idle_flush_gates) % std::max<size_t>(1, round_gates_ / 8) == 0 && levels_.size() == 1 && device_idle())
             return flush(1);
         if (front >= level_flush_gates &&
             (levels_.size() == 1 || 2 * levels_[1]->gate_count() >= level_flush_gates || front >= 8 * level_flush_gates))

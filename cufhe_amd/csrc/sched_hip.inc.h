@@ -12,7 +12,7 @@ namespace {
 
 long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
-long g_sched_level_gates = 4096; // a dependence level this full is launched at once (two rounds of the batch kernel's grid)
+long g_sched_level_gates = -1;   // a dependence level this full is launched at once: -1 = two rounds of the batch kernel's grid (8 rotations per CU each), one when the device is idle
 long g_sched_total_gates = 32768;
 long g_sched_rename = 1;          // outputs take fresh device buffers instead of waiting for the old one's users, values return to the ciphertext's own buffer before the host may look (sched_core.h); 0: never
 long g_sched_zero_copy = 1;       // 1: ciphertext staging is read / written by the scatter / gather kernels in pinned host memory (no copy-engine step)
@@ -63,6 +63,14 @@ class HipBackend : public sched::Backend {
         return n;
     }
     int num_streams() override { return (int)(g_sched_streams < 1 ? 1 : g_sched_streams); }
+    // one full-throughput round of the blind-rotate grid: a workgroup of 8 rotations per CU (capi.hip: launch_blind_rotate)
+    size_t round_gates() override
+    {
+        int cus = 0;
+        if (g_cus_override > 0) cus = (int)g_cus_override;
+        else if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, phys_device(device_)) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+        return (size_t)kBrWavesPerBlock * (size_t)(cus > 0 ? cus : 256);
+    }
     int words(int level) override
     {
         if (g_param_set >= 0) return ps_ctxt_words((int)g_param_set, level);       // the active parameter set's sizes (2: a TRLWE, 3: a TRGSW in the NTT domain)
@@ -286,6 +294,20 @@ std::vector<sched::Scheduler*> g_parked;
 std::unordered_map<cufhe_amd_ctxt*, sched::Scheduler*> g_ctxt_owner;
 std::mutex g_sched_mu;     // the reference API is single-issuer; this only guards against misuse
 
+// the options that shape the scheduler, applied to the live one (flush rules in grid rounds of the device: nothing is a chip constant)
+void sched_apply_settings()
+{
+    if (!g_scheduler) return;
+    for (int d = 0; d < g_scheduler->gpu_num(); d++) {
+        sched::DeviceSched& ds = g_scheduler->dev(d);
+        ds.set_round_gates(ds.backend()->round_gates());
+        if (g_sched_level_gates > 0) ds.set_level_flush_gates((size_t)g_sched_level_gates);
+        ds.total_flush_gates = (size_t)g_sched_total_gates;
+        ds.rename_outputs = g_sched_rename != 0;
+        ds.copy_op = CUFHE_AMD_COPY;
+    }
+}
+
 sched::Scheduler* scheduler()
 {
     if (!g_scheduler) {
@@ -295,13 +317,7 @@ sched::Scheduler* scheduler()
             g_sched_backends.push_back(b);
             return b;
         });
-        for (int d = 0; d < g_gpu_num; d++) {
-            g_scheduler->dev(d).level_flush_gates = (size_t)g_sched_level_gates;
-            g_scheduler->dev(d).idle_flush_gates = (size_t)std::min(g_sched_level_gates, 2048L);
-            g_scheduler->dev(d).total_flush_gates = (size_t)g_sched_total_gates;
-            g_scheduler->dev(d).rename_outputs = g_sched_rename != 0;
-            g_scheduler->dev(d).copy_op = CUFHE_AMD_COPY;
-        }
+        sched_apply_settings();
     }
     return g_scheduler;
 }

@@ -61,6 +61,11 @@ int cufhe_amd_device_count(void);                       /* physical GPUs visible
  * (cudaSetDevice(i), include/cufhe_gpu.cuh:68-74); bench.py uses this to prove that N ranks / N logical devices
  * are N distinct GPUs (test/test_gate_gpu_multi.cc:36-93 assumes it). */
 int cufhe_amd_device_identity(int device, char* buf, size_t len);
+/* Compute units of logical device `device` -- the unit of every launch-shape and flush rule of this library (one grid round of the
+ * blind rotation = a workgroup of 8 rotations per CU); "cus_override" (cufhe_amd_set_option) replaces it. */
+int cufhe_amd_device_cus(int device);
+/* hipMemGetInfo of the device: what Initialize leaves free (every key is replicated per GPU, src/bootstrap_gpu.cu:115-137) */
+int cufhe_amd_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int cufhe_amd_initialize_ntt(void);                     /* Initialize()          :40 */
 /* Initialize(const EvalKey&) :42-47 = InitializeNTThandlers + BootstrappingKeyToNTT
  * (src/bootstrap_gpu.cu:111-138) + KeySwitchingKeyToDevice (src/keyswitch_gpu.cu:6-16).
@@ -126,7 +131,7 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);   /* constan
  * :160-167, device buffers only).  The gate is RECORDED with its data dependences; the recorded
  * program of a device is launched level by level (all gates whose operands are ready: one
  * blind-rotate + one key-switch launch per level) at Synchronize / StreamQuery / cufhe_amd_flush,
- * or as soon as a level holds 4096 gates (2048 when the device is idle).  Stream order, output aliasing, shared inputs and
+ * or as soon as a level holds two grid rounds of gates (one when the device is idle; a round = 8 gates per compute unit).  Stream order, output aliasing, shared inputs and
  * completion semantics are those of the reference (see cufhe_amd/csrc/sched_core.h).
  * cufhe_amd_ctxt_destroy never waits: buffers are recycled when the last recorded gate naming
  * them has retired. */
@@ -281,8 +286,13 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * value still in a renamed buffer when the caller asks for completion (Synchronize, StreamQuery of the stream that wrote
  * it) is copied home by one Copy gate in the flush that request triggers, so the published pointer holds the value
  * whenever the host may look -- results, tlwehost, tlwedevices and every API call behave as with 0 (never rename).
- * "sched_level_gates" (default 4096 while the device has work -- 32 768 gates through the per-gate API 96.1 k -> 99.4 k gates/s --, 2048 when it is idle) / "sched_total_gates" (default 32768): a dependence level this
+ * "sched_level_gates" (default -1 = two grid rounds of the device, 16 gates per CU, while it has work -- on MI355X 4096: 32 768 gates through
+ * the per-gate API 96.1 k -> 99.4 k gates/s --, one round when it is idle) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program.
+ * "test_fail_alloc" n (default -1 = off): the (n+1)-th device allocation of an Initialize entry point fails like an exhausted device,
+ * once -- a test hook for the error paths (the keys that were loaded stay loaded and usable, nothing leaks).
+ * "cus_override" (default 0 = the device's own count): every launch-shape rule above and the scheduler's flush rules behave as on a
+ * device with that many compute units (a partitioned device, another chip); results do not depend on it.
  * "sched_zero_copy" (default 1): the batched ciphertext traffic of a flush is read and written by the scatter / gather kernels
  * directly in pinned host memory, the inputs of a flush's first level chunk by chunk while the rest is still being gathered
  * from the tlwehosts; 0 = one H2D / D2H copy per flush through device staging buffers (the round-3 path).

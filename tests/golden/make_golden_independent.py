@@ -461,8 +461,57 @@ def main_smallmod():
     print("wrote", dst, out["seconds"], "s")
 
 
+def cmux_trgsws(R, seed):
+    """the two TRGSWs of the CMUXNTT cases, [(k+1) l][k+1][N] torus words flattened: uniform words, and extreme words with a first row
+    of 0x80000000 (every word -2^31 in a signed reading)"""
+    rng = np.random.default_rng(seed)
+    K1, rows = R.k + 1, (R.k + 1) * R.l
+    uniform = random_words(rng, rows * K1 * R.N)
+    ext = np.array(EXTREME_WORDS, np.uint32)
+    extreme = ext[rng.integers(0, ext.size, rows * K1 * R.N)]
+    extreme[: K1 * R.N] = 0x80000000
+    return uniform, extreme
+
+
+def main_cmux_sets():
+    """tests/golden/golden_independent_cmux_sets_v1.json (round 6): CMUXNTT on the OTHER compiled parameter sets -- in the reference the
+    set TFHEpp selects at build time serves CMUXNTT / TRGSW2NTT too (src/bootstrap_gpu.cu:75-94,197-285 are templates over lvl1param) --
+    as exact schoolbook sums: `k2n512` (three polynomials of 512, nine TRGSW rows) and `cggi16` (l = 2, Bg = 2^10: the set whose key the
+    library takes in two 16-bit limbs; here there are no limbs, only the integer sum), each on a TRGSW of uniform words, on one of extreme
+    words, and in place (res = c0 is the reference's usual call, test/test_cmux.cc).  A fixture of its own: the cases of v5 keep their
+    file and their words."""
+    out = {"format": 6, "generator": "tests/golden/make_golden_independent.py cmux_sets (schoolbook, no code shared with oracle/)", "cases": []}
+    t0 = time.time()
+    irng = np.random.default_rng(779)
+    out["inputs"] = {}
+    for name, R in (("k2n512", K2N512), ("cggi16", CGGI16)):
+        K1, rows = R.k + 1, (R.k + 1) * R.l
+        trl = [random_words(irng, K1 * R.N) for _ in range(2)]
+        trgsw, trgsw_x = cmux_trgsws(R, 20261010 + R.N + R.l)
+        trl[0][:8] = trl[1][:8]                               # difference 0 -> the digits of the bare offset
+        out["inputs"]["trlwe_" + name] = [x.tolist() for x in trl]
+        # like the keys: regenerated from the seed by the test (cmux_trgsws below), pinned by a hash
+        out["inputs"]["trgsw_" + name] = {"seed": 20261010 + R.N + R.l, "sha256": [hashlib.sha256(t.tobytes()).hexdigest() for t in (trgsw, trgsw_x)]}
+        as_trlwe = lambda x, R=R, K1=K1: [[int(v) for v in x[j * R.N:(j + 1) * R.N]] for j in range(K1)]
+        flat = lambda t: [int(v) for comp in t for v in comp]
+        for which, tg in (("uniform", trgsw), ("extreme", trgsw_x)):
+            print("CMUXNTT", name, which, flush=True)
+            out["cases"].append({"set": name, "level": 2, "op": "CMUXNTT", "trgsw": ["uniform", "extreme"].index(which), "inputs": "trlwe_" + name,
+                                 "operands": [0, 1], "expected": flat(cmux(tg.reshape(rows, K1, R.N), as_trlwe(trl[0]), as_trlwe(trl[1]), R))})
+        # chained: the second CMUX takes the first one's result as c0 and the operands swapped
+        first = cmux(trgsw.reshape(rows, K1, R.N), as_trlwe(trl[0]), as_trlwe(trl[1]), R)
+        out["cases"].append({"set": name, "level": 2, "op": "CMUXNTT_CHAINED", "trgsw": 1, "inputs": "trlwe_" + name, "operands": [1, 0],
+                             "expected": flat(cmux(trgsw_x.reshape(rows, K1, R.N), as_trlwe(trl[1]), first, R))})
+    out["seconds"] = round(time.time() - t0, 1)
+    dst = os.path.join(HERE, "golden_independent_cmux_sets_v1.json")
+    json.dump(out, open(dst, "w"))
+    print("wrote", dst, out["seconds"], "s")
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["smallmod"]:
+    if sys.argv[1:] == ["cmux_sets"]:
+        main_cmux_sets()
+    elif sys.argv[1:] == ["smallmod"]:
         main_smallmod()
     else:
         main()

@@ -379,7 +379,8 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
     std::mt19937_64 prng(seed);
     Test t(gpus, threaded, seed, 1 + (int)(prng() % 4));
     for (int d = 0; d < gpus; d++) {
-        t.S->dev(d).level_flush_gates = 4 + prng() % 40;     // exercise partial flushes
+        t.S->dev(d).set_round_gates(8 + prng() % 32);        // (the idle rule: one round)
+        t.S->dev(d).set_level_flush_gates(4 + prng() % 40);  // exercise partial flushes
         t.S->dev(d).total_flush_gates = 30 + prng() % 200;
     }
     const int kStreams = 6;

@@ -61,6 +61,7 @@ def _bind_gate_path(L):
     L.orc_keyswitch.argtypes = [ctypes.c_void_p, _u32, _u32]
     L.orc_gate_batch.argtypes = [ctypes.c_void_p, _i32, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                  _u32, _u32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.orc_cmux.argtypes = [_u32, _u32, _u32, _u32]
     L.orc_truth.argtypes = [ctypes.c_int] * 4
     return L
 

@@ -23,6 +23,8 @@ import oracle_lib as ol
 
 FIXTURE = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_v5.json")
 FIXTURE_SMALLMOD = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_smallmod_v1.json")
+# round 6 (the same script, argument `cmux_sets`): CMUXNTT on the other compiled sets -- uniform and extreme TRGSW words, chained in place
+FIXTURE_CMUX_SETS = os.path.join(ol.ROOT, "tests", "golden", "golden_independent_cmux_sets_v1.json")
 OPS = {n: i for i, n in enumerate(ol.OPS)}
 
 
@@ -73,6 +75,43 @@ def cases():
         for c in fx["cases"]:
             ins = [np.array(fx["inputs"][c["inputs"]][i], np.uint32) for i in c["operands"]]
             yield c, ins, np.array(c["expected"], np.uint32)
+
+
+def cmux_set_cases():
+    """(case, trgsw torus words, c1, c0, expected) of the CMUXNTT fixture on the other parameter sets; the TRGSWs are regenerated from
+    the fixture's seed (the generator's cmux_trgsws()) and checked against its hashes"""
+    fx = json.load(open(FIXTURE_CMUX_SETS))
+    ext = np.array((0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001), np.uint32)
+    for c in fx["cases"]:
+        n, N, k, l, bits, t = SETS[c["set"]]
+        meta = fx["inputs"]["trgsw_" + c["set"]]
+        rng = np.random.default_rng(meta["seed"])
+        size = (k + 1) * l * (k + 1) * N
+        uniform = words(size, rng)
+        extreme = ext[rng.integers(0, ext.size, size)]
+        extreme[: (k + 1) * N] = 0x80000000
+        tg = (uniform, extreme)[c["trgsw"]]
+        assert hashlib.sha256(tg.tobytes()).hexdigest() == meta["sha256"][c["trgsw"]], "numpy generated other TRGSW words than the fixture was made with"
+        trl = [np.array(x, np.uint32) for x in fx["inputs"][c["inputs"]]]
+        yield c, (uniform, extreme), [trl[i] for i in c["operands"]], np.array(c["expected"], np.uint32)
+
+
+def test_oracle_cmux_on_the_other_sets_matches_independent_generator():
+    """orc_cmux of the per-set oracle builds (what the GPU's CMUXNTT on a set is compared with everywhere else) == the schoolbook sums."""
+    seen = []
+    for c, (uniform, extreme), (c1, c0), want in cmux_set_cases():
+        L = ol.load_set(c["set"])
+        got = np.zeros(want.size, np.uint32)
+        if c["op"] == "CMUXNTT_CHAINED":      # first = cmux(uniform, c0, c1); then cmux(extreme, c1 = operand 0, c0 = first), in place on `first`
+            first = np.zeros(want.size, np.uint32)
+            L.orc_cmux(first, uniform, c0, c1)
+            L.orc_cmux(first, extreme, c1, first.copy())
+            got = first
+        else:
+            L.orc_cmux(got, (uniform, extreme)[c["trgsw"]], c1, c0)
+        assert np.array_equal(got, want), f"oracle CMUXNTT differs from the independent generator: {c['set']} {c['op']} trgsw {c['trgsw']}"
+        seen.append((c["set"], c["op"], c["trgsw"]))
+    assert seen == [(s, op, tg) for s in ("k2n512", "cggi16") for op, tg in (("CMUXNTT", 0), ("CMUXNTT", 1), ("CMUXNTT_CHAINED", 1))]
 
 
 def test_fixture_is_what_the_generator_describes():
@@ -196,6 +235,25 @@ for case, ins, want in tg.cases():
     eng.Synchronize()
     assert np.array_equal(out.download(), want), \
         f"HIP words differ from the independent generator: {name} level {case['level']} {case['op']}"
+# CMUXNTT / TRGSW2NTT on the other compiled sets (needs Initialize() only): the second fixture, incl. the chained in-place case
+eng.Initialize()
+for c, (uniform, extreme), (c1, c0), want in tg.cmux_set_cases():
+    idx = ps_index[c["set"]]
+    ntt_words = []
+    for tgw in (uniform, extreme):
+        dtg = api.DeviceBuffer(tgw.size).upload(tgw)
+        dntt = api.DeviceBuffer(2 * tgw.size * api.ps_params(idx).key_limbs)     # doubles, once per key limb
+        api.ps_trgsw_to_ntt_batch(idx, dtg, dntt, 1)
+        ntt_words.append(dntt)
+    d1, d0 = api.DeviceBuffer(c1.size).upload(c1), api.DeviceBuffer(c0.size).upload(c0)
+    out = api.DeviceBuffer(want.size)
+    if c["op"] == "CMUXNTT_CHAINED":
+        api.ps_cmux_batch(idx, ntt_words[0], d0, d1, out, 1)        # first = cmux(uniform, operands swapped back)
+        api.ps_cmux_batch(idx, ntt_words[1], d1, out, out, 1)       # in place: res = c0
+    else:
+        api.ps_cmux_batch(idx, ntt_words[c["trgsw"]], d1, d0, out, 1)
+    eng.Synchronize()
+    assert np.array_equal(out.download(), want), f"HIP CMUXNTT differs from the independent generator: {c['set']} {c['op']} trgsw {c['trgsw']}"
 eng.CleanUp()
 print("child ok")
 '''

@@ -224,3 +224,45 @@ def test_blind_rotate_with_extreme_key_words(engine2, keys2, oracle):
     finally:
         oracle.orc2_evalkey_destroy(ek)
         engine2.lvl2_initialize(keys2.bk, keys2.ksk)
+
+
+def test_half_wave_layout_is_built_on_first_use(engine2, keys2, keys):
+    """The key in the half-transform kernel's layout (495 MB per device) is built when a launch first takes that kernel -- launches of at
+    most one rotation per CU, or "lvl2_kernel" 0 -- not by cufhe_amd_lvl2_initialize: a process that only runs batches keeps the half
+    gigabyte.  A failing allocation on the way (the "test_fail_alloc" hook) leaves the loaded key usable and leaks nothing."""
+    api = engine2.api
+    api.Synchronize()
+    engine2.lvl2_initialize(keys2.bk, keys2.ksk)             # a fresh load: drops a half layout built by earlier tests
+    free_loaded, _ = api.device_mem_info()
+    count = 6
+    bits = np.array([[0, 1, 0, 1, 1, 0], [0, 0, 1, 1, 0, 1]], np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=2600 + i) for i in range(2)]
+    d0, d1 = _upload(engine2, ins[0]), _upload(engine2, ins[1])
+    dout = api.DeviceBuffer(count * (ol.n + 1))
+    want = np.asarray(keys2.gate_batch(0, ins[0], ins[1])).reshape(count, -1)
+    half_bytes = ol.n * 8 * 2 * ol.N2 * 3 * 8                # n steps x 8 rows x 2 polynomials x N x three limbs, doubles
+    api.set_option("lvl2_kernel", 1)
+    try:
+        api.lvl2_gate_batch(0, dout, d0, d1, count=count)
+        api.Synchronize()
+        assert np.array_equal(dout.download().reshape(count, -1), want)
+        free_q, _ = api.device_mem_info()
+        assert free_loaded - free_q < half_bytes // 4, "the quarter-wave kernel must not need the second layout"
+        api.set_option("lvl2_kernel", 0)
+        api.set_option("test_fail_alloc", 0)                  # the layout's own allocation fails
+        with pytest.raises(Exception):
+            api.lvl2_gate_batch(0, dout, d0, d1, count=count)
+        api.set_option("test_fail_alloc", 1)                  # ... and the staging copy behind it
+        with pytest.raises(Exception):
+            api.lvl2_gate_batch(0, dout, d0, d1, count=count)
+        api.Synchronize()
+        free_failed, _ = api.device_mem_info()
+        assert abs(free_failed - free_q) < (64 << 20), "a failed build of the half layout leaked device memory"
+        api.lvl2_gate_batch(0, dout, d0, d1, count=count)     # builds it now
+        api.Synchronize()
+        assert np.array_equal(dout.download().reshape(count, -1), want)
+        free_h, _ = api.device_mem_info()
+        assert free_q - free_h > half_bytes * 9 // 10, "the half-wave kernel's layout was expected to be allocated now"
+    finally:
+        api.set_option("test_fail_alloc", -1)
+        api.set_option("lvl2_kernel", -1)

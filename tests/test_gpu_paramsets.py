@@ -189,7 +189,64 @@ def test_trlwe_level_operations_over_a_parameter_set(engine, pset):
     assert np.array_equal(d_r.download().reshape(count, -1), np.stack([x.trlwehost for x in r]))
     assert np.array_equal(d_o.download().reshape(count, -1), np.stack([x.tlwehost for x in outs]))
     with pytest.raises(Exception):
-        api.ps_trlwe_op_batch(idx, 103, d_r, d_t, 1)          # CMUXNTT: BASELINE set only
+        api.ps_trlwe_op_batch(idx, 103, d_r, d_t, 1)          # CMUXNTT takes four operands: cufhe_amd_ps_cmux_batch
+
+
+def test_cmux_and_trgsw2ntt_over_a_parameter_set(engine, pset):
+    """TRGSW2NTT + CMUXNTT (src/bootstrap_gpu.cu:75-94,197-285: templates over the lvl1param the build selected) on every compiled set but
+    the small-modulus one (whose build in the reference has none, src/cufhe_gates_gpu.cu:68-86): res = c0 + trgsw [x] (c1 - c0) word for
+    word against the set's oracle -- uniform operands, a TRGSW of extreme words (cggi16: the sums that need both key limbs), a row of the
+    bootstrapping key (a real TRGSW encryption of a key bit), and in place on c0 and on c1."""
+    name, idx, L, K = pset
+    api = engine.api
+    l = ol.set_params(L)[1]["l"]
+    trlwe_words, trgsw_words = (K.k + 1) * K.N, (K.k + 1) * l * (K.k + 1) * K.N
+    count = 7
+    rng = np.random.default_rng(77)
+    tg = rng.integers(0, 2**32, size=(count, trgsw_words), dtype=np.uint64).astype(np.uint32)
+    ext = np.array((0x80000000, 0x7FFFFFFF, 0, 0xFFFFFFFF, 0x80000001), np.uint32)
+    tg[1] = ext[rng.integers(0, ext.size, trgsw_words)]
+    tg[2] = 0x80000000
+    tg[3] = np.asarray(K.bk, np.uint32).reshape(K.n, trgsw_words)[5]
+    c1 = rng.integers(0, 2**32, size=(count, trlwe_words), dtype=np.uint64).astype(np.uint32)
+    c0 = rng.integers(0, 2**32, size=(count, trlwe_words), dtype=np.uint64).astype(np.uint32)
+    c1[4, :64] = c0[4, :64]                      # difference 0: the digits of the bare offset
+    c1[5] = c0[5] + np.uint32(0x7FFFFFFF)
+    d_tg = _up(engine, tg)
+    limbs = api.ps_params(idx).key_limbs
+    d_ntt = api.DeviceBuffer(count * 2 * trgsw_words * limbs)
+    if name == "smallmod":
+        with pytest.raises(Exception, match="small-modulus"):
+            api.ps_trgsw_to_ntt_batch(idx, d_tg, d_ntt, count)
+        with pytest.raises(Exception, match="small-modulus"):
+            api.ps_cmux_batch(idx, d_ntt, _up(engine, c1), _up(engine, c0), api.DeviceBuffer(count * trlwe_words), count)
+        return
+    api.ps_trgsw_to_ntt_batch(idx, d_tg, d_ntt, count)
+    d1, d0, dres = _up(engine, c1), _up(engine, c0), api.DeviceBuffer(count * trlwe_words)
+    api.ps_cmux_batch(idx, d_ntt, d1, d0, dres, count)
+    got = dres.download().reshape(count, -1)
+    want = np.zeros_like(got)
+    for g in range(count):
+        L.orc_cmux(want[g], np.ascontiguousarray(tg[g]), np.ascontiguousarray(c1[g]), np.ascontiguousarray(c0[g]))
+        assert np.array_equal(got[g], want[g]), f"{name}: CMUXNTT {g}"
+    api.ps_cmux_batch(idx, d_ntt, d1, d0, d0, count)       # in place on c0 (the reference's usual call, test/test_cmux.cc)
+    assert np.array_equal(d0.download().reshape(count, -1), want), f"{name}: CMUXNTT in place on c0"
+    d0 = _up(engine, c0)
+    api.ps_cmux_batch(idx, d_ntt, d1, d0, d1, count)       # ... and on c1
+    assert np.array_equal(d1.download().reshape(count, -1), want), f"{name}: CMUXNTT in place on c1"
+    # the selector works: with TRGSW(s) of a key bit s the result decrypts to c1's message if s else c0's
+    bits = np.array([1, 0], np.uint8)
+    s0 = np.asarray(K.s0)
+    for i in (int(np.argmax(s0 == 1)), int(np.argmax(s0 == 0))):
+        row = np.ascontiguousarray(np.asarray(K.bk, np.uint32).reshape(K.n, trgsw_words)[i])
+        t = [K.blind_rotate(K.encrypt(bits[j:j + 1], 0, seed=900 + j)[0]) for j in range(2)]      # TRLWEs of mu * (+-1) at coefficient 0
+        d_row, d_rn = _up(engine, row), api.DeviceBuffer(2 * trgsw_words * limbs)
+        api.ps_trgsw_to_ntt_batch(idx, d_row, d_rn, 1)
+        dr = api.DeviceBuffer(trlwe_words)
+        api.ps_cmux_batch(idx, d_rn, _up(engine, t[0]), _up(engine, t[1]), dr, 1)
+        tl = np.zeros(K.words[1], np.uint32)
+        L.orc_sample_extract0(tl, dr.download())
+        assert K.decrypt(tl[None, :], 1)[0] == (bits[0] if s0[i] else bits[1]), f"{name}: CMUXNTT selects the wrong operand for key bit {int(s0[i])}"
 
 
 def test_mixed_batch(engine, pset):

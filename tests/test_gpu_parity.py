@@ -576,11 +576,108 @@ def test_launch_shapes_with_tails(engine, keys, count, opts):
         engine.api.set_option("ll_threshold", -1)
         engine.api.set_option("ll2_threshold", -1)
     assert np.array_equal(keys.decrypt(got, 0), 1 - bits[0] * bits[1])
-    cut = count - count % 2048
-    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, cut + 511, cut + 512, cut + 513, cut + 1023, cut + 1024,
-                                      cut + 1027, count - 5, count - 2, count - 1]), 0, count - 1))
+    # the cuts are in units of the device's CU count (capi.hip: launch_blind_rotate): a grid round is 8 rotations per CU
+    cus = engine.api.device_cus()
+    cut = count - count % (8 * cus)
+    idx = np.unique(np.clip(np.array([0, 3, 4, 7, cut - 1, cut, cut + 3, cut + 4, cut + 2 * cus - 1, cut + 2 * cus, cut + 2 * cus + 1, cut + 4 * cus - 1,
+                                      cut + 4 * cus, cut + 4 * cus + 3, count - 5, count - 2, count - 1]), 0, count - 1))
     want = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0][idx], ins[1][idx])
     assert np.array_equal(got[idx], want)
+
+
+@pytest.mark.parametrize("cus", [40, 104])
+def test_launch_and_flush_rules_follow_the_cu_count(engine, keys, cus):
+    """No rule is tied to MI355X's 256 CUs: with "cus_override" (a partitioned device, another chip) the blind rotation is cut at
+    multiples of 8 x cus -- visible in the number of launches -- and the per-gate API flushes a full level at two such rounds; the
+    words do not change."""
+    api = engine.api
+    api.set_option("cus_override", cus)
+    try:
+        assert api.device_cus() == cus
+        count = 8 * cus + cus + 3                 # one full round + a tail of a little more than one rotation per CU
+        rng = np.random.default_rng(cus)
+        bits = rng.integers(0, 2, size=(2, count)).astype(np.uint8)
+        ins = [keys.encrypt(bits[i], 0, seed=8800 + cus + i) for i in range(2)]
+        dins = [_upload(engine, x) for x in ins]
+        dout = api.DeviceBuffer(count * (ol.n + 1))
+        api.profile_enable(True)
+        api.profile_get(reset=True)
+        engine.gate_batch(ol.OPS.index("XOR"), 0, dout, dins[0], dins[1], count=count)
+        got = dout.download().reshape(count, -1)
+        prof = api.profile_get(reset=True)
+        api.profile_enable(False)
+        assert prof.blind_rotations == count and prof.blind_rotate_launches == 1      # one launch SEQUENCE (rounds + tail inside it)
+        assert np.array_equal(keys.decrypt(got, 0), bits[0] ^ bits[1])
+        cut = 8 * cus
+        idx = np.unique(np.clip(np.array([0, cut - 1, cut, cut + cus - 1, cut + cus, cut + 2 * cus - 1, cut + 2 * cus, count - 1]), 0, count - 1))
+        assert np.array_equal(got[idx], keys.gate_batch(ol.OPS.index("XOR"), 0, ins[0][idx], ins[1][idx]))
+        # the scheduler: on the idle device a level is launched at ONE grid round of this CU count, behind it at TWO
+        rnd = 8 * cus
+        n = 3 * rnd
+        cts = [api.Ctxt(0) for _ in range(3 * n)]
+        enc = keys.encrypt(rng.integers(0, 2, size=2 * n).astype(np.uint8), 0, seed=8900 + cus)
+        for i in range(2 * n):
+            cts[n + i].tlwehost[:] = enc[i]
+        st = api.Stream()
+        st.Create()
+        api.Synchronize()
+        api.sched_stats(reset=True)
+        for i in range(rnd - 1):
+            api.Nand(cts[i], cts[n + i], cts[2 * n + i], st)
+        assert api.sched_stats().groups == 0
+        api.Nand(cts[rnd - 1], cts[n + rnd - 1], cts[2 * n + rnd - 1], st)
+        assert api.sched_stats().groups == 1, f"the idle device was not handed the first round of {rnd} gates"
+        for i in range(rnd, n - 1):
+            api.Nand(cts[i], cts[n + i], cts[2 * n + i], st)
+        assert api.sched_stats().groups == 1
+        api.Nand(cts[n - 1], cts[2 * n - 1], cts[3 * n - 1], st)
+        assert api.sched_stats().groups == 2, f"a level of two rounds ({2 * rnd} gates) was not launched behind the running one"
+        api.Synchronize()
+        assert api.sched_stats().max_level_gates == 2 * rnd
+        pick = np.array([0, rnd - 1, rnd, n - 1])
+        want = keys.gate_batch(ol.OPS.index("NAND"), 0, enc[pick], enc[n + pick])
+        assert np.array_equal(np.stack([cts[i].tlwehost for i in pick]), want)
+        st.Destroy()
+    finally:
+        api.profile_enable(False)
+        api.set_option("cus_override", 0)
+
+
+def test_failed_initialize_keeps_the_loaded_keys(engine, keys, oracle):
+    """Initialize(ek) builds the new keys beside the loaded ones and swaps at the end (capi.hip: cufhe_amd_initialize): when an
+    allocation fails on the way -- every one of the call's three, through the "test_fail_alloc" hook -- the call reports -2, the OLD
+    keys still produce their words, and no device memory is lost."""
+    api = engine.api
+    other = ol.Keys(oracle, seed=2)
+    count = 5
+    bits = np.array([[0, 1, 0, 1, 1], [0, 0, 1, 1, 0]], np.uint8)
+    ins = [keys.encrypt(bits[i], 0, seed=3300 + i) for i in range(2)]
+    d0, d1 = _upload(engine, ins[0]), _upload(engine, ins[1])
+    dout = api.DeviceBuffer(count * (ol.n + 1))
+    want_old = keys.gate_batch(ol.OPS.index("NAND"), 0, ins[0], ins[1]).reshape(count, -1)
+    api.Synchronize()
+    free0, _ = api.device_mem_info()
+    try:
+        for nth in range(3):
+            api.set_option("test_fail_alloc", nth)
+            with pytest.raises(engine.CufheAmdError):
+                engine.Initialize(other.bk, other.ksk)
+            engine.gate_batch(ol.OPS.index("NAND"), 0, dout, d0, d1, count=count)
+            assert np.array_equal(dout.download().reshape(count, -1), want_old), f"allocation {nth} failed and took the loaded keys with it"
+        api.Synchronize()
+        free1, _ = api.device_mem_info()
+        assert abs(free0 - free1) < (32 << 20), "failed Initialize calls leaked device memory"
+        engine.Initialize(other.bk, other.ksk)            # the hook has disarmed itself: this one succeeds and replaces the keys
+        engine.gate_batch(ol.OPS.index("NAND"), 0, dout, d0, d1, count=count)
+        got = dout.download().reshape(count, -1)
+        assert not np.array_equal(got, want_old)
+        assert np.array_equal(got, other.gate_batch(ol.OPS.index("NAND"), 0, ins[0], ins[1]).reshape(count, -1))
+    finally:
+        api.set_option("test_fail_alloc", -1)
+        engine.Initialize(keys.bk, keys.ksk)
+    api.Synchronize()
+    free2, _ = api.device_mem_info()
+    assert abs(free0 - free2) < (32 << 20), "replacing the keys twice changed the device memory in use"
 
 
 def test_empty_batch_and_errors(engine):
