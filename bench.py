@@ -12,8 +12,9 @@ BASELINE configs[2] instead: the 32 768 mixed gates of SURVEY.md 8(d) config 3 s
 contiguously over the ranks (strong scaling); a plain `--gpus N` run with N > 1 times that
 workload as well, in the same processes, after the NAND timing (extra_workloads.mixed_32768_strong).
 
-The line starts with the numbers (first 2 KB: value, value_pcie_inclusive, single-gate latency, the
-extra workloads' rates in `summary`, roofline, cpu_baseline); what the fields mean and how each is
+The line starts with the contract fields and ENDS with a compact `summary` (the driver's record keeps the
+tail of stdout): value, value_pcie_inclusive and their ratio, single-gate latency, one rate per extra
+workload, the dependent netlist, how the word checks went.  What the fields mean and how each is
 measured is prose that does not change from run to run: profiles/bench_line_notes.md.
 
 Prints ONE JSON line (rank 0):
@@ -314,47 +315,62 @@ def cpu_baseline(ol, L, bk, ksk, in0, in1, gpu_out, oracle_ek, target_seconds=15
 
 
 def ordered_line(res):
-    """The numbers first: the driver keeps the head of the line (stdout_tail), so everything a reader needs to judge the run sits in
-    the first 2 KB -- the contract fields, the PCIe-inclusive rate, the single-gate latency, one figure per extra workload
-    (`summary`), the roofline and cpu_baseline objects cut to their numbers -- and the detail blocks follow."""
+    """Key order of the one JSON line.  The contract fields come first, then the roofline and cpu_baseline objects cut to their numbers,
+    the detail blocks, and -- as the LAST key, because the driver's record keeps the TAIL of stdout -- a compact `summary`: the
+    PCIe-inclusive rate and its ratio to `value`, the single-gate latency, one figure per extra workload, the dependent netlist with
+    its launch-sequence count, and how the word checks went (run / failed / unchecked / workloads that raised)."""
     ex = res.get("extra_workloads") or {}
     api_blk = res.get("api_pcie_inclusive") or {}
 
     def val(d, k="value"):
         return d.get(k) if isinstance(d, dict) else None
+    netl = api_blk.get("depth_first_netlist") if isinstance(api_blk, dict) else None
     summary = {
+        "value": res.get("value"), "value_pcie_inclusive": res.get("value_pcie_inclusive"),
+        "pcie_inclusive_over_value": (res["value_pcie_inclusive"] / res["value"]) if res.get("value_pcie_inclusive") and res.get("value") else None,
+        "single_gate_ms": res.get("ms_per_gate_latency_single_gate"),
+        "roofline_frac": val(res.get("roofline"), "frac"),
         "mux_gates_per_s": val(ex.get("mux")), "mixed_gates_per_s": val(ex.get("mixed")),
         "nand_lvl2_per_s": val(ex.get("nand_lvl2")), "nand_level1_per_s": val(ex.get("nand_level1")),
         "nand_512_ms": val(ex.get("nand_512"), "ms_per_step"),
         "mixed_32768_strong_gates_per_s": val(ex.get("mixed_32768_strong")),
-        "adder_netlist_gates_per_s": val(api_blk.get("depth_first_netlist"), "gates_per_s"),
+        "adder_netlist_gates_per_s": val(netl, "gates_per_s"),
+        "adder_netlist_over_value": (netl["gates_per_s"] / res["value"]) if isinstance(netl, dict) and netl.get("gates_per_s") and res.get("value") else None,
+        "adder_netlist_launch_sequences": val(netl, "launch_sequences"),
         "adder_netlist_without_renaming_gates_per_s": val(api_blk.get("depth_first_netlist_without_renaming"), "gates_per_s"),
         "api_reference_style_latency_ms_per_gate": val(api_blk.get("reference_style"), "latency_ms_per_gate"),
         "api_single_nand_ms": val(api_blk, "single_nand_call_to_synchronize_ms"),
         "api_chain16_ms_per_gate": val(api_blk, "chain_of_16_dependent_nand_ms_per_gate"),
         "param_sets_per_s": {k: val(v) for k, v in (ex.get("param_sets") or {}).items()} or None,
-        "all_word_checks_pass": None,
     }
-    checks = []
+    # Word checks: every "*_match_oracle" / "*_match_cpu" field anywhere in the record.  True counts as passed; False as failed; None
+    # (the check could not be made, e.g. --no-cpu-baseline) as unchecked; a workload recorded as {"error": ..} as an error.  The flag
+    # is true only when something was checked and nothing failed, was left unchecked where a check was due, or raised.
+    counts = {"run": 0, "failed": 0, "unchecked": 0, "errors": 0}
 
     def walk(o):
         if isinstance(o, dict):
+            if "error" in o and isinstance(o["error"], str):
+                counts["errors"] += 1
             for k, v in o.items():
                 if k.endswith("_match_oracle") or k.endswith("_match_cpu"):
-                    if v is not None:
-                        checks.append(bool(v))
+                    if v is None:
+                        counts["unchecked"] += 1
+                    else:
+                        counts["run"] += 1
+                        counts["failed"] += 0 if v else 1
                 else:
                     walk(v)
         elif isinstance(o, list):
             for v in o:
                 walk(v)
     walk(res)
-    summary["all_word_checks_pass"] = all(checks) if checks else None
-    summary = {k: v for k, v in summary.items() if v is not None}
+    summary["word_checks"] = counts
+    summary["all_word_checks_pass"] = bool(counts["run"]) and not (counts["failed"] or counts["unchecked"] or counts["errors"])
+    summary = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in summary.items() if v is not None}
     head_keys = ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                  "dtype", "data", "value_pcie_inclusive", "ms_per_gate_latency_single_gate", "ms_per_gate_throughput")
     out = {k: res[k] for k in head_keys if k in res}
-    out["summary"] = summary
     rf = res.get("roofline")
     if rf:
         first = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "frac_valu_fp64", "launch_ms", "rotations_per_launch",
@@ -371,8 +387,9 @@ def ordered_line(res):
     if cb:
         out["cpu_baseline_detail"] = {k: v for k, v in cb.items() if k not in out["cpu_baseline"]}
     for k, v in res.items():
-        if k not in out:
+        if k not in out and k != "summary":
             out[k] = v
+    out["summary"] = summary          # last: what the tail of the line shows
     return out
 
 

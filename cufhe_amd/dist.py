@@ -153,24 +153,10 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
                 pass
             procs[r].wait()
 
-    try:
-        for r in range(world):
-            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-            procs.append(subprocess.Popen(list(child_cmd), env=e, stdin=subprocess.DEVNULL, start_new_session=True,
-                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    except OSError:
-        end_all(range(len(procs)))      # the ranks already started would wait in the barrier forever
-        raise
-    # rank 0's stdout is drained by a thread so that a long line can never block the child
-    import threading
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    t0 = time.monotonic()
-    rc = 0
-    pending = set(range(world))
     # The ranks lead their own sessions, so a Ctrl-C or a SIGTERM aimed at the launcher (a harness timeout) does not reach them by
-    # itself: SIGTERM is turned into an exception for the duration of the wait, and ANY exception ends the ranks before it goes on.
+    # itself: from BEFORE the first rank is started until the last one has been reaped SIGTERM is turned into an exception, and ANY
+    # exception ends the ranks that exist by then before it goes on.  While end_all runs SIGTERM is ignored: a second signal must
+    # not abort the clean-up halfway.
     import signal
 
     class _Terminated(BaseException):
@@ -183,7 +169,33 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
         old_term = signal.signal(signal.SIGTERM, _on_term)
     except ValueError:          # not the main thread: signals go to the main thread, nothing to install
         old_term = None
+
+    def end_all_quietly(which):
+        prev = None
+        try:
+            prev = signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        except ValueError:
+            prev = None
+        try:
+            end_all(which)
+        finally:
+            if prev is not None:
+                signal.signal(signal.SIGTERM, prev)
+
+    pending = set()
     try:
+        for r in range(world):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(list(child_cmd), env=e, stdin=subprocess.DEVNULL, start_new_session=True,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+            pending.add(r)
+        # rank 0's stdout is drained by a thread so that a long line can never block the child
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        t0 = time.monotonic()
+        rc = 0
         while pending:
             for r in list(pending):
                 code = procs[r].poll()
@@ -194,12 +206,12 @@ def spawn_ranks(child_cmd, world, env=None, timeout=None, poll=0.05):
             if rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout):
                 if rc == 0:
                     rc = 124
-                end_all(sorted(pending))        # kills each group BEFORE reaping its leader: the pgid cannot have been reused
+                end_all_quietly(sorted(pending))        # kills each group BEFORE reaping its leader: the pgid cannot have been reused
                 pending = set()
             if pending:
                 time.sleep(poll)
-    except BaseException:
-        end_all(sorted(pending))
+    except BaseException:       # incl. an OSError while starting a rank (ENOMEM, EAGAIN) and a signal during the spawn loop
+        end_all_quietly(sorted(pending))        # the ranks already started would wait in the barrier forever
         raise
     finally:
         if old_term is not None:
