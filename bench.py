@@ -337,6 +337,8 @@ def ordered_line(res):
         "adder_netlist_gates_per_s": val(netl, "gates_per_s"),
         "adder_netlist_over_value": (netl["gates_per_s"] / res["value"]) if isinstance(netl, dict) and netl.get("gates_per_s") and res.get("value") else None,
         "adder_netlist_launch_sequences": val(netl, "launch_sequences"),
+        "adder_netlist_two_lane_launches": val(netl, "two_lane_launches"),
+        "adder_netlist_level_by_level_gates_per_s": val(api_blk.get("depth_first_netlist_level_by_level"), "gates_per_s"),
         "adder_netlist_without_renaming_gates_per_s": val(api_blk.get("depth_first_netlist_without_renaming"), "gates_per_s"),
         "api_reference_style_latency_ms_per_gate": val(api_blk.get("reference_style"), "latency_ms_per_gate"),
         "api_single_nand_ms": val(api_blk, "single_nand_call_to_synchronize_ms"),
@@ -676,12 +678,15 @@ def main():
                 # enqueue -> Synchronize with H2D/D2H of the ciphertexts inside the timed region
                 # (the reference's own way of timing, test/test_util.h:29-72); `value` above is the inputs-resident rate
                 res["value_pcie_inclusive"] = lines[0].get("gates_per_s")
-                if len(lines) > 1:
-                    res["api_pcie_inclusive"]["depth_first_netlist"] = lines[1]
-                if len(lines) > 2:
-                    res["api_pcie_inclusive"]["depth_first_netlist_without_renaming"] = lines[2]
-                if len(lines) > 3:
-                    res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = lines[3]
+                for ln in lines[1:]:         # the netlist lines say what they are
+                    if "single-assignment" in ln.get("netlist", ""):
+                        res["api_pcie_inclusive"]["netlist_level_reassignment_bound"] = ln
+                    elif ln.get("sched_rename") == 0:
+                        res["api_pcie_inclusive"]["depth_first_netlist_without_renaming"] = ln
+                    elif ln.get("sched_two_lane") == 0:
+                        res["api_pcie_inclusive"]["depth_first_netlist_level_by_level"] = ln
+                    else:
+                        res["api_pcie_inclusive"]["depth_first_netlist"] = ln
                 # one cufhe::Nand on host ciphertexts, call -> Synchronize, and a chain of 16 dependent ones (tools/api_latency.cpp): the
                 # ms/gate a user of the reference's API sees (test/test_api_gpu.cu:140-159 is the chained pattern)
                 lat = subprocess.run([os.path.join(ROOT, "tools", "api_latency")], capture_output=True, text=True, timeout=120,

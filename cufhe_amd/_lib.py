@@ -56,7 +56,7 @@ class SchedStats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("gates", "groups", "levels", "launch_sequences", "uploads",
                                                "uploads_shared", "downloads", "forced_syncs", "max_level_gates",
                                                "cross_stream_waits", "record_ns", "retire_ns", "launch_ns", "renames",
-                                               "worker_cpus", "home_copies")]
+                                               "worker_cpus", "home_copies", "two_lane_groups", "two_lane_launches")]
 
 
 class GroupTrace(ctypes.Structure):

@@ -1469,6 +1469,13 @@ int cufhe_amd_set_option(const char* key, long value)
         sched_apply_settings();        // the scheduler's flush rules are in grid rounds of 8 rotations per CU
         return 0;
     }
+    if (!strcmp(key, "sched_two_lane")) {
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        if (int rc = sched_synchronize_all()) return rc;      // what is recorded was recorded under the old renaming policy
+        g_sched_two_lane = value != 0;
+        sched_apply_settings();
+        return 0;
+    }
     if (!strcmp(key, "sched_rename")) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
         g_sched_rename = value != 0;

@@ -36,8 +36,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -104,6 +107,17 @@ class Backend {
     // gate and whatever it put there before runs ahead of it; here gates run on internal streams, and these two calls restore that
     // order when the caller asks for the handle (DeviceSched::stream_fence): the caller's stream waits for one of our events /
     // internal stream `s` waits for everything the caller's stream holds now.
+    // Two lanes (DeviceSched::compile_two_lane).  A flush whose levels are narrow costs a launch sequence per level however few
+    // gates it holds; when the device can run a grid on half of its compute units beside another one, the gates of a flush can instead
+    // be scheduled one by one: the CHAIN lane runs steps of up to chain_gates gates on a low-latency shape, the BULK lane chunks of up
+    // to bulk_gates on the throughput shape, on two internal streams.  lane_model returns false when the backend cannot (the default).
+    // launch_ms(n): what one level of n gates costs the level-by-level order.  gate_weight(op): blind rotations of a gate (0: linear).
+    struct LaneModel { size_t chain_gates = 0, bulk_gates = 0; double chain_ms = 0, bulk_ms = 0; };
+    virtual bool lane_model(LaneModel* /*m*/) { return false; }
+    virtual double launch_ms(size_t /*n*/) { return 0.0; }
+    virtual int gate_weight(int /*op*/) { return 1; }
+    // the same as run_gates with the launch shape of a lane: 0 = chain, 1 = bulk (anything else: by the backend's own rules)
+    virtual int run_gates_lane(int s, int level, const GateRef* g, size_t n, int /*lane*/) { return run_gates(s, level, g, n); }
     virtual int caller_stream_wait(void* /*caller_stream*/, void* /*ev*/) { return 0; }
     virtual int wait_for_caller_stream(int /*s*/, void* /*caller_stream*/) { return 0; }
     virtual void* mark(int /*s*/) { return nullptr; }
@@ -152,6 +166,8 @@ struct cufhe_amd_ctxt {
         uint32_t ready = 0;         // depth from which a gate may read `dev` (0: resident since long)
         uint32_t wdepth = 0;        // depth of the newest recorded write of `dev` (0: none on record)
         bool w_upload = false;      // ... which was an upload (runs before the gates of its level)
+        uint32_t widx = 0;          // ... else the position of the writing gate in that level's gate list of kind wkind
+        uint8_t wkind = 0;
         uint64_t version = 0;       // bumps at every recorded write of `dev`
         uint32_t last_use = 0;      // newest level naming this buffer in any way (keeps a destroyed ciphertext alive)
         // levels that read `dev` since that write: a few inline, the rest (rare) in a vector
@@ -197,6 +213,7 @@ struct Stats {
     uint64_t cross_stream_waits = 0;
     uint64_t renames = 0;             // outputs that took a fresh device buffer instead of waiting for the old one's users
     uint64_t home_copies = 0;         // renamed values copied back to the ciphertext's own buffer before the host could look
+    std::atomic<uint64_t> two_lane_groups{0}, two_lane_launches{0};      // flushes scheduled gate by gate on two lanes, and their launches
     std::atomic<uint64_t> worker_cpus{0};   // CPUs the launch worker is pinned to
     // host time: on the issuing thread (recording, delivering results) and on the launch worker
     uint64_t record_ns = 0, retire_ns = 0;
@@ -211,6 +228,8 @@ struct Stats {
         record_ns = o.record_ns; retire_ns = o.retire_ns;
         launch_ns.store(o.launch_ns.load());
         worker_cpus.store(o.worker_cpus.load());
+        two_lane_groups.store(o.two_lane_groups.load());
+        two_lane_launches.store(o.two_lane_launches.load());
 
         return *this;
     }
@@ -224,9 +243,23 @@ struct ScopedNs {
 
 struct Delivery { cufhe_amd_ctxt* c; size_t slot; uint64_t token; };
 
+// The producers of a gate's operands inside the recorded program: (level, index in that level's gate list of the same kind), level 0 =
+// the operand is resident (an upload, or a value produced before the program on record).  What per-gate scheduling of a flush needs
+// (DeviceSched::compile_two_lane); the level-by-level launch order does not look at it.
+struct GateDep {
+    uint32_t depth[3] = {0, 0, 0};
+    uint32_t idx[3] = {0, 0, 0};
+    uint8_t kind[3] = {0, 0, 0};
+    // the scheduler's own copy of a renamed value back to its ciphertext's buffer (restore_homes): besides its operand it must follow
+    // every recorded reader of the value the home buffer held -- the level it was placed at does; a per-gate order runs it last
+    bool home_copy = false;
+};
+
 struct Plan {                         // one dependence level of the recorded program
     uint32_t depth = 0;
     std::vector<GateRef> gates[kKinds];
+    std::vector<GateDep> deps[kKinds];             // parallel to gates
+    bool level_ordered = false;                    // some gate of this level relies on level order for a buffer hazard (it could not be renamed)
     std::vector<CopyRec> uploads, downloads;
     std::vector<cufhe_amd_ctxt*> upload_ctxts;     // parallel to uploads
     std::vector<Delivery> deliveries;              // parallel to downloads
@@ -239,6 +272,8 @@ struct Plan {                         // one dependence level of the recorded pr
     void reset()
     {
         gates[0].clear(); gates[1].clear(); gates[2].clear(); uploads.clear(); downloads.clear(); upload_ctxts.clear(); deliveries.clear();
+        deps[0].clear(); deps[1].clear(); deps[2].clear();
+        level_ordered = false;
         dep_depths.clear(); streams.clear();
         in_words = out_words = in_base = out_base = 0;
     }
@@ -269,6 +304,7 @@ struct Group {                        // consecutive levels flushed together
     void* marks[4] = {nullptr, nullptr, nullptr, nullptr};
     bool zero_copy_in = false, zero_copy_out = false;     // dev_in / dev_out alias the pinned blocks: nothing to recycle
     std::vector<void*> ext_waits;     // caller streams whose own work (enqueued through the raw handle) this group must follow
+    std::vector<void*> lane_events;   // events between the two lanes of a per-gate scheduled flush (destroyed when the group retires)
 };
 
 class Scheduler;
@@ -412,6 +448,9 @@ class DeviceSched {
     // pointer holds the value whenever the host is entitled to look, exactly as without renaming.  TLWE ciphertexts only
     // (the copy back is an ordinary Copy gate of the ciphertext's level).
     bool rename_outputs = true;
+    // Per-gate scheduling of flushes with several dependence levels on two lanes (compile_two_lane below; "sched_two_lane").  Needs
+    // renaming (the recorded program must be single-assignment) and a backend with a lane model.
+    bool two_lane = true;
     int copy_op = 13;                  // the op code of Copy (CUFHE_AMD_COPY) in GateRef::op
     void forget_renamed(cufhe_amd_ctxt* c)        // the ciphertext goes away: nothing to copy home any more
     {
@@ -569,6 +608,12 @@ class DeviceSched {
     void record_upload(cufhe_amd_ctxt* c, void* stream);
     int after_record();
     int launch(Group* g);                       // worker (or inline): submit the group's work
+    // one launch of a per-gate scheduled flush: lane 0 = chain, 1 = bulk; wait_other = the newest launch of the OTHER lane that
+    // produces one of its operands (-1: none; launches of one lane run in order on one stream)
+    struct LaneLaunch { int lane = 0; int index = 0; int wait_other = -1; bool signal = false; std::vector<GateRef> gates; };
+    // tail: the independent remainder, one launch behind both lanes; post: the copies home, behind everything
+    struct TwoLanePlan { int kind = 0; std::vector<LaneLaunch> seq; std::vector<GateRef> tail, post; double est_ms = 0, level_ms = 0; };
+    bool compile_two_lane(Group* g, TwoLanePlan* out);
     int retire(Group* g);                       // issuing thread: deliver results, recycle
     void worker_loop();
     void wait_worker_idle()
@@ -923,18 +968,44 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     // operand buffers as of now: an in-place gate reads the buffer its output may be about to leave
     const uint32_t* const in_dev[3] = {ins[0]->d[device_].dev, ins[1] ? ins[1]->d[device_].dev : nullptr,
                                        ins[2] ? ins[2]->d[device_].dev : nullptr};
+    // Per-gate scheduling of a flush (two_lane) orders gates by their data dependences ONLY: every other use of the output buffer that is
+    // still on record -- a reader of the value it holds, a write this gate does not read, a result of that value still travelling to
+    // tlwehost which this gate does not supersede -- must then be taken out of the way by renaming, whether or not the level order
+    // would have kept them apart.
+    bool users = false;
+    if (two_lane && rename_outputs && out->level <= 1) {
+        bool is_input = false;
+        for (int i = 0; i < 3; i++) is_input = is_input || ins[i] == out;
+        for_readers(po, [&](uint32_t r) { users = users || r >= base_depth_; });
+        if (!is_input && po.wdepth >= base_depth_) users = true;
+        if (is_input && !copying && out->host_dev == device_ && out->host_version == po.version) users = true;
+    }
+    // the producers of the operands, as the buffers stand now (an in-place gate names the producer of the value it overwrites)
+    GateDep gd;
+    for (int i = 0; i < 3; i++) {
+        if (!ins[i]) continue;
+        const cufhe_amd_ctxt::PerDev& pd = ins[i]->d[device_];
+        if (pd.wdepth >= base_depth_ && !pd.w_upload) { gd.depth[i] = pd.wdepth; gd.idx[i] = pd.widx; gd.kind[i] = pd.wkind; }
+    }
     uint32_t* fresh = nullptr;
     bool back_home = false;
-    if (rename_outputs && D > Din && out->level <= 1) {
+    bool hazard_by_level = false;
+    if (rename_outputs && (D > Din || users) && out->level <= 1) {
         if (po.dev != po.home && all_done_through(max_depth_of(po.home_deps))) {
             fresh = po.home;                                          // nothing recorded names the home buffer any more
             back_home = true;
             D = Din;
         } else if (slot_alloc(out->level, &fresh) == 0) D = Din;
-        else fresh = nullptr;
+        else {
+            fresh = nullptr;
+            hazard_by_level = true;
+        }
+    } else if (D > Din || users) {
+        hazard_by_level = true;
     }
 
     Plan& p = plan_at(D);
+    if (hazard_by_level) p.level_ordered = true;
     for (int i = 0; i < 3; i++) {
         if (!ins[i]) continue;
         cufhe_amd_ctxt::PerDev& pd = ins[i]->d[device_];
@@ -982,7 +1053,10 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     po.ustream = nullptr;
     po.umany = false;
     use(po, D);
+    po.widx = (uint32_t)p.gates[kind].size();
+    po.wkind = (uint8_t)kind;
     p.gates[kind].push_back(GateRef{op, po.dev, in_dev[0], in_dev[1], in_dev[2]});
+    p.deps[kind].push_back(gd);
     if (copying) {
         const size_t slot = p.out_words;
         p.out_words += (size_t)be_->words(out->level);
@@ -1048,12 +1122,19 @@ inline int DeviceSched::restore_homes(void* only_stream)
         Plan& p = plan_at(D);
         add_dep(p, pd.wdepth);
         for (uint32_t dd : pd.home_deps) add_dep(p, dd);
+        GateDep gd;
+        gd.home_copy = true;
+        if (pd.wdepth >= base_depth_ && !pd.w_upload) { gd.depth[0] = pd.wdepth; gd.idx[0] = pd.widx; gd.kind[0] = pd.wkind; }
+        const uint32_t copy_idx = (uint32_t)p.gates[c->level].size();
         p.gates[c->level].push_back(GateRef{copy_op, pd.home, pd.dev, nullptr, nullptr});
+        p.deps[c->level].push_back(gd);
         retired_.push_back({pd.dev, c->level, std::max(pd.last_use, D)});
         pd.dev = pd.home;
         pd.home_deps.clear();
         pd.wdepth = D;                 // same value, same version: a result on its way to tlwehost still matches
         pd.w_upload = false;
+        pd.widx = copy_idx;
+        pd.wkind = (uint8_t)c->level;
         pd.ready = D + 1;
         clear_readers(pd);
         pd.last_use = D;
@@ -1189,6 +1270,210 @@ inline void DeviceSched::worker_loop()
     }
 }
 
+// Per-gate scheduling of one flush.  The recorded program of the group is a DAG of gates (GateDep) over single-assignment buffers
+// (record_gate renames every output whose buffer has other recorded users while two_lane is on), so any order that respects the data
+// dependences computes the in-order result.  The level-by-level order pays one launch sequence per level: a ripple-carry adder's 32
+// carry levels of a few hundred gates each run on the latency shapes with the rest of the chip waiting, after a first level of
+// thousands.  Here the gates are list-scheduled, longest remaining path first, onto two lanes that share the device
+// (Backend::LaneModel): steps of the low-latency shape on half of the compute units carry the chains while chunks of the throughput
+// shape on the other half carry whatever nothing waits for.  The plan is only used when the backend's own cost model says it beats the
+// level order by more than 5 %; everything it cannot express (several kinds of gates in the flush, uploads behind the first level,
+// a hazard that a level kept apart because it could not be renamed) leaves the flush to the level order.
+inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
+{
+    Backend::LaneModel m;
+    if (!two_lane || !rename_outputs || nstreams_ < 2 || g->plans.size() < 3 || !be_->lane_model(&m) || m.chain_gates == 0 || m.bulk_gates == 0) return false;
+    int kind = -1;
+    size_t N = 0;
+    std::vector<size_t> off(g->plans.size() + 1, 0);
+    for (size_t pi = 0; pi < g->plans.size(); pi++) {
+        const Plan* p = g->plans[pi];
+        if (p->level_ordered || !p->gates[2].empty() || (pi > 0 && !p->uploads.empty())) return false;
+        for (int l = 0; l < 2; l++)
+            if (!p->gates[l].empty()) {
+                if (kind >= 0 && kind != l) return false;
+                kind = l;
+            }
+        off[pi] = N;
+        N += kind >= 0 ? p->gates[kind].size() : 0;
+    }
+    off[g->plans.size()] = N;
+    if (kind < 0 || N < 4 * m.chain_gates) return false;
+    // producers (ids inside the group: a producer sits at a lower level, so at a lower id), consumers, weights, heights
+    std::vector<int32_t> prod(3 * N, -1);
+    std::vector<uint32_t> ncons(N, 0), indeg(N, 0), height(N, 0);
+    std::vector<uint8_t> weight(N, 1), is_post(N, 0);
+    double level_ms = 0;
+    for (size_t pi = 0; pi < g->plans.size(); pi++) {
+        const Plan* p = g->plans[pi];
+        const size_t n = p->gates[kind].size();
+        if (p->deps[kind].size() != n) return false;
+        size_t rotations = 0;
+        for (size_t gi = 0; gi < n; gi++) {
+            const size_t id = off[pi] + gi;
+            weight[id] = (uint8_t)std::max(0, std::min(255, be_->gate_weight(p->gates[kind][gi].op)));
+            rotations += weight[id];
+            const GateDep& d = p->deps[kind][gi];
+            if (d.home_copy) { is_post[id] = 1; continue; }                // runs behind everything (and must not be anybody's operand: below)
+            for (int i = 0; i < 3; i++) {
+                if (d.depth[i] < g->first_depth) continue;                 // resident, or produced by an earlier flush (the group's own dependences)
+                if (d.depth[i] >= p->depth || d.kind[i] != kind) return false;
+                const size_t pp = d.depth[i] - g->first_depth;
+                if (d.idx[i] >= g->plans[pp]->gates[kind].size() || is_post[off[pp] + d.idx[i]]) return false;
+                bool dup = false;
+                for (int j = 0; j < i; j++) dup = dup || prod[3 * id + j] == (int32_t)(off[pp] + d.idx[i]);
+                if (dup) continue;
+                prod[3 * id + i] = (int32_t)(off[pp] + d.idx[i]);
+                ncons[off[pp] + d.idx[i]]++;
+                indeg[id]++;
+            }
+        }
+        level_ms += be_->launch_ms(rotations);
+    }
+    std::vector<uint32_t> cstart(N + 1, 0);
+    for (size_t i = 0; i < N; i++) cstart[i + 1] = cstart[i] + ncons[i];
+    std::vector<uint32_t> cons(cstart[N]), cfill(cstart.begin(), cstart.end() - 1);
+    for (size_t id = 0; id < N; id++)
+        for (int i = 0; i < 3; i++)
+            if (prod[3 * id + i] >= 0) cons[cfill[(size_t)prod[3 * id + i]]++] = (uint32_t)id;
+    for (size_t id = N; id-- > 0;)
+        for (int i = 0; i < 3; i++)
+            if (prod[3 * id + i] >= 0) height[(size_t)prod[3 * id + i]] = std::max(height[(size_t)prod[3 * id + i]], height[id] + 1);
+    uint32_t hmax = 0;
+    for (size_t id = 0; id < N; id++) hmax = std::max(hmax, height[id]);
+    if (hmax < 4) return false;                                            // no chain worth a lane of its own
+    auto gate_of = [&](size_t id) -> const GateRef& {
+        const size_t pi = (size_t)(std::upper_bound(off.begin(), off.end(), id) - off.begin()) - 1;
+        return g->plans[pi]->gates[kind][id - off[pi]];
+    };
+    // list scheduling over the two lanes, simulated on the backend's cost model
+    struct Avail { double t; uint32_t id; bool operator<(const Avail& o) const { return t > o.t; } };                 // min-heap on time
+    struct Ready { uint32_t h, id; bool operator<(const Ready& o) const { return h != o.h ? h < o.h : id > o.id; } }; // max-heap on height, then issue order
+    std::vector<Avail> pending;
+    std::vector<Ready> ready;
+    std::vector<double> fin(N, -1.0);
+    std::vector<int32_t> lane_of(N, -1), launch_of(N, -1);
+    out->post.clear();
+    size_t scheduled = 0, unscheduled_with_consumers = 0;
+    for (size_t id = 0; id < N; id++) {
+        if (is_post[id]) {
+            // results are fetched before the copies home run: a fetch of the value a copy home DELIVERS (recorded behind it) does not fit
+            const size_t pi = (size_t)(std::upper_bound(off.begin(), off.end(), id) - off.begin()) - 1;
+            const uint32_t* home = gate_of(id).out;
+            for (size_t pj = pi; pj < g->plans.size(); pj++)
+                for (const CopyRec& r : g->plans[pj]->downloads)
+                    if (r.dev == home) return false;
+            out->post.push_back(gate_of(id)); lane_of[id] = 2; scheduled++; continue;
+        }
+        if (indeg[id] == 0) { ready.push_back({height[id], (uint32_t)id}); std::push_heap(ready.begin(), ready.end()); }
+    }
+    double tfree[2] = {0.0, 0.0};
+    int launches[2] = {0, 0};
+    std::vector<uint32_t> by_height(hmax + 1, 0);                          // unscheduled gates per height
+    for (size_t id = 0; id < N; id++)
+        if (!is_post[id]) by_height[height[id]]++;
+    uint32_t hrem = hmax;
+    const uint32_t margin = (uint32_t)std::max(1.0, std::ceil(m.bulk_ms / m.chain_ms));
+    for (size_t id = 0; id < N; id++) unscheduled_with_consumers += ncons[id] != 0;
+    const size_t cap[2] = {m.chain_gates, m.bulk_gates};
+    const double dur[2] = {m.chain_ms, m.bulk_ms};
+    out->seq.clear();
+    while (scheduled < N && unscheduled_with_consumers > 0) {
+        const int lane = tfree[0] <= tfree[1] ? 0 : 1;
+        const double t = tfree[lane];
+        while (!pending.empty() && pending.front().t <= t) {
+            std::pop_heap(pending.begin(), pending.end());
+            const uint32_t id = pending.back().id;
+            pending.pop_back();
+            ready.push_back({height[id], id});
+            std::push_heap(ready.begin(), ready.end());
+        }
+        const double next = pending.empty() ? -1.0 : pending.front().t;
+        if (ready.empty()) {
+            if (next < 0) return false;                                    // cannot happen in a DAG: leave the flush to the level order
+            tfree[lane] = std::max(next, t);
+            continue;
+        }
+        // The bulk lane keeps a gate for a whole chunk (about `margin` chain steps): it may only take gates that the longest remaining
+        // chain does not reach for that long -- those at least `margin` below the greatest height still unscheduled -- and among them
+        // the ones needed soonest.  The chain lane takes the most urgent gates first.
+        while (hrem > 0 && by_height[hrem] == 0) hrem--;
+        std::vector<Ready> too_urgent;
+        if (lane == 1) {
+            while (!ready.empty() && ready.front().h + margin > hrem) {
+                std::pop_heap(ready.begin(), ready.end());
+                too_urgent.push_back(ready.back());
+                ready.pop_back();
+            }
+            if (ready.size() < cap[1] / 2) {
+                // a chunk of the throughput shape costs its 19 ms whatever it carries: the bulk lane waits for a worthwhile load -- until
+                // more gates become available or the chain lane (busy beyond t, or it would have been chosen) has taken its pick
+                for (const Ready& r : too_urgent) { ready.push_back(r); std::push_heap(ready.begin(), ready.end()); }
+                tfree[1] = next >= 0 ? std::min(next, tfree[0]) : tfree[0];
+                continue;
+            }
+        }
+        LaneLaunch L;
+        L.lane = lane;
+        L.index = launches[lane]++;
+        size_t load = 0;
+        std::vector<uint32_t> placed;
+        while (!ready.empty()) {
+            const uint32_t id = ready.front().id;
+            if (load && load + weight[id] > cap[lane]) break;
+            std::pop_heap(ready.begin(), ready.end());
+            ready.pop_back();
+            by_height[height[id]]--;
+            load += weight[id];
+            L.gates.push_back(gate_of(id));
+            placed.push_back(id);
+            lane_of[id] = lane;
+            launch_of[id] = L.index;
+            for (int i = 0; i < 3; i++) {
+                const int32_t pr = prod[3 * id + i];
+                if (pr >= 0 && lane_of[(size_t)pr] == 1 - lane) L.wait_other = std::max(L.wait_other, launch_of[(size_t)pr]);
+            }
+            scheduled++;
+            if (ncons[id]) unscheduled_with_consumers--;
+        }
+        for (const Ready& r : too_urgent) { ready.push_back(r); std::push_heap(ready.begin(), ready.end()); }
+        const double finish = t + dur[lane] * (lane == 0 && 2 * load <= cap[0] ? 0.7 : 1.0);      // a half-empty chain step takes the single-rotation shape
+        tfree[lane] = finish;
+        out->seq.push_back(std::move(L));
+        // consumers whose producers are all scheduled now become available when the latest of them ends
+        for (uint32_t id : placed) fin[id] = finish;
+        for (uint32_t id : placed)
+            for (uint32_t ci = cstart[id]; ci < cstart[id + 1]; ci++) {
+                const uint32_t c = cons[ci];
+                if (--indeg[c] == 0) {
+                    double a = 0;
+                    for (int i = 0; i < 3; i++)
+                        if (prod[3 * c + i] >= 0) a = std::max(a, fin[(size_t)prod[3 * c + i]]);
+                    pending.push_back({a, c});
+                    std::push_heap(pending.begin(), pending.end());
+                }
+            }
+    }
+    // what is left has no consumers left to serve and every producer scheduled: one launch by the backend's own rules behind both lanes
+    out->tail.clear();
+    size_t tail_rot = 0;
+    for (size_t id = 0; id < N; id++)
+        if (lane_of[id] < 0) { out->tail.push_back(gate_of(id)); tail_rot += weight[id]; }
+    // which launches must signal the other lane
+    for (LaneLaunch& L : out->seq)
+        if (L.wait_other >= 0)
+            for (LaneLaunch& P : out->seq)
+                if (P.lane == 1 - L.lane && P.index == L.wait_other) P.signal = true;
+    out->kind = kind;
+    out->level_ms = level_ms;
+    out->est_ms = std::max(tfree[0], tfree[1]) + (tail_rot ? be_->launch_ms(tail_rot) : 0.0);
+    static const bool debug = getenv("CUFHE_AMD_SCHED_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[sched] flush of %zu gates in %zu levels: level by level %.1f ms, two lanes %.1f ms (%d chain steps to %.1f, %d bulk chunks to %.1f, remainder %zu, copies home %zu)\n",
+                N, g->plans.size(), level_ms, out->est_ms, launches[0], tfree[0], launches[1], tfree[1], tail_rot, out->post.size());
+    return out->est_ms < 0.95 * level_ms;
+}
+
 inline int DeviceSched::launch(Group* g)
 {
     uint64_t ns = 0;
@@ -1266,6 +1551,45 @@ inline int DeviceSched::launch(Group* g)
     }
     // the device-side spans of the trace (scatter | gates | gather) are marked for groups of one level; longer groups get one span
     const bool single = g->plans.size() == 1;
+    TwoLanePlan tl;
+    if (rc == 0 && compile_two_lane(g, &tl)) {
+        // Gate by gate on two lanes: the uploads (all in the first level), the launches in the order the plan generated them -- each on
+        // its lane's stream, behind the other lane's launch that produces its operands -- the independent remainder as one launch by the
+        // backend's own rules, then every result of the flush (the recorded program is single-assignment: nothing was overwritten).
+        const int sc = (s + 1) % nstreams_;                            // the chain lane's stream; the bulk lane keeps the group's
+        Plan* p0 = g->plans[0];
+        if (p0->uploads.size() > first_done)
+            step(be_->copy_ctxts(s, p0->uploads.data() + first_done, p0->uploads.size() - first_done, g->dev_in + p0->in_base, true));
+        auto new_event = [&](int stream) -> void* {
+            void* ev = nullptr;
+            if (!step(be_->event_create(&ev))) return nullptr;
+            g->lane_events.push_back(ev);
+            step(be_->event_record(stream, ev));
+            return ev;
+        };
+        if (void* start = new_event(s)) step(be_->stream_wait(sc, start));      // the chain lane starts behind the uploads and the group's dependences
+        std::vector<void*> done_ev[2];
+        for (const LaneLaunch& L : tl.seq) {
+            if (rc) break;
+            const int st = L.lane == 0 ? sc : s;
+            if (L.wait_other >= 0) {
+                void* ev = done_ev[1 - L.lane][(size_t)L.wait_other];
+                if (ev) step(be_->stream_wait(st, ev));
+            }
+            step(be_->run_gates_lane(st, tl.kind, L.gates.data(), L.gates.size(), L.lane));
+            done_ev[L.lane].push_back(L.signal && !rc ? new_event(st) : nullptr);
+            stats_.two_lane_launches++;
+        }
+        if (!rc)
+            if (void* joined = new_event(sc)) step(be_->stream_wait(s, joined));
+        if (!rc && !tl.tail.empty()) step(be_->run_gates(s, tl.kind, tl.tail.data(), tl.tail.size()));
+        // the results first: a copy home (post) rewrites a buffer whose earlier value an earlier level's result may still be waiting in
+        for (Plan* p : g->plans)
+            if (!rc && !p->downloads.empty())
+                step(be_->copy_ctxts(s, p->downloads.data(), p->downloads.size(), g->dev_out + p->out_base, false));
+        if (!rc && !tl.post.empty()) step(be_->run_gates(s, tl.kind, tl.post.data(), tl.post.size()));
+        stats_.two_lane_groups++;
+    } else
     for (size_t pi = 0; pi < g->plans.size(); pi++) {
         Plan* p = g->plans[pi];
         if (rc) break;
@@ -1348,6 +1672,8 @@ inline int DeviceSched::retire(Group* g)
     }
     for (void*& m : g->marks)
         if (m) { be_->event_destroy(m); m = nullptr; }
+    for (void* ev : g->lane_events) be_->event_destroy(ev);
+    g->lane_events.clear();
     g->trace.t_delivered = now_ns();
     trace_.push_back(g->trace);
     if (trace_.size() > 64) trace_.pop_front();
@@ -1390,9 +1716,9 @@ inline int DeviceSched::synchronize()
 
 inline int DeviceSched::stream_query(void* stream)
 {
+    restore_homes(stream);                        // (may be the first thing on record for this stream: a value it only re-uploaded)
     auto it = streams_.find(stream);
     if (it == streams_.end()) return 1;
-    restore_homes(stream);
     StreamState& ss = streams_[stream];           // references survive a rehash, iterators do not
     if (ss.max_depth >= base_depth_)
         if (int rc = flush()) return rc;          // it can only complete once it has been launched
@@ -1435,8 +1761,8 @@ inline int DeviceSched::stream_fence(void* stream)
 {
     ext_streams_.insert(stream);
     fence_epoch_[stream]++;
-    if (streams_.find(stream) == streams_.end()) return 0;      // nothing of this stream is recorded or in flight
     restore_homes(stream);
+    if (streams_.find(stream) == streams_.end()) return 0;      // nothing of this stream is recorded or in flight
     StreamState& ss = streams_[stream];
     if (ss.max_depth >= base_depth_)
         if (int rc = flush()) return rc;
@@ -1454,8 +1780,8 @@ inline int DeviceSched::stream_fence(void* stream)
 
 inline int DeviceSched::stream_synchronize(void* stream)
 {
-    if (streams_.find(stream) == streams_.end()) return 0;
     restore_homes(stream);
+    if (streams_.find(stream) == streams_.end()) return 0;
     {
         StreamState& ss = streams_[stream];
         if (ss.max_depth >= base_depth_)

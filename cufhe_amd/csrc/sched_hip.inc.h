@@ -14,6 +14,7 @@ long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
 long g_sched_level_gates = -1;   // a dependence level this full is launched at once: -1 = two rounds of the batch kernel's grid (8 rotations per CU each), one when the device is idle
 long g_sched_total_gates = 32768;
+long g_sched_two_lane = 1;        // flushes of several dependence levels are scheduled gate by gate on two lanes when the cost model says so (sched_core.h: compile_two_lane)
 long g_sched_rename = 1;          // outputs take fresh device buffers instead of waiting for the old one's users, values return to the ciphertext's own buffer before the host may look (sched_core.h); 0: never
 long g_sched_zero_copy = 1;       // 1: ciphertext staging is read / written by the scatter / gather kernels in pinned host memory (no copy-engine step)
 long g_sched_affinity = 1;        // 1: a device's launch worker runs on the CPUs local to that GPU (NUMA node of its PCI function)
@@ -130,6 +131,46 @@ class HipBackend : public sched::Backend {
         if (int rc = stream(s, &st)) return rc;
         if (level == 2) return keep(run_trlwe_ops(device_, (void*)st, g, n));
         return keep(::run_gates(device_, (void*)st, level, n, [&](size_t i) { return g[i]; }));
+    }
+    // Two lanes: measured on MI355X with both lanes running (tools/two_lane_probe.py, profiles/r06_two_lane_probe.txt) -- a step of the
+    // paired low-latency kernel on half of the CUs, key switch included, 5.15 ms beside the bulk lane (4.66 alone); a chunk of the batch
+    // kernel on the other half 19.9 ms (18.3 alone).  Half of the CUs each: an in-order stream then never has more workgroups in flight
+    // than the other lane leaves free, so neither lane ever queues behind the other (full-width chunks beside the chain: 132 ms
+    // against 79).  Only for the hand-scheduled BASELINE path: the parameter-set and N = 2048 paths pick their own shapes.
+    bool lane_model(LaneModel* m) override
+    {
+        if (!g_sched_two_lane || g_param_set >= 0 || g_lvl0_ring != 1024) return false;
+        const size_t cus = round_gates() / kBrWavesPerBlock;
+        if (cus < 16) return false;
+        m->chain_gates = 2 * (cus / 2);
+        m->bulk_gates = (size_t)kBrWavesPerBlock * (cus / 2);
+        m->chain_ms = 5.15;
+        m->bulk_ms = 19.9;
+        return true;
+    }
+    // one dependence level of n rotations by the rules of launch_blind_rotate, key switch and launch gaps included (MI355X, ms)
+    double launch_ms(size_t n) override
+    {
+        if (n == 0) return 0.0;
+        const size_t c = std::max<size_t>(1, round_gates() / kBrWavesPerBlock), round = (size_t)kBrWavesPerBlock * c;
+        auto small = [&](size_t t) {
+            if (t <= c) return 3.45;
+            if (t > 6 * c) return 19.3;
+            const size_t rem = t % (2 * c), paired = (rem == 0 || rem > c) ? t : t - rem;
+            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.7 + (paired < t ? 3.45 : 0.0);
+        };
+        const size_t full = n / round, tail = n % round;
+        return (double)full * 18.7 + (tail ? small(tail) : 0.0);
+    }
+    int gate_weight(int op) override { return op == CUFHE_AMD_MUX || op == CUFHE_AMD_NMUX ? 2 : op == CUFHE_AMD_NOT || op == CUFHE_AMD_COPY ? 0 : 1; }
+    int run_gates_lane(int s, int level, const sched::GateRef* g, size_t n, int lane) override
+    {
+        // chain lane: the paired low-latency kernel (the single one for at most a rotation per CU of its half); bulk lane: the batch kernel
+        const size_t cus = round_gates() / kBrWavesPerBlock;
+        g_br_shape = lane == 1 ? 1 : n <= cus / 2 ? 3 : 2;
+        const int rc = run_gates(s, level, g, n);
+        g_br_shape = 0;
+        return rc;
     }
     int event_create(void** ev) override
     {
@@ -304,6 +345,7 @@ void sched_apply_settings()
         if (g_sched_level_gates > 0) ds.set_level_flush_gates((size_t)g_sched_level_gates);
         ds.total_flush_gates = (size_t)g_sched_total_gates;
         ds.rename_outputs = g_sched_rename != 0;
+        ds.two_lane = g_sched_two_lane != 0;
         ds.copy_op = CUFHE_AMD_COPY;
     }
 }
@@ -570,6 +612,8 @@ int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset)
     out->record_ns = s.record_ns; out->retire_ns = s.retire_ns; out->launch_ns = s.launch_ns.load();
     out->renames = s.renames;
     out->home_copies = s.home_copies;
+    out->two_lane_groups = s.two_lane_groups.load();
+    out->two_lane_launches = s.two_lane_launches.load();
     out->worker_cpus = s.worker_cpus.load();
     if (reset) {
         const uint64_t cpus = s.worker_cpus.load();      // a property of the worker thread, not a counter

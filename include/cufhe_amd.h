@@ -172,6 +172,8 @@ typedef struct cufhe_amd_sched_stats {
     uint64_t renames;               /* outputs that took a fresh device buffer ("sched_rename") */
     uint64_t worker_cpus;           /* CPUs the device's launch worker is pinned to (0: not pinned; "sched_affinity") */
     uint64_t home_copies;           /* renamed values copied back to the ciphertext's own buffer before the host could look */
+    uint64_t two_lane_groups;       /* flushes scheduled gate by gate on two lanes ("sched_two_lane") ... */
+    uint64_t two_lane_launches;     /* ... and the launches they were cut into */
 } cufhe_amd_sched_stats;
 int cufhe_amd_sched_get_stats(int device, cufhe_amd_sched_stats* out, int reset);
 /* Timeline of the most recent flushes of a device (oldest first, at most 64 kept): host times are std::chrono::steady_clock
@@ -286,6 +288,13 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * value still in a renamed buffer when the caller asks for completion (Synchronize, StreamQuery of the stream that wrote
  * it) is copied home by one Copy gate in the flush that request triggers, so the published pointer holds the value
  * whenever the host may look -- results, tlwehost, tlwedevices and every API call behave as with 0 (never rename).
+ * "sched_two_lane" (default 1): a flush of several dependence levels (a recorded netlist) is scheduled GATE BY GATE instead of level by
+ * level when the library's cost model says that is faster: the gates on long dependence chains run as steps of the paired low-latency
+ * kernel on half of the compute units while the gates nothing waits for run as chunks of the batch kernel on the other half, on two
+ * internal streams (256 sixteen-bit ripple-carry adders, 32 carry levels of 256 gates behind one level of 8192: see DESIGN.md 2a).
+ * Needs "sched_rename" (the recorded program is kept single-assignment); results, completion rules and tlwedevices do not change.
+ * "br_shape" (of the calling thread; default 0 = the launch-shape rules above): 1 / 2 / 3 put every blind rotation of the thread's
+ * launches on the batch kernel / the paired low-latency kernel / the single one -- what the two lanes use, and tools/two_lane_probe.py.
  * "sched_level_gates" (default -1 = two grid rounds of the device, 16 gates per CU, while it has work -- on MI355X 4096: 32 768 gates through
  * the per-gate API 96.1 k -> 99.4 k gates/s --, one round when it is idle) / "sched_total_gates" (default 32768): a dependence level this
  * full is launched at once / bound on the recorded program.

@@ -47,6 +47,7 @@ static void toy_gate(int op, int level, uint32_t* out, const uint32_t* a, const 
     memcpy(out, r.data(), r.size() * 4);
 }
 
+static bool g_two_lane = true;     // argv[6]: flushes of several levels are scheduled gate by gate on two lanes when eligible (DeviceSched::compile_two_lane)
 static bool g_zero_copy = false;   // argv[5]: the stub's pinned memory is "visible to the device" (Backend::device_alias): no staging copies
 
 struct FakeEvent { uint64_t submitted = 0, completed = 0; };
@@ -139,6 +140,21 @@ class FakeBackend : public Backend {
         return 0;
     }
     std::string error_text() override { return "stub"; }
+    // two lanes: a toy model under which the per-gate plan wins whenever a flush is eligible -- the harness is after its ORDER, not its timing
+    bool lane_model(LaneModel* m) override
+    {
+        if (!g_two_lane) return false;
+        m->chain_gates = 3; m->bulk_gates = 8; m->chain_ms = 1.0; m->bulk_ms = 3.0;
+        return true;
+    }
+    double launch_ms(size_t n) override { return n ? 1000.0 : 0.0; }
+    int gate_weight(int op) override { return op == OP_MUX || op == OP_NMUX ? 2 : op == OP_HOME_COPY ? 0 : 1; }
+    int run_gates_lane(int s, int level, const GateRef* g, size_t n, int lane) override
+    {
+        { std::lock_guard<std::mutex> lk(mu_); lane_launches[lane == 0 ? 0 : 1]++; }
+        return run_gates(s, level, g, n);
+    }
+    uint64_t lane_launches[2] = {0, 0};
     // the caller's own streams (raw handles of Stream::st()): queues like the internal ones, filled by the test itself
     int caller_stream_wait(void* cs, void* ev) override
     {
@@ -242,7 +258,7 @@ struct Test {
             be.push_back(b);
             return b;
         });
-        for (int d = 0; d < gpus; d++) { S->dev(d).rename_outputs = g_rename; S->dev(d).copy_op = OP_HOME_COPY; }
+        for (int d = 0; d < gpus; d++) { S->dev(d).rename_outputs = g_rename; S->dev(d).two_lane = g_two_lane; S->dev(d).copy_op = OP_HOME_COPY; }
     }
     ~Test()
     {
@@ -352,7 +368,7 @@ struct Test {
         for (C* c : ct) {
             if (!c->alive || !c->m.dev_defined[dev]) continue;
             if (c->last_dev_upload_stream[dev] ? c->last_dev_upload_stream[dev] != st : c->last_dev_writer_stream[dev] != st) continue;
-            if (c->h->d[dev].dev != c->home[dev]) { failures++; printf("FAIL ctxt %p still renamed after StreamQuery\n", (void*)c); }
+            if (c->h->d[dev].dev != c->home[dev]) { failures++; printf("FAIL ctxt %p [%d] still renamed after StreamQuery (dev %d stream %p)\n", (void*)c, idx(c), dev, st); }
         }
     }
     void sync_and_check(bool check_dev)
@@ -499,8 +515,63 @@ static int random_program(uint64_t seed, int gpus, bool threaded)
     return t.failures;
 }
 
+// ---- random single-kind netlists: what the per-gate (two-lane) order of a flush is made for ----
+// One device, level-0 ciphertexts only, inputs uploaded by the first gates that read them, then a few hundred gates whose operands are
+// drawn from everything computed so far: deep chains beside wide independent work, temporaries re-used (renamed), in-place gates,
+// copying and device-resident gates mixed, Mux gates (two rotations), explicit D2H copies, several streams; Synchronize once at the end
+// (or in the middle, so that a second flush depends on the first).  Every value is compared with the in-order interpreter.
+static uint64_t g_two_lane_groups = 0, g_two_lane_launches = 0;
+static int dag_program(uint64_t seed, bool threaded)
+{
+    std::mt19937_64 prng(seed);
+    Test t(1, threaded, seed, 2 + (int)(prng() % 3));
+    t.S->dev(0).set_round_gates(100000);            // nothing is launched before the Synchronize: the whole netlist is one flush
+    t.S->dev(0).total_flush_gates = 1u << 30;
+    const int inputs = 6 + (int)(prng() % 10), temps = 4 + (int)(prng() % 12), gates = 60 + (int)(prng() % 400);
+    std::vector<Test::C*> pool;
+    for (int i = 0; i < inputs + temps; i++) pool.push_back(t.make(0));
+    std::vector<bool> defined(pool.size(), false);
+    auto st = [&](int i) { return (void*)(uintptr_t)(0x500 + i % 5); };
+    // the inputs reach the device with the first copying gates
+    for (int i = 0; i < inputs; i += 2) {
+        Test::C* out = pool[inputs + (i / 2) % temps];
+        t.gate(0, st(i), (int)(prng() % 10), true, out, pool[i], pool[(i + 1) % inputs], nullptr);
+        defined[i] = defined[(i + 1) % inputs] = true;
+        defined[inputs + (i / 2) % temps] = true;
+    }
+    const int mid_sync = prng() % 3 == 0 ? (int)(prng() % gates) : -1;
+    for (int k = 0; k < gates; k++) {
+        auto pick_def = [&]() {
+            for (;;) {
+                const size_t i = prng() % pool.size();
+                if (defined[i]) return i;
+            }
+        };
+        const size_t a = pick_def(), b = pick_def(), c = pick_def();
+        const bool chain = prng() % 3 != 0;              // most gates extend what was just computed: long chains
+        static size_t last = 0;
+        const size_t in0 = chain && defined[last] ? last : a;
+        size_t o = inputs + prng() % temps;
+        if (prng() % 6 == 0) o = in0;                    // in place
+        const unsigned r = (unsigned)(prng() % 20);
+        if (r == 0) t.gate(0, st(k), OP_NOT, false, pool[o], pool[in0], nullptr, nullptr);
+        else if (r <= 2) t.gate(0, st(k), prng() % 2 ? OP_MUX : OP_NMUX, false, pool[o], pool[in0], pool[b], pool[c]);
+        else if (r == 3) t.copy(0, st(k), pool[in0], false);
+        else if (r == 4 && pool[in0]->m.dev[0] == pool[in0]->m.host) t.gate(0, st(k), (int)(prng() % 10), true, pool[o], pool[in0], pool[b], nullptr);   // a copying gate whose re-upload is the device value
+        else t.gate(0, st(k), (int)(prng() % 10), false, pool[o], pool[in0], pool[b], nullptr);
+        if (r != 3) { defined[o] = true; last = o; }
+        if (k == mid_sync) t.sync_and_check(true);
+    }
+    for (size_t i = 0; i < pool.size(); i++)
+        if (defined[i] && prng() % 2) t.copy(0, st((int)i), pool[i], false);      // fetch some of the results
+    t.sync_and_check(true);
+    g_two_lane_groups += t.S->dev(0).stats().two_lane_groups.load();
+    g_two_lane_launches += t.S->dev(0).stats().two_lane_launches.load();
+    return t.failures;
+}
+
 // ---- shaped programs with launch-count expectations ----
-struct Shape { const char* name; uint64_t launch_sequences, levels, gates, groups, uploads, uploads_shared; int failures; };
+struct Shape { const char* name; uint64_t launch_sequences, levels, gates, groups, uploads, uploads_shared; int failures; uint64_t two_lane_groups = 0, two_lane_launches = 0; };
 
 static Shape chained(bool threaded)
 {
@@ -542,7 +613,7 @@ static Shape ripple(bool threaded)
         }
     t.sync_and_check(true);
     const Stats& s = t.S->dev(0).stats();
-    return {"ripple_adders", s.launch_sequences, s.levels, s.gates, s.groups, s.uploads, s.uploads_shared, t.failures};
+    return {"ripple_adders", s.launch_sequences, s.levels, s.gates, s.groups, s.uploads, s.uploads_shared, t.failures, s.two_lane_groups.load(), s.two_lane_launches.load()};
 }
 
 static Shape intensive(bool threaded)
@@ -620,6 +691,68 @@ class NullBackend : public Backend {
     std::string error_text() override { return ""; }
 };
 
+// The benchmark's dependent netlist (tools/bench_api.cpp: 256 x 16-bit ripple-carry adders, issued adder by adder) against a device
+// that does nothing but carries the HIP backend's cost model (sched_hip.inc.h: lane_model, launch_ms for 256 CUs): with
+// CUFHE_AMD_SCHED_DEBUG=1 the scheduler prints what the level order and the two-lane plan are estimated to cost -- the plan can be
+// tuned here, on the CPU.
+class ModelBackend : public NullBackend {
+   public:
+    bool lane_model(LaneModel* m) override { m->chain_gates = 256; m->bulk_gates = 1024; m->chain_ms = 5.15; m->bulk_ms = 19.9; return true; }
+    double launch_ms(size_t n) override
+    {
+        if (n == 0) return 0.0;
+        const size_t c = 256, round = 8 * c;
+        auto small = [&](size_t t) {
+            if (t <= c) return 3.45;
+            if (t > 6 * c) return 19.3;
+            const size_t rem = t % (2 * c), paired = (rem == 0 || rem > c) ? t : t - rem;
+            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.7 + (paired < t ? 3.45 : 0.0);
+        };
+        const size_t full = n / round, tail = n % round;
+        return (double)full * 18.7 + (tail ? small(tail) : 0.0);
+    }
+    int gate_weight(int op) override { return op == 10 || op == 11 ? 2 : op == 12 || op == 13 ? 0 : 1; }
+    uint64_t lanes[3] = {0, 0, 0};
+    int run_gates_lane(int, int, const GateRef*, size_t, int lane) override { lanes[lane == 0 ? 0 : 1]++; return 0; }
+    int run_gates(int, int, const GateRef*, size_t) override { lanes[2]++; return 0; }
+};
+
+static void plan_netlist(int adders, int bits)
+{
+    ModelBackend* mb = nullptr;
+    Scheduler S(1, true, [&](int) { mb = new ModelBackend(); return mb; });
+    S.dev(0).set_round_gates(2048);
+    std::vector<std::vector<uint32_t>> host;
+    std::vector<cufhe_amd_ctxt*> c;
+    std::string err;
+    auto make = [&]() { host.emplace_back(631, 7u); c.push_back(nullptr); S.ctxt_create(0, host.back().data(), &c.back(), &err); return c.back(); };
+    host.reserve((size_t)adders * (3 * bits + 3) + 8);
+    std::vector<cufhe_amd_ctxt*> x, y, sum, carry, t1, t2;
+    for (int i = 0; i < adders * bits; i++) { x.push_back(make()); y.push_back(make()); sum.push_back(make()); }
+    for (int i = 0; i < adders; i++) { carry.push_back(make()); t1.push_back(make()); t2.push_back(make()); }
+    auto gate = [&](void* st, int op, cufhe_amd_ctxt* o, cufhe_amd_ctxt* a, cufhe_amd_ctxt* b) {
+        cufhe_amd_ctxt* ins[3] = {a, b, nullptr};
+        S.dev(0).record_gate(st, op, true, o, ins);
+    };
+    for (int i = 0; i < adders; i++) {
+        void* st = (void*)(uintptr_t)(0x1000 + i % 256);
+        for (int k = 0; k < bits; k++) {
+            cufhe_amd_ctxt *X = x[i * bits + k], *Y = y[i * bits + k], *Sm = sum[i * bits + k], *C = carry[i];
+            gate(st, 5, t1[i], X, Y);
+            gate(st, 5, Sm, t1[i], C);
+            gate(st, 3, t2[i], t1[i], C);
+            gate(st, 3, t1[i], X, Y);
+            gate(st, 4, C, t1[i], t2[i]);
+        }
+    }
+    S.synchronize_all();
+    const Stats& st = S.dev(0).stats();
+    printf("PLAN {\"adders\": %d, \"bits\": %d, \"gates\": %llu, \"levels\": %llu, \"two_lane_groups\": %llu, \"chain_steps\": %llu, \"bulk_chunks\": %llu, \"other_launches\": %llu}\n",
+           adders, bits, (unsigned long long)st.gates, (unsigned long long)st.levels, (unsigned long long)st.two_lane_groups.load(),
+           (unsigned long long)mb->lanes[0], (unsigned long long)mb->lanes[1], (unsigned long long)mb->lanes[2]);
+    for (auto* k : c) S.ctxt_destroy(k);
+}
+
 static void host_cost(int gpus, int gates_per_gpu)
 {
     // what tools/bench_api.cpp does, for `gpus` devices from one issuing thread: Nand(out, a, b, st) on
@@ -661,6 +794,10 @@ static void host_cost(int gpus, int gates_per_gpu)
 
 int main(int argc, char** argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "plan")) {
+        plan_netlist(argc > 2 ? atoi(argv[2]) : 256, argc > 3 ? atoi(argv[3]) : 16);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "hostcost")) {
         host_cost(1, 4096);
         host_cost(8, 4096);
@@ -671,9 +808,15 @@ int main(int argc, char** argv)
     const bool threaded = argc > 3 ? atoi(argv[3]) != 0 : true;
     g_rename = argc > 4 ? atoi(argv[4]) != 0 : false;
     g_zero_copy = argc > 5 ? atoi(argv[5]) != 0 : false;
+    g_two_lane = argc > 6 ? atoi(argv[6]) != 0 : true;
     int failures = 0;
     if (const char* one = getenv("SCHED_HARNESS_SEED")) {      // one random program, for debugging: SCHED_HARNESS_SEED=1038 sched_harness 0 3 1
         const int sd = atoi(one);
+        if (sd >= 5000) {
+            const int f = dag_program(sd, threaded);
+            printf("netlist seed %d: %d mismatches\n", sd, f);
+            return f ? 1 : 0;
+        }
         const int f = random_program(sd, 1 + ((sd - 1000) % gpus), threaded);
         printf("seed %d: %d mismatches\n", sd, f);
         return f ? 1 : 0;
@@ -684,11 +827,21 @@ int main(int argc, char** argv)
         failures += f;
     }
     printf("random programs: %d seeds, %d failures\n", seeds, failures);
+    int dag_failures = 0;
+    for (int s = 1; s <= seeds; s++) {
+        const int f = dag_program(5000 + s, threaded);
+        if (f) printf("FAIL random netlist seed %d: %d mismatches\n", 5000 + s, f);
+        dag_failures += f;
+    }
+    printf("random netlists: %d seeds, %d failures, %llu flushes scheduled gate by gate on two lanes (%llu launches)\n", seeds, dag_failures,
+           (unsigned long long)g_two_lane_groups, (unsigned long long)g_two_lane_launches);
+    failures += dag_failures;
     for (Shape sh : {chained(threaded), ripple(threaded), intensive(threaded), multi_gpu(threaded)}) {
         printf("SHAPE {\"name\": \"%s\", \"launch_sequences\": %llu, \"levels\": %llu, \"gates\": %llu, \"groups\": %llu, "
-               "\"uploads\": %llu, \"uploads_shared\": %llu, \"failures\": %d}\n",
+               "\"uploads\": %llu, \"uploads_shared\": %llu, \"failures\": %d, \"two_lane_groups\": %llu, \"two_lane_launches\": %llu}\n",
                sh.name, (unsigned long long)sh.launch_sequences, (unsigned long long)sh.levels, (unsigned long long)sh.gates,
-               (unsigned long long)sh.groups, (unsigned long long)sh.uploads, (unsigned long long)sh.uploads_shared, sh.failures);
+               (unsigned long long)sh.groups, (unsigned long long)sh.uploads, (unsigned long long)sh.uploads_shared, sh.failures,
+               (unsigned long long)sh.two_lane_groups, (unsigned long long)sh.two_lane_launches);
         failures += sh.failures;
     }
     printf("%s\n", failures ? "FAILED" : "ALL PASS");

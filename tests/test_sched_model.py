@@ -27,8 +27,8 @@ def harness():
     return EXE
 
 
-def _run(exe, seeds, gpus, threaded, rename=0, zero_copy=0):
-    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded), str(rename), str(zero_copy)], capture_output=True, text=True, timeout=900)
+def _run(exe, seeds, gpus, threaded, rename=0, zero_copy=0, two_lane=1):
+    out = subprocess.run([exe, str(seeds), str(gpus), str(threaded), str(rename), str(zero_copy), str(two_lane)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     return {s["name"]: s for s in (json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("SHAPE "))}
 
@@ -63,6 +63,21 @@ def test_random_programs_with_zero_copy_staging(harness):
     assert shapes["chained"]["launch_sequences"] <= 6 and shapes["intensive"]["uploads"] <= 8
     _run(harness, 60, 3, 1, rename=1, zero_copy=1)
     _run(harness, 60, 2, 0, zero_copy=1)
+
+
+def test_random_netlists_scheduled_gate_by_gate_on_two_lanes(harness):
+    """DeviceSched::compile_two_lane ("sched_two_lane"): a flush of several dependence levels is list-scheduled gate by gate onto a chain
+    lane and a bulk lane (two internal streams) instead of level by level.  The harness's random netlists -- deep chains beside wide
+    work, re-used temporaries, in-place gates, Mux, fetched results, a second flush depending on the first -- are made for it: hundreds of
+    flushes take that path under the stub's cost model, every value equals the in-order interpreter's, and the ripple-carry adders do too."""
+    out = subprocess.run([harness, "150", "3", "1", "1", "0", "1"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ALL PASS" in out.stdout, out.stdout[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("random netlists:")][0]
+    assert int(line.split("failures, ")[1].split()[0]) >= 100, line            # the path was taken
+    shapes = {s["name"]: s for s in (json.loads(l[6:]) for l in out.stdout.splitlines() if l.startswith("SHAPE "))}
+    assert shapes["ripple_adders"]["two_lane_groups"] == 1 and shapes["ripple_adders"]["failures"] == 0
+    _run(harness, 100, 1, 0, rename=1, zero_copy=1, two_lane=1)
+    _run(harness, 100, 2, 1, rename=1, two_lane=0)        # the same netlists level by level
 
 
 def test_random_programs_on_one_device_without_workers(harness):
@@ -104,6 +119,16 @@ MUTATIONS = [
      "g->deps.push_back(dg->done);", ";", ["120", "3", "1", "0", "0"]),
     ("a write no longer follows the recorded readers of the buffer it overwrites",
      "if (has_readers(po)) D = std::max(D, max_reader(po) + 1);         // write after read", ";", ["120", "3", "1", "0", "0"]),
+    ("a launch of one lane no longer waits for the other lane's launch that produces its operands",
+     "if (ev) step(be_->stream_wait(st, ev));", ";", ["150", "1", "0", "1", "0", "1"]),
+    ("the remainder of a two-lane flush no longer waits for the chain lane",
+     "if (void* joined = new_event(sc)) step(be_->stream_wait(s, joined));", ";", ["150", "1", "0", "1", "0", "1"]),
+    ("with per-gate scheduling on, an output whose buffer still has recorded readers is no longer renamed",
+     "for_readers(po, [&](uint32_t r) { users = users || r >= base_depth_; });", ";", ["150", "1", "0", "1", "0", "1"]),
+    ("with per-gate scheduling on, an output whose buffer holds an unrelated recorded write is no longer renamed",
+     "if (!is_input && po.wdepth >= base_depth_) users = true;", ";", ["150", "1", "0", "1", "0", "1"]),
+    ("a copy home runs among the other gates of a two-lane flush instead of behind them",
+     "if (d.home_copy) { is_post[id] = 1; continue; }", "", ["150", "3", "0", "1", "0", "1"]),
     ("a renamed value refreshed by an upload on another stream is not copied home for that stream's StreamQuery",
      "pd.wstream != only_stream && pd.ustream != only_stream", "pd.wstream != only_stream", ["150", "3", "1", "1", "0"]),
 ]

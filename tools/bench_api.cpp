@@ -77,6 +77,7 @@ int main(int argc, char** argv)
             sum.gates += one.gates; sum.levels += one.levels; sum.launch_sequences += one.launch_sequences;
             sum.record_ns += one.record_ns; sum.retire_ns += one.retire_ns; sum.launch_ns += one.launch_ns;
             sum.max_level_gates = std::max(sum.max_level_gates, one.max_level_gates);
+            sum.two_lane_groups += one.two_lane_groups; sum.two_lane_launches += one.two_lane_launches;
         }
     };
     std::vector<cufhe_amd_sched_stats> per_dev(gpus);
@@ -145,7 +146,11 @@ int main(int argc, char** argv)
     // ("sched_rename" 1: outputs take fresh device buffers, only the carry chain is left, the values return to the
     // ciphertexts' own buffers in the flush of Synchronize) and once as the reference's buffers dictate ("sched_rename" 0:
     // the temporaries t1, t2 re-used bit after bit order the program).
-    for (int rename = 1; rename >= 0 && netlist; rename--) {
+    // variants: the defaults (renaming, per-gate scheduling on two lanes where the cost model picks it), the same level by level
+    // ("sched_two_lane" 0), and as the reference's buffers dictate ("sched_rename" 0)
+    for (int variant = 0; variant < 3 && netlist; variant++) {
+        const int rename = variant < 2 ? 1 : 0, two_lane = variant == 0 ? 1 : 0;
+        CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_two_lane", two_lane));
         CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", rename));
         const int kAdders = 256, kBits = 16;
         std::vector<Ctxt<P>> x(kAdders * kBits), y(kAdders * kBits), sum(kAdders * kBits), carry(kAdders), t1(kAdders), t2(kAdders);
@@ -174,13 +179,15 @@ int main(int argc, char** argv)
             best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             all_stats(ns, 0);
         }
-        std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"sched_rename\": %d, \"gates\": %llu, "
+        std::printf("{\"netlist\": \"256 x 16-bit ripple-carry adders, issued depth-first\", \"sched_rename\": %d, \"sched_two_lane\": %d, \"gates\": %llu, "
                     "\"total_ms\": %.2f, \"gates_per_s\": %.0f, \"dependence_levels\": %llu, \"launch_sequences\": %llu, "
-                    "\"max_level_gates\": %llu}\n",
-                    rename, (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
-                    (unsigned long long)ns.launch_sequences, (unsigned long long)ns.max_level_gates);
+                    "\"max_level_gates\": %llu, \"two_lane_flushes\": %llu, \"two_lane_launches\": %llu}\n",
+                    rename, two_lane, (unsigned long long)ns.gates, best, ns.gates / (best * 1e-3), (unsigned long long)ns.levels,
+                    (unsigned long long)ns.launch_sequences, (unsigned long long)ns.max_level_gates,
+                    (unsigned long long)ns.two_lane_groups, (unsigned long long)ns.two_lane_launches);
     }
     CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_rename", 1));
+    CUFHE_AMD_CHECK(cufhe_amd_set_option("sched_two_lane", 1));
     // What a smarter level assignment could reach at best, emulated by the program itself: the same adders in single-assignment
     // form (no buffer is written twice, so only data dependences order it), the sum bits -- the only gates nothing else reads --
     // withheld until the carry chains are launched and issued as ONE level at the end.  If this is not faster than the
