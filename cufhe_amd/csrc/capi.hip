@@ -1469,6 +1469,13 @@ int cufhe_amd_set_option(const char* key, long value)
         sched_apply_settings();        // the scheduler's flush rules are in grid rounds of 8 rotations per CU
         return 0;
     }
+    if (!strcmp(key, "sched_copy_threads")) {
+        if (value < 1 || value > 16) return fail(-1, "sched_copy_threads must be 1..16");
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        g_sched_copy_threads = value;
+        sched_apply_settings();          // takes effect for devices that have not flushed yet (the helpers start with the first large copy)
+        return 0;
+    }
     if (!strcmp(key, "sched_two_lane")) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
         if (int rc = sched_synchronize_all()) return rc;      // what is recorded was recorded under the old renaming policy

@@ -43,6 +43,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -307,6 +308,86 @@ struct Group {                        // consecutive levels flushed together
     std::vector<void*> lane_events;   // events between the two lanes of a per-gate scheduled flush (destroyed when the group retires)
 };
 
+// A few helper threads for the two host copies that sit on the latency path of a flush: ciphertexts out of the tlwehosts into the
+// pinned staging block (launch worker), results out of the pinned block into the tlwehosts (issuing thread).  run(n, f) calls f(0) ..
+// f(n-1), the caller taking its share, and returns when all are done; one run at a time.
+class CopyHelpers {
+   public:
+    explicit CopyHelpers(int threads)
+    {
+        for (int i = 0; i < threads; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~CopyHelpers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    template <class F>
+    void run(size_t n, F f)
+    {
+        if (n == 0) return;
+        std::lock_guard<std::mutex> one(run_mu_);
+        std::function<void(size_t)> fn = f;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            next_ = 0;
+            total_ = n;
+            done_ = 0;
+            epoch_++;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return done_ == total_; });
+        fn_ = nullptr;
+    }
+
+   private:
+    void work()
+    {
+        for (;;) {
+            size_t i;
+            const std::function<void(size_t)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!fn_ || next_ >= total_) return;
+                i = next_++;
+                fn = fn_;
+            }
+            (*fn)(i);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (++done_ == total_) cv_done_.notify_all();
+            }
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t next_ = 0, total_ = 0, done_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 class Scheduler;
 
 class DeviceSched {
@@ -451,6 +532,8 @@ class DeviceSched {
     // Per-gate scheduling of flushes with several dependence levels on two lanes (compile_two_lane below; "sched_two_lane").  Needs
     // renaming (the recorded program must be single-assignment) and a backend with a lane model.
     bool two_lane = true;
+    int copy_threads = 4;              // host threads that share a large gather / delivery ("sched_copy_threads"; before the first flush)
+    size_t parallel_copy_min = 1024;   // ... from this many ciphertexts of one level on
     int copy_op = 13;                  // the op code of Copy (CUFHE_AMD_COPY) in GateRef::op
     void forget_renamed(cufhe_amd_ctxt* c)        // the ciphertext goes away: nothing to copy home any more
     {
@@ -667,6 +750,14 @@ class DeviceSched {
     bool busy_ = false, stop_ = false;
     std::vector<Buf> pinned_cache_, dev_cache_;
     std::thread worker_;
+    // the copies in and out of the tlwehosts are split over copy_threads (the calling thread included) from parallel_copy_min ciphertexts on
+    std::unique_ptr<CopyHelpers> helpers_;
+    std::once_flag helpers_once_;
+    CopyHelpers* helpers()
+    {
+        std::call_once(helpers_once_, [&] { if (copy_threads > 1) helpers_.reset(new CopyHelpers(copy_threads - 1)); });
+        return helpers_.get();
+    }
 };
 
 class Scheduler {
@@ -1516,17 +1607,25 @@ inline int DeviceSched::launch(Group* g)
             constexpr size_t kChunk = 512;
             for (size_t pi = 0; pi < g->plans.size() && !rc; pi++) {
                 Plan* p = g->plans[pi];
-                for (size_t lo = 0; lo < p->uploads.size() && !rc; lo += kChunk) {
-                    const size_t hi = std::min(p->uploads.size(), lo + kChunk);
+                auto gather = [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi; i++) {
+                        cufhe_amd_ctxt* c = p->upload_ctxts[i];
+                        const uint32_t* shadow = c->shadow.load(std::memory_order_acquire);
+                        memcpy((uint32_t*)g->pin_in + p->in_base + p->uploads[i].slot, shadow ? shadow : c->host,
+                               (size_t)be_->words(c->level) * 4);
+                        c->host_reads.fetch_sub(1, std::memory_order_release);
+                    }
+                };
+                // a wave of chunks at a time: one chunk per copy thread, then (first level, staging visible to the device) the scatter
+                // of the wave is submitted while the next wave is being gathered
+                CopyHelpers* pool = p->uploads.size() >= parallel_copy_min ? helpers() : nullptr;
+                const size_t wave = kChunk * (pool ? (size_t)copy_threads : 1);
+                for (size_t lo = 0; lo < p->uploads.size() && !rc; lo += wave) {
+                    const size_t hi = std::min(p->uploads.size(), lo + wave);
                     {
                         std::lock_guard<std::mutex> lk(copy_mu_);
-                        for (size_t i = lo; i < hi; i++) {
-                            cufhe_amd_ctxt* c = p->upload_ctxts[i];
-                            const uint32_t* shadow = c->shadow.load(std::memory_order_acquire);
-                            memcpy((uint32_t*)g->pin_in + p->in_base + p->uploads[i].slot, shadow ? shadow : c->host,
-                                   (size_t)be_->words(c->level) * 4);
-                            c->host_reads.fetch_sub(1, std::memory_order_release);
-                        }
+                        if (pool) pool->run((hi - lo + kChunk - 1) / kChunk, [&](size_t j) { gather(lo + j * kChunk, std::min(hi, lo + (j + 1) * kChunk)); });
+                        else gather(lo, hi);
                     }
                     if (zero_copy && pi == 0) {
                         step(be_->copy_ctxts(s, p->uploads.data() + lo, hi - lo, g->dev_in + p->in_base, true));
@@ -1631,13 +1730,21 @@ inline int DeviceSched::retire(Group* g)
         err_ = g->error_text;
     }
     for (Plan* p : g->plans) {
-        for (const Delivery& dl : p->deliveries) {
-            cufhe_amd_ctxt* c = dl.c;
-            if (c->host_token != dl.token) continue;          // superseded by a newer result
-            if (c->host && !rc)
-                memcpy(c->host, (const uint32_t*)g->pin_out + p->out_base + dl.slot, (size_t)be_->words(c->level) * 4);
-            c->host_dev = -1;
-        }
+        auto deliver = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                const Delivery& dl = p->deliveries[i];
+                cufhe_amd_ctxt* c = dl.c;
+                if (c->host_token != dl.token) continue;          // superseded by a newer result (at most one entry per ciphertext is current)
+                if (c->host && !rc)
+                    memcpy(c->host, (const uint32_t*)g->pin_out + p->out_base + dl.slot, (size_t)be_->words(c->level) * 4);
+                c->host_dev = -1;
+            }
+        };
+        CopyHelpers* pool = p->deliveries.size() >= parallel_copy_min ? helpers() : nullptr;
+        if (pool) {
+            constexpr size_t kChunk = 256;
+            pool->run((p->deliveries.size() + kChunk - 1) / kChunk, [&](size_t j) { deliver(j * kChunk, std::min(p->deliveries.size(), (j + 1) * kChunk)); });
+        } else deliver(0, p->deliveries.size());
         // an upload snapshot lives in this level's staging copy: keep it only for inputs that were re-used
         for (size_t i = 0; i < p->uploads.size(); i++) {
             cufhe_amd_ctxt::PerDev& pd = p->upload_ctxts[i]->d[device_];
