@@ -1479,7 +1479,8 @@ int cufhe_amd_set_option(const char* key, long value)
     if (!strcmp(key, "sched_two_lane")) {
         std::lock_guard<std::mutex> lk2(g_sched_mu);
         if (int rc = sched_synchronize_all()) return rc;      // what is recorded was recorded under the old renaming policy
-        g_sched_two_lane = value != 0;
+        if (value < 0 || value > 2) return fail(-1, "sched_two_lane must be 0 (never), 1 (by the cost model) or 2 (whenever a flush is eligible)");
+        g_sched_two_lane = value;
         sched_apply_settings();
         return 0;
     }

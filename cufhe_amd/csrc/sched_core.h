@@ -531,7 +531,7 @@ class DeviceSched {
     bool rename_outputs = true;
     // Per-gate scheduling of flushes with several dependence levels on two lanes (compile_two_lane below; "sched_two_lane").  Needs
     // renaming (the recorded program must be single-assignment) and a backend with a lane model.
-    bool two_lane = true;
+    int two_lane = 1;                  // 0: never; 1: when the backend's cost model says it beats the level order; 2: whenever the flush is eligible (tests)
     int copy_threads = 4;              // host threads that share a large gather / delivery ("sched_copy_threads"; before the first flush)
     size_t parallel_copy_min = 1024;   // ... from this many ciphertexts of one level on
     int copy_op = 13;                  // the op code of Copy (CUFHE_AMD_COPY) in GateRef::op
@@ -1562,7 +1562,7 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
     if (debug)
         fprintf(stderr, "[sched] flush of %zu gates in %zu levels: level by level %.1f ms, two lanes %.1f ms (%d chain steps to %.1f, %d bulk chunks to %.1f, remainder %zu, copies home %zu)\n",
                 N, g->plans.size(), level_ms, out->est_ms, launches[0], tfree[0], launches[1], tfree[1], tail_rot, out->post.size());
-    return out->est_ms < 0.95 * level_ms;
+    return two_lane == 2 || out->est_ms < 0.95 * level_ms;
 }
 
 inline int DeviceSched::launch(Group* g)

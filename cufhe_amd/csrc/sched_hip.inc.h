@@ -346,7 +346,7 @@ void sched_apply_settings()
         if (g_sched_level_gates > 0) ds.set_level_flush_gates((size_t)g_sched_level_gates);
         ds.total_flush_gates = (size_t)g_sched_total_gates;
         ds.rename_outputs = g_sched_rename != 0;
-        ds.two_lane = g_sched_two_lane != 0;
+        ds.two_lane = (int)g_sched_two_lane;
         ds.copy_threads = (int)g_sched_copy_threads;
         ds.copy_op = CUFHE_AMD_COPY;
     }

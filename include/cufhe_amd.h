@@ -296,6 +296,7 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * kernel on half of the compute units while the gates nothing waits for run as chunks of the batch kernel on the other half, on two
  * internal streams (256 sixteen-bit ripple-carry adders, 32 carry levels of 256 gates behind one level of 8192: see DESIGN.md 2a).
  * Needs "sched_rename" (the recorded program is kept single-assignment); results, completion rules and tlwedevices do not change.
+ * 0 = never, 2 = whenever a flush is eligible, whatever the cost model says (tests).
  * "br_shape" (of the calling thread; default 0 = the launch-shape rules above): 1 / 2 / 3 put every blind rotation of the thread's
  * launches on the batch kernel / the paired low-latency kernel / the single one -- what the two lanes use, and tools/two_lane_probe.py.
  * "sched_level_gates" (default -1 = two grid rounds of the device, 16 gates per CU, while it has work -- on MI355X 4096: 32 768 gates through

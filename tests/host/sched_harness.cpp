@@ -259,7 +259,7 @@ struct Test {
             return b;
         });
         for (int d = 0; d < gpus; d++) {
-            S->dev(d).rename_outputs = g_rename; S->dev(d).two_lane = g_two_lane; S->dev(d).copy_op = OP_HOME_COPY;
+            S->dev(d).rename_outputs = g_rename; S->dev(d).two_lane = g_two_lane ? 1 : 0; S->dev(d).copy_op = OP_HOME_COPY;
             S->dev(d).parallel_copy_min = seed % 2 ? 3 : 1024;       // every other program: the gathers and deliveries split over the copy threads
         }
     }
