@@ -435,7 +435,7 @@ class DeviceSched {
     int flush(size_t max_levels = (size_t)-1);
     int flush_for_completion()                 // the caller is about to wait for everything: renamed values go home in the same flush
     {
-        restore_homes(nullptr);
+        restore_homes(nullptr, true);
         return flush();
     }
     int stream_query(void* stream);            // 1: everything issued on `stream` is complete and delivered
@@ -560,7 +560,7 @@ class DeviceSched {
     struct RetiredBuf { uint32_t* p; int level; uint32_t last_use; };      // renamed-away buffers still named by recorded levels
     std::vector<RetiredBuf> retired_;
     std::vector<cufhe_amd_ctxt*> renamed_;        // live ciphertexts whose value is in a renamed buffer on this device
-    int restore_homes(void* only_stream);         // record the copies back (all, or those last written on one caller stream)
+    int restore_homes(void* only_stream, bool all = false);     // record the copies back: all, or those last written / uploaded on one caller stream (nullptr is a stream like any other: the default one)
     static uint32_t max_depth_of(const std::vector<uint32_t>& v)
     {
         uint32_t m = 0;
@@ -1202,12 +1202,12 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
 // The caller is about to observe completion (Synchronize, or StreamQuery of `only_stream`): every value that lives in a
 // renamed buffer goes back to the buffer its ciphertext was created with, as one Copy gate per ciphertext at the first level
 // that follows the value's producer and the last recorded users of the home buffer.
-inline int DeviceSched::restore_homes(void* only_stream)
+inline int DeviceSched::restore_homes(void* only_stream, bool all)
 {
     for (size_t k = 0; k < renamed_.size();) {
         cufhe_amd_ctxt* c = renamed_[k];
         cufhe_amd_ctxt::PerDev& pd = c->d[device_];
-        if (only_stream && !pd.umany && pd.wstream != only_stream && pd.ustream != only_stream) { k++; continue; }
+        if (!all && !pd.umany && pd.wstream != only_stream && !(pd.ustream == only_stream && only_stream != nullptr)) { k++; continue; }
         uint32_t D = std::max(base_depth_, pd.ready);
         D = std::max(D, max_depth_of(pd.home_deps) + 1);
         Plan& p = plan_at(D);
@@ -1796,7 +1796,7 @@ inline int DeviceSched::retire(Group* g)
 
 inline int DeviceSched::synchronize()
 {
-    restore_homes(nullptr);
+    restore_homes(nullptr, true);
     if (int rc = flush()) return rc;
     wait_worker_idle();
     be_->bind_thread();

@@ -130,7 +130,7 @@ MUTATIONS = [
     ("a copy home runs among the other gates of a two-lane flush instead of behind them",
      "if (d.home_copy) { is_post[id] = 1; continue; }", "", ["150", "3", "0", "1", "0", "1"]),
     ("a renamed value refreshed by an upload on another stream is not copied home for that stream's StreamQuery",
-     "pd.wstream != only_stream && pd.ustream != only_stream", "pd.wstream != only_stream", ["150", "3", "1", "1", "0"]),
+     "&& !(pd.ustream == only_stream && only_stream != nullptr)", "", ["150", "3", "1", "1", "0"]),
 ]
 
 
