@@ -1469,6 +1469,13 @@ int cufhe_amd_set_option(const char* key, long value)
         sched_apply_settings();        // the scheduler's flush rules are in grid rounds of 8 rotations per CU
         return 0;
     }
+    if (!strcmp(key, "sched_idle_gates")) {
+        if (value < 1 && value != -1) return fail(-1, "sched_idle_gates must be -1 (one grid round) or a gate count");
+        std::lock_guard<std::mutex> lk2(g_sched_mu);
+        g_sched_idle_gates = value;
+        sched_apply_settings();
+        return 0;
+    }
     if (!strcmp(key, "sched_copy_threads")) {
         if (value < 1 || value > 16) return fail(-1, "sched_copy_threads must be 1..16");
         std::lock_guard<std::mutex> lk2(g_sched_mu);

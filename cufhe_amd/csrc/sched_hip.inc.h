@@ -14,6 +14,7 @@ long g_sched_streams = 4;        // internal HIP streams per device
 long g_sched_threads = 1;        // 1: a launch worker thread per device, 0: launches on the issuing thread
 long g_sched_level_gates = -1;   // a dependence level this full is launched at once: -1 = two rounds of the batch kernel's grid (8 rotations per CU each), one when the device is idle
 long g_sched_total_gates = 32768;
+long g_sched_idle_gates = -1;     // gates of a level at which an IDLE device is handed it (-1: one grid round)
 long g_sched_copy_threads = 4;    // host threads (the calling one included) that share a large gather out of / delivery into the tlwehosts; before the first flush
 long g_sched_two_lane = 1;        // flushes of several dependence levels are scheduled gate by gate on two lanes when the cost model says so (sched_core.h: compile_two_lane)
 long g_sched_rename = 1;          // outputs take fresh device buffers instead of waiting for the old one's users, values return to the ciphertext's own buffer before the host may look (sched_core.h); 0: never
@@ -344,6 +345,7 @@ void sched_apply_settings()
         sched::DeviceSched& ds = g_scheduler->dev(d);
         ds.set_round_gates(ds.backend()->round_gates());
         if (g_sched_level_gates > 0) ds.set_level_flush_gates((size_t)g_sched_level_gates);
+        if (g_sched_idle_gates > 0) ds.idle_flush_gates = std::min(ds.level_flush_gates, (size_t)g_sched_idle_gates);
         ds.total_flush_gates = (size_t)g_sched_total_gates;
         ds.rename_outputs = g_sched_rename != 0;
         ds.two_lane = (int)g_sched_two_lane;

@@ -288,6 +288,9 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * value still in a renamed buffer when the caller asks for completion (Synchronize, StreamQuery of the stream that wrote
  * it) is copied home by one Copy gate in the flush that request triggers, so the published pointer holds the value
  * whenever the host may look -- results, tlwehost, tlwedevices and every API call behave as with 0 (never rename).
+ * "sched_idle_gates" (default -1 = one grid round): gates of a level at which an IDLE device is handed it (never more than "sched_level_gates").
+ * (Two rounds -- one flush and one key-switch launch for a burst of 4096 gates -- was measured and is no faster: the device then starts
+ * 0.7 ms later, which is what the second key-switch launch costs.)
  * "sched_copy_threads" (default 4; before the first flush): host threads, the calling one included, that share the two copies on a flush's
  * latency path once it moves 1024 ciphertexts or more -- inputs out of the tlwehosts into the pinned staging block (launch worker) and
  * results back into the tlwehosts (issuing thread): 4096 NANDs' 10 MB of inputs are gathered in 0.2 ms instead of 0.7.
