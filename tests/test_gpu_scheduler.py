@@ -541,3 +541,70 @@ def test_random_program_matches_in_order_oracle(engine, keys, oracle, rename, se
             assert np.array_equal(c.tlwehost, host[id(c)]), f"level {lvl} ciphertext {i}"
     for s in sts:
         s.Destroy()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("CUFHE_AMD_STRESS_SEEDS", "2")))))
+def test_random_netlist_on_two_lanes_matches_in_order_oracle(engine, keys, seed):
+    """A seeded random NETLIST on the real device with the flush scheduled gate by gate on two lanes ("sched_two_lane" 2, "cus_override"
+    16: chain steps of 16 rotations beside bulk chunks of 64 on two internal streams): inputs uploaded once, then 260 device-resident gates
+    whose operands are drawn from everything computed so far -- long chains beside wide independent work, temporaries re-used (renamed),
+    in-place gates, Mux (two rotations), Not -- every value fetched at the end.  Every tlwehost must hold the words of the in-order
+    interpreter whose gates are the CPU oracle's (the CPU twin with a stubbed device: tests/host/sched_harness.cpp dag_program)."""
+    api = engine.api
+    api.set_option("cus_override", 16)
+    api.set_option("sched_two_lane", 2)
+    try:
+        rng = np.random.default_rng(4100 + seed)
+        n_in, n_tmp, n_gates = 10, 14, 260
+        cts = [api.Ctxt(0) for _ in range(n_in + n_tmp)]
+        enc = keys.encrypt(rng.integers(0, 2, n_in).astype(np.uint8), 0, seed=9100 + seed)
+        sts = [api.Stream() for _ in range(4)]
+        for s in sts:
+            s.Create()
+        dev = [None] * len(cts)
+        for i in range(n_in):
+            cts[i].tlwehost[:] = enc[i]
+            api.CtxtCopyH2D(cts[i], sts[i % 4])
+            dev[i] = enc[i].copy()
+        two = ["NAND", "NOR", "XNOR", "AND", "OR", "XOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+        gfn = {n: getattr(api, "g" + n[0] + n[1:].lower().replace("ny", "NY").replace("yn", "YN")) for n in two}
+
+        def oracle(op, ins):
+            arrs = [np.ascontiguousarray(x).reshape(1, -1) for x in ins] + [None] * (3 - len(ins))
+            return keys.gate_batch(op, 0, arrs[0], arrs[1], arrs[2], threads=1)[0]
+        api.Synchronize()
+        api.sched_stats(reset=True)
+        last = 0
+        for k in range(n_gates):
+            defined = [i for i in range(len(cts)) if dev[i] is not None]
+            a = last if rng.random() < 0.65 else defined[rng.integers(len(defined))]       # most gates extend what was just computed
+            b, c = defined[rng.integers(len(defined))], defined[rng.integers(len(defined))]
+            o = a if rng.random() < 0.15 else n_in + rng.integers(n_tmp)
+            st = sts[rng.integers(4)]
+            r = rng.random()
+            if r < 0.05:
+                res = oracle(ol.OPS.index("NOT"), [dev[a]])
+                api.gNot(cts[o], cts[a], st)
+            elif r < 0.15:
+                res = oracle(ol.OPS.index("MUX"), [dev[a], dev[b], dev[c]])
+                api.gMux(cts[o], cts[a], cts[b], cts[c], st)
+            else:
+                name = two[rng.integers(len(two))]
+                res = oracle(ol.OPS.index(name), [dev[a], dev[b]])
+                gfn[name](cts[o], cts[a], cts[b], st)
+            dev[o] = res
+            last = o
+        for i in range(len(cts)):
+            if dev[i] is not None:
+                api.CtxtCopyD2H(cts[i], sts[i % 4])
+        api.Synchronize()
+        stats = api.sched_stats()
+        assert stats.two_lane_groups >= 1 and stats.two_lane_launches >= 8, (stats.two_lane_groups, stats.two_lane_launches, stats.levels)
+        for i in range(len(cts)):
+            if dev[i] is not None:
+                assert np.array_equal(cts[i].tlwehost, dev[i]), f"ciphertext {i} differs from the in-order oracle"
+        for s in sts:
+            s.Destroy()
+    finally:
+        api.set_option("sched_two_lane", 1)
+        api.set_option("cus_override", 0)
