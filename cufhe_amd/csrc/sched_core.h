@@ -44,6 +44,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -560,6 +561,7 @@ class DeviceSched {
     struct RetiredBuf { uint32_t* p; int level; uint32_t last_use; };      // renamed-away buffers still named by recorded levels
     std::vector<RetiredBuf> retired_;
     std::vector<cufhe_amd_ctxt*> renamed_;        // live ciphertexts whose value is in a renamed buffer on this device
+    uint32_t home_copy_depth_ = 0;                // the lowest level on record that holds a copy home (0: none)
     int restore_homes(void* only_stream, bool all = false);     // record the copies back: all, or those last written / uploaded on one caller stream (nullptr is a stream like any other: the default one)
     static uint32_t max_depth_of(const std::vector<uint32_t>& v)
     {
@@ -1149,6 +1151,7 @@ inline int DeviceSched::record_gate(void* stream, int op, bool copying, cufhe_am
     p.gates[kind].push_back(GateRef{op, po.dev, in_dev[0], in_dev[1], in_dev[2]});
     p.deps[kind].push_back(gd);
     if (copying) {
+        if (home_copy_depth_ && D >= home_copy_depth_) p.level_ordered = true;      // a per-gate order fetches results BEFORE the copies home run
         const size_t slot = p.out_words;
         p.out_words += (size_t)be_->words(out->level);
         p.downloads.push_back({po.dev, slot, out->level});
@@ -1181,6 +1184,7 @@ inline int DeviceSched::record_copy(void* stream, cufhe_amd_ctxt* c, bool to_dev
     if (int rc = owner_->before_host_write(c, device_)) return fail(rc, "scheduler: flushing another device failed");
     const uint32_t D = std::max(base_depth_, pd.wdepth);
     Plan& p = plan_at(D);
+    if (home_copy_depth_ && D >= home_copy_depth_) p.level_ordered = true;          // a per-gate order fetches results BEFORE the copies home run
     add_dep(p, pd.wdepth);
     add_reader(pd, D);
     const size_t slot = p.out_words;
@@ -1216,6 +1220,7 @@ inline int DeviceSched::restore_homes(void* only_stream, bool all)
         GateDep gd;
         gd.home_copy = true;
         if (pd.wdepth >= base_depth_ && !pd.w_upload) { gd.depth[0] = pd.wdepth; gd.idx[0] = pd.widx; gd.kind[0] = pd.wkind; }
+        home_copy_depth_ = home_copy_depth_ ? std::min(home_copy_depth_, D) : D;
         const uint32_t copy_idx = (uint32_t)p.gates[c->level].size();
         p.gates[c->level].push_back(GateRef{copy_op, pd.home, pd.dev, nullptr, nullptr});
         p.deps[c->level].push_back(gd);
@@ -1305,6 +1310,7 @@ inline int DeviceSched::flush(size_t max_levels)
             }
         }
     base_depth_ += (uint32_t)k;
+    if (home_copy_depth_ && home_copy_depth_ < base_depth_) home_copy_depth_ = levels_.empty() ? 0 : base_depth_;      // (conservative for what is left on record)
     pending_gates_ -= std::min(pending_gates_, ngates);
     for (Plan* p : g->plans)
         for (void* st : p->streams) {
@@ -1372,6 +1378,7 @@ inline void DeviceSched::worker_loop()
 // a hazard that a level kept apart because it could not be renamed) leaves the flush to the level order.
 inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
 {
+    const int64_t t_compile = now_ns();
     Backend::LaneModel m;
     if (!two_lane || !rename_outputs || nstreams_ < 2 || g->plans.size() < 3 || !be_->lane_model(&m) || m.chain_gates == 0 || m.bulk_gates == 0) return false;
     int kind = -1;
@@ -1394,6 +1401,7 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
     std::vector<int32_t> prod(3 * N, -1);
     std::vector<uint32_t> ncons(N, 0), indeg(N, 0), height(N, 0);
     std::vector<uint8_t> weight(N, 1), is_post(N, 0);
+    std::vector<const GateRef*> gref(N, nullptr);
     double level_ms = 0;
     for (size_t pi = 0; pi < g->plans.size(); pi++) {
         const Plan* p = g->plans[pi];
@@ -1402,6 +1410,7 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
         size_t rotations = 0;
         for (size_t gi = 0; gi < n; gi++) {
             const size_t id = off[pi] + gi;
+            gref[id] = &p->gates[kind][gi];
             weight[id] = (uint8_t)std::max(0, std::min(255, be_->gate_weight(p->gates[kind][gi].op)));
             rotations += weight[id];
             const GateDep& d = p->deps[kind][gi];
@@ -1433,30 +1442,25 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
     uint32_t hmax = 0;
     for (size_t id = 0; id < N; id++) hmax = std::max(hmax, height[id]);
     if (hmax < 4) return false;                                            // no chain worth a lane of its own
-    auto gate_of = [&](size_t id) -> const GateRef& {
-        const size_t pi = (size_t)(std::upper_bound(off.begin(), off.end(), id) - off.begin()) - 1;
-        return g->plans[pi]->gates[kind][id - off[pi]];
-    };
+    auto gate_of = [&](size_t id) -> const GateRef& { return *gref[id]; };
     // list scheduling over the two lanes, simulated on the backend's cost model
-    struct Avail { double t; uint32_t id; bool operator<(const Avail& o) const { return t > o.t; } };                 // min-heap on time
-    struct Ready { uint32_t h, id; bool operator<(const Ready& o) const { return h != o.h ? h < o.h : id > o.id; } }; // max-heap on height, then issue order
-    std::vector<Avail> pending;
-    std::vector<Ready> ready;
+    // gates whose producers are all scheduled, by the time the last of them ends: one entry per launch end (a few dozen), not per gate
+    std::map<double, std::vector<uint32_t>> pending;
+    // the ready gates by height, each bucket in the order its gates became ready (a flush of 20 000 gates is planned in well under a
+    // millisecond: the plan sits on the critical path of the flush)
+    std::vector<std::vector<uint32_t>> bucket(hmax + 1);
+    std::vector<size_t> bucket_head(hmax + 1, 0);
+    size_t ready_count = 0;
+    auto push_ready = [&](uint32_t id) { bucket[height[id]].push_back(id); ready_count++; };
     std::vector<double> fin(N, -1.0);
     std::vector<int32_t> lane_of(N, -1), launch_of(N, -1);
     out->post.clear();
     size_t scheduled = 0, unscheduled_with_consumers = 0;
     for (size_t id = 0; id < N; id++) {
-        if (is_post[id]) {
-            // results are fetched before the copies home run: a fetch of the value a copy home DELIVERS (recorded behind it) does not fit
-            const size_t pi = (size_t)(std::upper_bound(off.begin(), off.end(), id) - off.begin()) - 1;
-            const uint32_t* home = gate_of(id).out;
-            for (size_t pj = pi; pj < g->plans.size(); pj++)
-                for (const CopyRec& r : g->plans[pj]->downloads)
-                    if (r.dev == home) return false;
-            out->post.push_back(gate_of(id)); lane_of[id] = 2; scheduled++; continue;
-        }
-        if (indeg[id] == 0) { ready.push_back({height[id], (uint32_t)id}); std::push_heap(ready.begin(), ready.end()); }
+        // (a fetch of the value a copy home delivers -- recorded at its level or behind it -- marks its level level_ordered at record time:
+        // results are fetched before the copies home run)
+        if (is_post[id]) { out->post.push_back(gate_of(id)); lane_of[id] = 2; scheduled++; continue; }
+        if (indeg[id] == 0) push_ready((uint32_t)id);
     }
     double tfree[2] = {0.0, 0.0};
     int launches[2] = {0, 0};
@@ -1472,34 +1476,28 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
     while (scheduled < N && unscheduled_with_consumers > 0) {
         const int lane = tfree[0] <= tfree[1] ? 0 : 1;
         const double t = tfree[lane];
-        while (!pending.empty() && pending.front().t <= t) {
-            std::pop_heap(pending.begin(), pending.end());
-            const uint32_t id = pending.back().id;
-            pending.pop_back();
-            ready.push_back({height[id], id});
-            std::push_heap(ready.begin(), ready.end());
+        while (!pending.empty() && pending.begin()->first <= t) {
+            for (uint32_t id : pending.begin()->second) push_ready(id);
+            pending.erase(pending.begin());
         }
-        const double next = pending.empty() ? -1.0 : pending.front().t;
-        if (ready.empty()) {
+        const double next = pending.empty() ? -1.0 : pending.begin()->first;
+        if (ready_count == 0) {
             if (next < 0) return false;                                    // cannot happen in a DAG: leave the flush to the level order
             tfree[lane] = std::max(next, t);
             continue;
         }
-        // The bulk lane keeps a gate for a whole chunk (about `margin` chain steps): it may only take gates that the longest remaining
-        // chain does not reach for that long -- those at least `margin` below the greatest height still unscheduled -- and among them
-        // the ones needed soonest.  The chain lane takes the most urgent gates first.
+        // The chain lane takes the most urgent gates first (greatest height).  The bulk lane keeps a gate for a whole chunk (about
+        // `margin` chain steps): it may only take gates that the longest remaining chain does not reach for that long -- those at least
+        // `margin` below the greatest height still unscheduled -- and among them the ones needed soonest.
         while (hrem > 0 && by_height[hrem] == 0) hrem--;
-        std::vector<Ready> too_urgent;
+        int top = (int)hmax;                                               // the highest bucket this lane may take from
         if (lane == 1) {
-            while (!ready.empty() && ready.front().h + margin > hrem) {
-                std::pop_heap(ready.begin(), ready.end());
-                too_urgent.push_back(ready.back());
-                ready.pop_back();
-            }
-            if (ready.size() < cap[1] / 2) {
+            top = (int)hrem - (int)margin;
+            size_t eligible = 0;
+            for (int hh = top; hh >= 0 && eligible < cap[1] / 2; hh--) eligible += bucket[(size_t)hh].size() - bucket_head[(size_t)hh];
+            if (eligible < cap[1] / 2) {
                 // a chunk of the throughput shape costs its 19 ms whatever it carries: the bulk lane waits for a worthwhile load -- until
                 // more gates become available or the chain lane (busy beyond t, or it would have been chosen) has taken its pick
-                for (const Ready& r : too_urgent) { ready.push_back(r); std::push_heap(ready.begin(), ready.end()); }
                 tfree[1] = next >= 0 ? std::min(next, tfree[0]) : tfree[0];
                 continue;
             }
@@ -1509,25 +1507,29 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
         L.index = launches[lane]++;
         size_t load = 0;
         std::vector<uint32_t> placed;
-        while (!ready.empty()) {
-            const uint32_t id = ready.front().id;
-            if (load && load + weight[id] > cap[lane]) break;
-            std::pop_heap(ready.begin(), ready.end());
-            ready.pop_back();
-            by_height[height[id]]--;
-            load += weight[id];
-            L.gates.push_back(gate_of(id));
-            placed.push_back(id);
-            lane_of[id] = lane;
-            launch_of[id] = L.index;
-            for (int i = 0; i < 3; i++) {
-                const int32_t pr = prod[3 * id + i];
-                if (pr >= 0 && lane_of[(size_t)pr] == 1 - lane) L.wait_other = std::max(L.wait_other, launch_of[(size_t)pr]);
+        bool full = false;
+        for (int hh = top; hh >= 0 && !full; hh--) {
+            std::vector<uint32_t>& b = bucket[(size_t)hh];
+            size_t& head = bucket_head[(size_t)hh];
+            while (head < b.size()) {
+                const uint32_t id = b[head];
+                if (load && load + weight[id] > cap[lane]) { full = true; break; }
+                head++;
+                ready_count--;
+                by_height[height[id]]--;
+                load += weight[id];
+                L.gates.push_back(gate_of(id));
+                placed.push_back(id);
+                lane_of[id] = lane;
+                launch_of[id] = L.index;
+                for (int i = 0; i < 3; i++) {
+                    const int32_t pr = prod[3 * id + i];
+                    if (pr >= 0 && lane_of[(size_t)pr] == 1 - lane) L.wait_other = std::max(L.wait_other, launch_of[(size_t)pr]);
+                }
+                scheduled++;
+                if (ncons[id]) unscheduled_with_consumers--;
             }
-            scheduled++;
-            if (ncons[id]) unscheduled_with_consumers--;
         }
-        for (const Ready& r : too_urgent) { ready.push_back(r); std::push_heap(ready.begin(), ready.end()); }
         const double finish = t + dur[lane] * (lane == 0 && 2 * load <= cap[0] ? 0.7 : 1.0);      // a half-empty chain step takes the single-rotation shape
         tfree[lane] = finish;
         out->seq.push_back(std::move(L));
@@ -1540,8 +1542,7 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
                     double a = 0;
                     for (int i = 0; i < 3; i++)
                         if (prod[3 * c + i] >= 0) a = std::max(a, fin[(size_t)prod[3 * c + i]]);
-                    pending.push_back({a, c});
-                    std::push_heap(pending.begin(), pending.end());
+                    pending[a].push_back(c);
                 }
             }
     }
@@ -1560,8 +1561,8 @@ inline bool DeviceSched::compile_two_lane(Group* g, TwoLanePlan* out)
     out->est_ms = std::max(tfree[0], tfree[1]) + (tail_rot ? be_->launch_ms(tail_rot) : 0.0);
     static const bool debug = getenv("CUFHE_AMD_SCHED_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[sched] flush of %zu gates in %zu levels: level by level %.1f ms, two lanes %.1f ms (%d chain steps to %.1f, %d bulk chunks to %.1f, remainder %zu, copies home %zu)\n",
-                N, g->plans.size(), level_ms, out->est_ms, launches[0], tfree[0], launches[1], tfree[1], tail_rot, out->post.size());
+        fprintf(stderr, "[sched] flush of %zu gates in %zu levels: level by level %.1f ms, two lanes %.1f ms (%d chain steps to %.1f, %d bulk chunks to %.1f, remainder %zu, copies home %zu; planned in %.2f ms)\n",
+                N, g->plans.size(), level_ms, out->est_ms, launches[0], tfree[0], launches[1], tfree[1], tail_rot, out->post.size(), (now_ns() - t_compile) * 1e-6);
     return two_lane == 2 || out->est_ms < 0.95 * level_ms;
 }
 
