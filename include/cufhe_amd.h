@@ -131,8 +131,9 @@ uint32_t* cufhe_amd_ctxt_device_ptr(cufhe_amd_ctxt* c, int device);   /* constan
  * :160-167, device buffers only).  The gate is RECORDED with its data dependences; the recorded
  * program of a device is launched level by level (all gates whose operands are ready: one
  * blind-rotate + one key-switch launch per level) at Synchronize / StreamQuery / cufhe_amd_flush,
- * or as soon as a level holds two grid rounds of gates (one when the device is idle; a round = 8 gates per compute unit).  Stream order, output aliasing, shared inputs and
- * completion semantics are those of the reference (see cufhe_amd/csrc/sched_core.h).
+ * or as soon as a level holds two grid rounds of gates (one when the device is idle; a round = 8 gates per compute unit).  A flush of several
+ * levels (a recorded netlist) may instead be scheduled gate by gate on two lanes ("sched_two_lane" below).  Stream order, output aliasing,
+ * shared inputs and completion semantics are those of the reference (see cufhe_amd/csrc/sched_core.h).
  * cufhe_amd_ctxt_destroy never waits: buffers are recycled when the last recorded gate naming
  * them has retired. */
 int cufhe_amd_enqueue_gate(int device, void* stream, int op, int copying, cufhe_amd_ctxt* out,
