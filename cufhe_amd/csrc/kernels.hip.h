@@ -402,6 +402,67 @@ constexpr int kKsBuffers = 3;
 constexpr int kKsLdsDigits = kKsWaves * kN * 2;                  // u16 digit words: 32768
 constexpr int kKsLdsBytes = kKsLdsDigits + kKsBuffers * kKsStepBytes;   // 155648
 
+// One digit of one key-switch step on one wave: f = val + 2 (wave-uniform, in an SGPR) selects +row(v=2) [f 0], +row(v=1) [f 1],
+// nothing [f 2] or -row(v=1) [f 3]; the row lies at a compile-time offset from the lane's three LDS addresses and is added to the
+// lane's ten sums IN PLACE.  The three-way choice is spelled as scalar branches INSIDE two asm blocks (the loads, then the ten
+// additions or subtractions), so that the compiler sees straight-line code: written as `if (f == 3) res -= r; else res += r;` the
+// structurised control flow gave every arm fresh result registers and copied them back (6 v_mov_b64 per digit) and the row offset
+// went through a VGPR (3 v_add per digit) -- 21 vector instructions per digit where 10 do the work (profiles/r06_keyswitch.md).
+typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ks_u32x2 __attribute__((ext_vector_type(2)));
+template <int ROW1, int ROW2>
+__device__ __forceinline__ void ks_digit(const uint32_t f, const uint32_t a0, const uint32_t a1, const uint32_t a2, uint32_t (&res)[10])
+{
+    ks_u32x4 r0, r1;
+    ks_u32x2 r2;
+    asm volatile(
+        "s_cmp_eq_u32 %3, 2\n\t"
+        "s_cbranch_scc1 .Lks_ld_end_%=\n\t"
+        "s_cmp_eq_u32 %3, 0\n\t"
+        "s_cbranch_scc1 .Lks_ld_two_%=\n\t"
+        "ds_read_b128 %0, %4 offset:%7\n\t"
+        "ds_read_b128 %1, %5 offset:%7\n\t"
+        "ds_read_b64 %2, %6 offset:%7\n\t"
+        "s_branch .Lks_ld_wait_%=\n"
+        ".Lks_ld_two_%=:\n\t"
+        "ds_read_b128 %0, %4 offset:%8\n\t"
+        "ds_read_b128 %1, %5 offset:%8\n\t"
+        "ds_read_b64 %2, %6 offset:%8\n"
+        ".Lks_ld_wait_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        ".Lks_ld_end_%=:"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+        : "s"(f), "v"(a0), "v"(a1), "v"(a2), "n"(ROW1), "n"(ROW2)
+        : "memory", "scc");
+#define CUFHE_AMD_KS_TEN(OP)                                                                                               \
+    OP " %0, %0, %11\n\t" OP " %1, %1, %12\n\t" OP " %2, %2, %13\n\t" OP " %3, %3, %14\n\t" OP " %4, %4, %15\n\t"             \
+    OP " %5, %5, %16\n\t" OP " %6, %6, %17\n\t" OP " %7, %7, %18\n\t" OP " %8, %8, %19\n\t" OP " %9, %9, %20\n"
+    asm volatile(
+        "s_cmp_eq_u32 %10, 2\n\t"
+        "s_cbranch_scc1 .Lks_acc_end_%=\n\t"
+        "s_cmp_eq_u32 %10, 3\n\t"
+        "s_cbranch_scc1 .Lks_acc_sub_%=\n\t"
+        CUFHE_AMD_KS_TEN("v_add_u32_e32")
+        "\ts_branch .Lks_acc_end_%=\n"
+        ".Lks_acc_sub_%=:\n\t"
+        CUFHE_AMD_KS_TEN("v_sub_u32_e32")
+        ".Lks_acc_end_%=:"
+        : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9])
+        : "s"(f), "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y)
+        : "scc");
+#undef CUFHE_AMD_KS_TEN
+}
+
+template <int K>
+__device__ __forceinline__ void ks_digits(const uint32_t dj, const uint32_t (&pb)[3], uint32_t (&res)[10])
+{
+    if constexpr (K < kKsT) {
+        const uint32_t f = (dj >> (16 - (K + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1);
+        ks_digit<(K * kKsNumBase) * (kKsRowPad * 4), (K * kKsNumBase + 1) * (kKsRowPad * 4)>(f, pb[0], pb[1], pb[2], res);
+        ks_digits<K + 1>(dj, pb, res);
+    }
+}
+
 // per_wg (1..16): ciphertexts per workgroup.  Waves at and above per_wg only move table pieces and keep the barriers: a
 // launch of fewer than 4096 ciphertexts then still covers every CU, and a step carries fewer row reads and additions
 // (2048 ciphertexts: 1.27 ms with 8 per workgroup against 1.53 with 16).
@@ -433,6 +494,7 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     issue(0);
     issue(1);
 
+
     // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98; only the top
     // t*basebit = 16 bits of a'_j + offset carry digits
     uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
@@ -445,22 +507,25 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     }
     bprime = __builtin_amdgcn_readlane(bprime, 0);    // j = 1024 is handled by lane 0
 
-    uint4 res[kKsPieces];
+    // Lane L owns 16-byte pieces L and L + 64 (words 4 L .. 4 L + 3 and 256 + 4 L ..) and the 8-byte piece L behind them (words
+    // 512 + 2 L, 513 + 2 L): ten words, no lane idles on a third quad.
+    uint32_t res[10];
 #pragma unroll
-    for (int m = 0; m < kKsPieces; m++) res[m] = make_uint4(0, 0, 0, 0);
-    if (lane == 29) res[2].z = bprime;           // word 630 = 4 * (29 + 128) + 2 starts from b'
-    int off[kKsPieces];
-    off[0] = lane * 16; off[1] = (lane + 64) * 16; off[2] = (lane < 32 ? lane + 128 : 159) * 16;
-    // per-buffer, per-piece LDS addresses kept in VGPRs: a row is then "VGPR + immediate"
-    const char* pbase[kKsBuffers][kKsPieces];
+    for (int m = 0; m < 10; m++) res[m] = 0;
+    if (lane == 59) res[8] = bprime;             // word 630 = 512 + 2 * 59 starts from b'
+    // per-buffer LDS addresses of the three pieces kept in VGPRs: a row is then "VGPR + immediate"
+    uint32_t pbase[kKsBuffers][kKsPieces];
 #pragma unroll
-    for (int bi = 0; bi < kKsBuffers; bi++)
-#pragma unroll
-        for (int m = 0; m < kKsPieces; m++) pbase[bi][m] = smem + opaque(kKsLdsDigits + bi * kKsStepBytes + off[m]);
+    for (int bi = 0; bi < kKsBuffers; bi++) {
+        const uint32_t buf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + kKsLdsDigits + bi * kKsStepBytes);
+        pbase[bi][0] = buf + lane * 16;
+        pbase[bi][1] = buf + 1024 + lane * 16;
+        pbase[bi][2] = buf + 2048 + lane * 8;
+    }
 
     __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
     // one step j: counted wait + barrier, issue step j+2, apply the 8 digits of a'_j
-    auto step = [&](int j, const char* const (&pb)[kKsPieces]) {
+    auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
         // The pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight across the
         // barrier, only step j must have landed.  lgkmcnt(0): this wave has finished reading
         // step j-1, whose buffer step j+2 is about to overwrite.
@@ -471,26 +536,9 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         issue(j + 2);
         if (!live) return;                                    // wave-uniform: this wave only serves the table pipeline
         const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
-#pragma unroll
-        for (int k = 0; k < kKsT; k++) {
-            // field f = val + 2: 0 -> +row(v=2), 1 -> +row(v=1), 2 -> nothing, 3 -> -row(v=1)
-            // (requesting the rows of several digits before adding any -- fewer dependent LDS round trips per step -- was
-            // measured: 1.33 ms per 4096 either way, the step is not bound by them; profiles/r04_radix4_and_latency.md)
-            const uint32_t f = (dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1);
-            if (f != 2) {
-                const int roff = (k * kKsNumBase + (f == 0 ? 1 : 0)) * (kKsRowPad * 4);
-                uint4 r[kKsPieces];
-#pragma unroll
-                for (int m = 0; m < kKsPieces; m++) r[m] = *(const uint4*)(pb[m] + roff);
-                if (f == 3) {
-#pragma unroll
-                    for (int m = 0; m < kKsPieces; m++) { res[m].x -= r[m].x; res[m].y -= r[m].y; res[m].z -= r[m].z; res[m].w -= r[m].w; }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < kKsPieces; m++) { res[m].x += r[m].x; res[m].y += r[m].y; res[m].z += r[m].z; res[m].w += r[m].w; }
-                }
-            }
-        }
+        // the 8 digits of a'_j, most significant first (requesting the rows of several digits before adding any -- fewer dependent
+        // LDS round trips per step -- was measured: 1.33 ms per 4096 either way; profiles/r04_radix4_and_latency.md)
+        ks_digits<0>(dj, pb, res);
     };
     static_assert(kKsBuffers == 3, "the j loop is unrolled by the number of buffers");
 #pragma unroll 1
@@ -501,14 +549,13 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     }
     step(kN - 1, pbase[(kN - 1) % kKsBuffers]);   // 1024 = 3 * 341 + 1
     if (!live) return;
+    {
+        uint32_t* o = d.out;                                 // 4-byte aligned only (ciphertexts packed at 631 words)
 #pragma unroll
-    for (int m = 0; m < kKsPieces; m++) {
-        if (m == 2 && lane >= 32) break;
-        const int i = off[m] / 4;
-        if (i + 0 <= kLvl0N) d.out[i + 0] = res[m].x;
-        if (i + 1 <= kLvl0N) d.out[i + 1] = res[m].y;
-        if (i + 2 <= kLvl0N) d.out[i + 2] = res[m].z;
-        if (i + 3 <= kLvl0N) d.out[i + 3] = res[m].w;
+        for (int m = 0; m < 4; m++) { o[4 * lane + m] = res[m]; o[256 + 4 * lane + m] = res[4 + m]; }      // words 0 .. 511
+        const int i = 512 + 2 * lane;
+        if (i + 0 <= kLvl0N) o[i + 0] = res[8];
+        if (i + 1 <= kLvl0N) o[i + 1] = res[9];
     }
 }
 
