@@ -41,7 +41,7 @@ FAULT_OUT = os.path.join(HERE, "libcufhe_amd_diag_ll2_timeout.so")
 
 
 def build(force=False, verbose=False, diagnostic=None, extra=(), out=None):
-    """diagnostic: list of ablation switch names (NO_TW, NO_XPOSE, NO_BK, BK0, PHASES, LL2_TIMEOUT): a build whose
+    """diagnostic: list of ablation switch names (NO_TW, NO_XPOSE, NO_BK, BK0, PHASES, LL2_TIMEOUT, KS_NO_DMA, KS_NO_DIGITS): a build whose
     results are WRONG by design (timing experiments, fault injection); it goes to libcufhe_amd_diag.so (or `out`)
     and is never loaded by the package."""
     if diagnostic:

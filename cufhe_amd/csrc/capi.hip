@@ -103,15 +103,15 @@ int phys_device(int device)
 }
 long g_ks_split_threshold = -1; // key switches per launch up to which each ciphertext is split over 8 workgroups
 // Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, tools/ks_per_wg.py, MI355X, ms per launch of n key switches):
-//   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.66 (2048)
-//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.18 (1536)  1.38 (1792)  1.57 (2048)  3.10 (4096)
+//   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.68 (2048)
+//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.19 (1536)  1.61 (2048)  3.17 (4096)
 //   table through LDS, ceil(n / 256) ciphertexts per workgroup (one grid round, every CU busy):
-//                                 0.94 (256)  1.07 (512)  1.17 (1024)  1.23 (1536)  1.27 (2048)  1.39 (3072)  1.55 (4096)
-//     (16 per workgroup whatever the count: 1.53 - 1.59 for any n <= 4096)
-// so: split up to 192, one workgroup per ciphertext up to 1600, the shared-table kernel above -- on 256 CUs; in units of the
-// device's CU count: 3/4 and 25/4 ciphertexts per CU
+//                                 0.70 (256)  0.76 (512)  0.81 (1024)  0.84 (1536)  0.86 (2048)  0.93 (3072)  1.04 (4096)
+//     (16 per workgroup whatever the count: 1.01 - 1.04 for any n <= 4096)
+// so: split up to 192, one workgroup per ciphertext up to 1024, the shared-table kernel above -- on 256 CUs; in units of the
+// device's CU count: 3/4 and 4 ciphertexts per CU
 inline long ks_auto_split(int cus) { return 3L * std::max(1, cus) / 4; }
-inline long ks_auto_wg(int cus) { return 25L * std::max(1, cus) / 4; }
+inline long ks_auto_wg(int cus) { return 4L * std::max(1, cus); }
 long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16

@@ -389,9 +389,14 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 // walks j in lock-step; the 16 candidate rows of one j (t = 8 levels x 2 values, contiguous
 // 40 KiB in the padded device layout [j][k][v][640]) are copied ONCE into LDS by LDS-DMA,
 // two steps ahead (3 buffers), and every wave adds or subtracts the 8 rows its own digits
-// select (wave-uniform branch per digit, rows read with ds_read_b128).  L2 traffic drops 16x.
-// Lane L owns 16-byte pieces L, L+64 and (L < 32) L+128 of the 160-piece row, i.e. output
-// words 4*piece .. 4*piece+3.
+// select (wave-uniform choice per digit).  L2 traffic drops 16x.
+// Lane L owns 16-byte pieces L and L+64 and the 8-byte piece L behind them (words 4L..4L+3,
+// 256+4L.. and 512+2L, 513+2L): ten words, two ds_read_b128 and one ds_read_b64 per row.
+// What a launch of 4096 costs (1.04 ms; round 5: 1.33): the 16 waves read 6 of their 8 rows
+// per step, 245 KB out of LDS per step and CU -- 0.8 ms at 128 bytes per cycle -- next to the
+// 40 KiB the DMA writes into it; the table pipeline alone (no digits) takes 0.40 ms, the
+// digits without it 1.0 ms (diagnostic builds KS_NO_DIGITS / KS_NO_DMA, tools/ks_floor.py,
+// profiles/r06_keyswitch.md).
 // ----------------------------------------------------------------------------------
 constexpr int kKsWaves = 16;
 constexpr int kKsThreads = 64 * kKsWaves;                        // 1024
@@ -404,17 +409,20 @@ constexpr int kKsLdsBytes = kKsLdsDigits + kKsBuffers * kKsStepBytes;   // 15564
 
 // One digit of one key-switch step on one wave: f = val + 2 (wave-uniform, in an SGPR) selects +row(v=2) [f 0], +row(v=1) [f 1],
 // nothing [f 2] or -row(v=1) [f 3]; the row lies at a compile-time offset from the lane's three LDS addresses and is added to the
-// lane's ten sums IN PLACE.  The three-way choice is spelled as scalar branches INSIDE two asm blocks (the loads, then the ten
-// additions or subtractions), so that the compiler sees straight-line code: written as `if (f == 3) res -= r; else res += r;` the
-// structurised control flow gave every arm fresh result registers and copied them back (6 v_mov_b64 per digit) and the row offset
-// went through a VGPR (3 v_add per digit) -- 21 vector instructions per digit where 10 do the work (profiles/r06_keyswitch.md).
+// lane's ten sums IN PLACE.  The three-way choice is spelled as scalar branches INSIDE asm blocks, so that the compiler sees
+// straight-line code: written as `if (f == 3) res -= r; else res += r;` the structurised control flow gave every arm fresh result
+// registers and copied them back (6 v_mov_b64 per digit) and the row offset went through a VGPR (3 v_add per digit) -- 21 vector
+// instructions per digit where 10 do the work.  And the rows of ALL digits of a step are requested before the first is added (one
+// wait): waited for one by one they are a chain of eight dependent LDS round trips per step, which with the scalar branching around
+// them was what a step took (0.75 us even for a single ciphertext per workgroup; the table pipeline alone: 0.2 us).
+// profiles/r06_keyswitch.md
 typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ks_u32x2 __attribute__((ext_vector_type(2)));
+struct KsRow { ks_u32x4 a, b; ks_u32x2 c; };
+// ... the loads: issued, NOT waited for
 template <int ROW1, int ROW2>
-__device__ __forceinline__ void ks_digit(const uint32_t f, const uint32_t a0, const uint32_t a1, const uint32_t a2, uint32_t (&res)[10])
+__device__ __forceinline__ void ks_digit_load(const uint32_t f, const uint32_t a0, const uint32_t a1, const uint32_t a2, KsRow& r)
 {
-    ks_u32x4 r0, r1;
-    ks_u32x2 r2;
     asm volatile(
         "s_cmp_eq_u32 %3, 2\n\t"
         "s_cbranch_scc1 .Lks_ld_end_%=\n\t"
@@ -423,17 +431,21 @@ __device__ __forceinline__ void ks_digit(const uint32_t f, const uint32_t a0, co
         "ds_read_b128 %0, %4 offset:%7\n\t"
         "ds_read_b128 %1, %5 offset:%7\n\t"
         "ds_read_b64 %2, %6 offset:%7\n\t"
-        "s_branch .Lks_ld_wait_%=\n"
+        "s_branch .Lks_ld_end_%=\n"
         ".Lks_ld_two_%=:\n\t"
         "ds_read_b128 %0, %4 offset:%8\n\t"
         "ds_read_b128 %1, %5 offset:%8\n\t"
         "ds_read_b64 %2, %6 offset:%8\n"
-        ".Lks_ld_wait_%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n"
         ".Lks_ld_end_%=:"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+        : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c)
         : "s"(f), "v"(a0), "v"(a1), "v"(a2), "n"(ROW1), "n"(ROW2)
         : "memory", "scc");
+}
+// ... the ten additions or subtractions.  (Without a branch for the sign -- res += row ^ s through v_xad_u32, s = 0 or ~0, the
+// subtractions counted in the prologue and added to every word at the end -- a launch of up to 1024 ciphertexts is 7 % faster and
+// one of 4096 is 4 % slower: profiles/r06_keyswitch_xad_experiment.patch.)
+__device__ __forceinline__ void ks_digit_acc(const uint32_t f, const KsRow& r, uint32_t (&res)[10])
+{
 #define CUFHE_AMD_KS_TEN(OP)                                                                                               \
     OP " %0, %0, %11\n\t" OP " %1, %1, %12\n\t" OP " %2, %2, %13\n\t" OP " %3, %3, %14\n\t" OP " %4, %4, %15\n\t"             \
     OP " %5, %5, %16\n\t" OP " %6, %6, %17\n\t" OP " %7, %7, %18\n\t" OP " %8, %8, %19\n\t" OP " %9, %9, %20\n"
@@ -448,19 +460,30 @@ __device__ __forceinline__ void ks_digit(const uint32_t f, const uint32_t a0, co
         CUFHE_AMD_KS_TEN("v_sub_u32_e32")
         ".Lks_acc_end_%=:"
         : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9])
-        : "s"(f), "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w), "v"(r2.x), "v"(r2.y)
+        : "s"(f), "v"(r.a.x), "v"(r.a.y), "v"(r.a.z), "v"(r.a.w), "v"(r.b.x), "v"(r.b.y), "v"(r.b.z), "v"(r.b.w), "v"(r.c.x), "v"(r.c.y)
         : "scc");
 #undef CUFHE_AMD_KS_TEN
 }
-
-template <int K>
-__device__ __forceinline__ void ks_digits(const uint32_t dj, const uint32_t (&pb)[3], uint32_t (&res)[10])
+template <int I, int N, class F>
+__device__ __forceinline__ void ks_for(F&& f)
 {
-    if constexpr (K < kKsT) {
-        const uint32_t f = (dj >> (16 - (K + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1);
-        ks_digit<(K * kKsNumBase) * (kKsRowPad * 4), (K * kKsNumBase + 1) * (kKsRowPad * 4)>(f, pb[0], pb[1], pb[2], res);
-        ks_digits<K + 1>(dj, pb, res);
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ks_for<I + 1, N>(f);
     }
+}
+// the 8 digits of a'_j (dj: its 16 digit bits, most significant digit first): all rows requested (not waited for) / all additions
+__device__ __forceinline__ uint32_t ks_field(const uint32_t dj, const int k) { return (dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1); }
+__device__ __forceinline__ void ks_load_all(const uint32_t dj, const uint32_t (&pb)[3], KsRow (&r)[kKsT])
+{
+    ks_for<0, kKsT>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        ks_digit_load<(K * kKsNumBase) * (kKsRowPad * 4), (K * kKsNumBase + 1) * (kKsRowPad * 4)>(ks_field(dj, K), pb[0], pb[1], pb[2], r[K]);
+    });
+}
+__device__ __forceinline__ void ks_acc_all(const uint32_t dj, const KsRow (&r)[kKsT], uint32_t (&res)[10])
+{
+    ks_for<0, kKsT>([&](auto kc) { ks_digit_acc(ks_field(dj, decltype(kc)::value), r[decltype(kc)::value], res); });
 }
 
 // per_wg (1..16): ciphertexts per workgroup.  Waves at and above per_wg only move table pieces and keep the barriers: a
@@ -488,7 +511,9 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         for (int c = 0; c < 3; c++) {
             const int piece = wave < 8 ? 3 * wave + c : 24 + 2 * (wave - 8) + c;
             if (c == 2 && wave >= 8) break;
+#if !(defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DMA))
             lds_dma16(src + piece * 1024, dst + piece * 1024);
+#endif
         }
     };
     issue(0);
@@ -524,8 +549,11 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     }
 
     __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
-    // one step j: counted wait + barrier, issue step j+2, apply the 8 digits of a'_j
-    auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
+    // One step j: counted wait + barrier, issue step j+2, apply the 8 digits of a'_j.  The waves of a SIMD (wave w runs on SIMD w % 4)
+    // come out of the barrier together and would all request rows (scalar and LDS work), then all wait, then all add (vector
+    // work), one pipe busy at a time.  So every second wave of a SIMD runs one phase behind: it requests the rows of step j at the
+    // END of the step's interval and adds them at the start of the next one, while its neighbours request theirs.
+    auto wait_and_issue = [&](int j) {
         // The pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight across the
         // barrier, only step j must have landed.  lgkmcnt(0): this wave has finished reading
         // step j-1, whose buffer step j+2 is about to overwrite.
@@ -534,20 +562,51 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         issue(j + 2);
-        if (!live) return;                                    // wave-uniform: this wave only serves the table pipeline
-        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
-        // the 8 digits of a'_j, most significant first (requesting the rows of several digits before adding any -- fewer dependent
-        // LDS round trips per step -- was measured: 1.33 ms per 4096 either way; profiles/r04_radix4_and_latency.md)
-        ks_digits<0>(dj, pb, res);
     };
-    static_assert(kKsBuffers == 3, "the j loop is unrolled by the number of buffers");
+    static_assert(kKsBuffers == 3, "the j loops are unrolled by the number of buffers");
+    KsRow r[kKsT];
+    // (with at most two live waves per SIMD -- per_wg <= 8 -- the shift costs more than it hides: 0.90 against 0.86 ms per 2048)
+    if (per_wg <= 8 || !((wave >> 2) & 1)) {
+        auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
+            wait_and_issue(j);
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
+            return;                                               // timing only: the table pipeline without the digits
+#endif
+            if (!live) return;                                    // wave-uniform: this wave only serves the table pipeline
+            const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+            ks_load_all(dj, pb, r);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ks_acc_all(dj, r, res);
+        };
 #pragma unroll 1
-    for (int j = 0; j + 2 < kN; j += 3) {
-        step(j, pbase[0]);
-        step(j + 1, pbase[1]);
-        step(j + 2, pbase[2]);
+        for (int j = 0; j + 2 < kN; j += 3) {
+            step(j, pbase[0]);
+            step(j + 1, pbase[1]);
+            step(j + 2, pbase[2]);
+        }
+        step(kN - 1, pbase[(kN - 1) % kKsBuffers]);   // 1024 = 3 * 341 + 1
+    } else {
+        auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
+            wait_and_issue(j);                                    // its lgkmcnt(0): the rows of step j-1 are in r
+#if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
+            return;                                               // timing only: the table pipeline without the digits
+#endif
+            if (!live) return;
+            if (j > 0) ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[j - 1]), r, res);
+            ks_load_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[j]), pb, r);
+        };
+#pragma unroll 1
+        for (int j = 0; j + 2 < kN; j += 3) {
+            step(j, pbase[0]);
+            step(j + 1, pbase[1]);
+            step(j + 2, pbase[2]);
+        }
+        step(kN - 1, pbase[(kN - 1) % kKsBuffers]);
+        if (live) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[kN - 1]), r, res);
+        }
     }
-    step(kN - 1, pbase[(kN - 1) % kKsBuffers]);   // 1024 = 3 * 341 + 1
     if (!live) return;
     {
         uint32_t* o = d.out;                                 // 4-byte aligned only (ciphertexts packed at 631 words)

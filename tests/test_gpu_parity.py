@@ -142,6 +142,39 @@ def test_keyswitch_words(engine, keys, oracle, br_kernel):
         assert np.array_equal(got[g], want)
 
 
+@pytest.mark.parametrize("count", [1, 2, 3, 33, 257, 1031])
+def test_keyswitch_shared_table_groupings(engine, keys, oracle, count):
+    """The shared-table key switch (the ciphertexts of a workgroup share each step of the key through LDS, a wave per ciphertext):
+    odd counts, a last workgroup that is not full, the largest and the smallest number of ciphertexts per workgroup -- every word
+    equal to the workgroup-per-ciphertext kernel's, first and last ciphertext equal to the oracle's."""
+    rng = np.random.default_rng(4100 + count)
+    t1 = rng.integers(0, 2**32, size=(count, ol.N + 1), dtype=np.uint64).astype(np.uint32)
+    t1[0, : ol.N] = 0xFFFFFFFF
+    d1 = _upload(engine, t1)
+    d0 = engine.api.DeviceBuffer(count * (ol.n + 1))
+
+    def run(split, wg, per):
+        engine.api.set_option("ks_split_threshold", split)
+        engine.api.set_option("ks_wg_threshold", wg)
+        engine.api.set_option("ks_per_wg", per)
+        try:
+            d0.upload(np.full(count * (ol.n + 1), 0xDEADBEEF, np.uint32))
+            engine.keyswitch_batch(d1, d0, count)
+            return d0.download().reshape(count, ol.n + 1).copy()
+        finally:
+            for k in ("ks_split_threshold", "ks_wg_threshold", "ks_per_wg"):
+                engine.api.set_option(k, -1)
+
+    ref = run(0, 1 << 30, -1)                      # one workgroup per ciphertext
+    for g in (0, count - 1):
+        want = np.zeros(ol.n + 1, np.uint32)
+        oracle.orc_keyswitch(keys.ek, want, np.ascontiguousarray(t1[g]))
+        assert np.array_equal(ref[g], want)
+    for per in (-1, 1, 6, 16):
+        got = run(0, 0, per)
+        assert np.array_equal(got, ref), f"shared-table key switch, {count} ciphertexts, {per} per workgroup"
+
+
 @pytest.mark.parametrize("level", [0, 1])
 def test_every_gate_words_and_truth_table(engine, keys, oracle, level, br_kernel):
     """All 14 ops on all input combinations: words == oracle, decrypt == truth table."""
