@@ -102,26 +102,47 @@ int phys_device(int device)
     return device + g_device_base;
 }
 long g_ks_split_threshold = -1; // key switches per launch up to which each ciphertext is split over 8 workgroups
-// Key switch launch shape, -1 = the measured rule (tools/ks_sweep.py, tools/ks_per_wg.py, MI355X, ms per launch of n key switches):
-//   8 workgroups per ciphertext   0.047 (n <= 32)  0.13 (128)  0.19 (192)  0.24 (256)  0.45 (512)  0.85 (1024)  1.68 (2048)
-//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.19 (1536)  1.61 (2048)  3.17 (4096)
-//   table through LDS, ceil(n / 256) ciphertexts per workgroup (one grid round, every CU busy):
-//                                 0.70 (256)  0.76 (512)  0.81 (1024)  0.84 (1536)  0.86 (2048)  0.93 (3072)  1.04 (4096)
-//     (16 per workgroup whatever the count: 1.01 - 1.04 for any n <= 4096)
-// so: split up to 192, one workgroup per ciphertext up to 1024, the shared-table kernel above -- on 256 CUs; in units of the
-// device's CU count: 3/4 and 4 ciphertexts per CU
-inline long ks_auto_split(int cus) { return 3L * std::max(1, cus) / 4; }
-inline long ks_auto_wg(int cus) { return 4L * std::max(1, cus); }
+// Key switch launch shape, -1 = the measured rule (tools/ks_slices.py, MI355X, ms per launch of n key switches):
+//   8 workgroups per ciphertext   0.046 (n = 1)  0.049 (16)  0.051 (32)  0.078 (64)  0.13 (128)  0.24 (256)  0.45 (512)  0.85 (1024)
+//   a workgroup per ciphertext    0.22 (n <= 256)  0.42 (512)  0.80 (1024)  1.19 (1536)  1.63 (2048)  3.3 (4096)
+//   table through LDS (keyswitch_kernel), 16 ciphertexts per workgroup and the steps of j cut into runs that fill the CUs:
+//                                 0.040 (1)  0.052 (16)  0.059 (32)  0.070 (64)  0.084 (128)  0.12 (256)  0.19 (512)  0.32 (1024)
+//                                 0.56 (1536)  0.58 (2048)  0.86 (3072)  1.04 - 1.09 (4096)
+// so: split up to 32, the shared-table kernel above -- on 256 CUs; in units of the device's CU count: 1/8 ciphertext per CU.
+// The workgroup-per-ciphertext kernel is no longer chosen by the rule ("ks_wg_threshold" still forces it).
+inline long ks_auto_split(int cus) { return std::max(1, cus) / 8; }
+inline long ks_auto_wg(int) { return 0; }
 long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kernel: -1 by cost, 0 never, > 0 for launches up to this size
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16
-int ks_auto_per_wg(size_t count, int cus)
+long g_ks_slices = -1;          // runs the shared-table key switch cuts j into: -1 by count, else a power of two 1..64
+// The shape of a shared-table launch (keyswitch_kernel: per_wg ciphertexts per workgroup, the 1024 steps of j cut into `slices` runs):
+// the cheapest by a model of the measured times -- a workgroup of 16 live waves takes 1.03 us per step (0.68 + 0.022 per live wave),
+// 12 us around its steps; the workgroups run in rounds of one per CU (hipDeviceProp_t::multiProcessorCount, cached in
+// DeviceState); a launch with runs zeroes the outputs first.  4096 ciphertexts: 256 workgroups x 1024 steps; 3072: 768 x 256 (three
+// rounds); 2048: 256 x 512; 256: 256 x 64.
+void ks_auto_shape(size_t count, int cus, int* per_wg, int* slices)
 {
-    // one grid round -- a workgroup per CU (256 on MI355X; hipDeviceProp_t::multiProcessorCount, cached in DeviceState) --
-    // with the fewest ciphertexts each
     const size_t c = cus > 0 ? (size_t)cus : 256;
-    const size_t p = (count + c - 1) / c;
-    return (int)(p < 1 ? 1 : p > 16 ? 16 : p);
+    if (g_ks_slices > 0 || g_ks_per_wg > 0) {            // forced (tests, sweeps): the other one by the round-5 rule
+        const size_t p = (count + c - 1) / c;
+        *per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : (int)(p < 1 ? 1 : p > 16 ? 16 : p);
+        *slices = g_ks_slices > 0 ? (int)g_ks_slices : 1;
+        return;
+    }
+    auto cost = [&](int p, int sl) {                      // us
+        const size_t wgs = (count + p - 1) / p * sl, rounds = (wgs + c - 1) / c;
+        return rounds * (kN / sl * (0.68 + 0.022 * p) + 12.0) + (sl > 1 ? 20.0 : 15.0);
+    };
+    const size_t fit = (count + c - 1) / c;               // fewest ciphertexts per workgroup that still fit one round
+    int best_p = (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit), best_sl = 1;
+    double best = cost(best_p, 1);
+    for (int sl = 1; sl <= 64; sl *= 2) {
+        const double t = cost(kKsWaves, sl);
+        if (t < best) { best = t; best_p = kKsWaves; best_sl = sl; }
+    }
+    *per_wg = best_p;
+    *slices = best_sl;
 }
 long g_ll_threshold = -1;      // rotations per launch up to which the 16-wave split-transform kernel is used; -1: by measured cost (below)
 long g_half_threshold = -1;    // ... up to which the batch kernel runs one rotation per SIMD (4 per workgroup); -1: by measured cost
@@ -643,6 +664,20 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     }
     return 0;
 }
+// keyswitch_kernel over `ksk_padded` (the default set's table, or that of a parameter set with the same key-switch shape)
+int launch_keyswitch_shared(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count, const uint32_t* ksk_padded)
+{
+    if (!s.ks_lds_opt_in) {
+        HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
+        s.ks_lds_opt_in = true;
+    }
+    int per_wg, slices;
+    ks_auto_shape(count, cus_of(s), &per_wg, &slices);
+    if (slices > 1) hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
+    const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg) * (unsigned)slices;
+    hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, ksk_padded, per_wg, slices);
+    return 0;
+}
 int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count)
 {
     if (count == 0) return 0;
@@ -652,10 +687,6 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    if (!s.ks_lds_opt_in) {
-        HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
-        s.ks_lds_opt_in = true;
-    }
     const long split_max = g_ks_split_threshold < 0 ? ks_auto_split(cus_of(s)) : g_ks_split_threshold;
     const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(cus_of(s)) : g_ks_wg_threshold;
     if ((long)count <= split_max) {
@@ -664,10 +695,7 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
     } else if ((long)count <= wg_max) {
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
-        // as few ciphertexts per workgroup as still fit one grid round of 256 workgroups (g_ks_per_wg: -1 by count, else 1..16)
-        const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, cus_of(s));
-        const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg);
-        hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, s.ksk, per_wg);
+        if (int rc = launch_keyswitch_shared(s, st, d, count, s.ksk)) return rc;
     }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {
@@ -1525,6 +1553,11 @@ int cufhe_amd_set_option(const char* key, long value)
             if (int rc = sched_synchronize_all()) return rc;
         }
         g_param_set = value;
+        return 0;
+    }
+    if (!strcmp(key, "ks_slices")) {
+        if (value != -1 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(-1, "ks_slices must be -1 or a power of two 1..64");
+        g_ks_slices = value;
         return 0;
     }
     if (!strcmp(key, "ks_per_wg")) {

@@ -487,26 +487,32 @@ __device__ __forceinline__ void ks_acc_all(const uint32_t dj, const KsRow (&r)[k
 }
 
 // per_wg (1..16): ciphertexts per workgroup.  Waves at and above per_wg only move table pieces and keep the barriers: a
-// launch of fewer than 4096 ciphertexts then still covers every CU, and a step carries fewer row reads and additions
-// (2048 ciphertexts: 1.27 ms with 8 per workgroup against 1.53 with 16).
+// launch of fewer than 4096 ciphertexts then still covers every CU, and a step carries fewer row reads and additions.
+// slices (a power of two, 1..64): the 1024 steps of j are cut into `slices` runs and workgroup i takes run i % slices for the
+// ciphertexts of group i / slices (workgroups of one XCD -- i % 8 -- then walk the same part of the table).  With slices > 1 the
+// partial sums are added into d.out with atomics, which keyswitch_split_zero_kernel has zeroed before: a launch of 2048 ciphertexts
+// is then 128 groups x 2 runs of 512 steps with all 16 waves live instead of 256 workgroups x 1024 steps with 8, one of 256 is
+// 16 groups x 16 runs of 64 steps (profiles/r06_keyswitch.md).
 __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
-    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded, int per_wg)
+    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded, int per_wg, int slices)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    int g = blockIdx.x * per_wg + wave;
+    const int slice = blockIdx.x % slices;
+    const int steps = kN / slices, j_lo = slice * steps;       // this workgroup's run of j: [j_lo, j_lo + steps); t below = j - j_lo
+    int g = (blockIdx.x / slices) * per_wg + wave;
     const bool live = wave < per_wg && g < count;
     if (!live) g = count - 1;
     const LinDesc d = descs[g];
     uint16_t* dig = (uint16_t*)smem + wave * kN;
     char* bufs = smem + kKsLdsDigits;
 
-    // LDS-DMA of step j: 40 pieces of 1 KiB; waves 0-7 move 3, waves 8-15 move 2
-    auto issue = [&](int j) {
-        if (j >= kN) return;
-        const char* src = (const char*)ksk_padded + (size_t)j * kKsStepBytes + lane * 16;
-        char* dst = bufs + (j % kKsBuffers) * kKsStepBytes;
+    // LDS-DMA of step t: 40 pieces of 1 KiB; waves 0-7 move 3, waves 8-15 move 2
+    auto issue = [&](int t) {
+        if (t >= steps) return;
+        const char* src = (const char*)ksk_padded + (size_t)(j_lo + t) * kKsStepBytes + lane * 16;
+        char* dst = bufs + (t % kKsBuffers) * kKsStepBytes;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int piece = wave < 8 ? 3 * wave + c : 24 + 2 * (wave - 8) + c;
@@ -519,25 +525,23 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     issue(0);
     issue(1);
 
-
     // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98; only the top
     // t*basebit = 16 bits of a'_j + offset carry digits
     uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
     for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
-    uint32_t bprime = 0;
-    for (int j = lane; j < kLvl1Words; j += 64) {
-        uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
-        if (j == kN) bprime = v + d.off;
-        else dig[j] = (uint16_t)((v + koff) >> 16);
+    for (int t = lane; t < steps; t += 64) {
+        const uint32_t v = (uint32_t)d.ca * d.in0[j_lo + t] + (uint32_t)d.cb * d.in1[j_lo + t];
+        dig[t] = (uint16_t)((v + koff) >> 16);
     }
-    bprime = __builtin_amdgcn_readlane(bprime, 0);    // j = 1024 is handled by lane 0
+    // b' = ca in0[1024] + cb in1[1024] + off: the start of word 630, in the first run only
+    const uint32_t bprime = slice == 0 ? (uint32_t)d.ca * d.in0[kN] + (uint32_t)d.cb * d.in1[kN] + d.off : 0u;
 
     // Lane L owns 16-byte pieces L and L + 64 (words 4 L .. 4 L + 3 and 256 + 4 L ..) and the 8-byte piece L behind them (words
     // 512 + 2 L, 513 + 2 L): ten words, no lane idles on a third quad.
     uint32_t res[10];
 #pragma unroll
     for (int m = 0; m < 10; m++) res[m] = 0;
-    if (lane == 59) res[8] = bprime;             // word 630 = 512 + 2 * 59 starts from b'
+    if (lane == 59) res[8] = bprime;             // word 630 = 512 + 2 * 59
     // per-buffer LDS addresses of the three pieces kept in VGPRs: a row is then "VGPR + immediate"
     uint32_t pbase[kKsBuffers][kKsPieces];
 #pragma unroll
@@ -549,72 +553,80 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
     }
 
     __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
-    // One step j: counted wait + barrier, issue step j+2, apply the 8 digits of a'_j.  The waves of a SIMD (wave w runs on SIMD w % 4)
+    // One step t: counted wait + barrier, issue step t+2, apply the 8 digits of a'_j.  The waves of a SIMD (wave w runs on SIMD w % 4)
     // come out of the barrier together and would all request rows (scalar and LDS work), then all wait, then all add (vector
-    // work), one pipe busy at a time.  So every second wave of a SIMD runs one phase behind: it requests the rows of step j at the
+    // work), one pipe busy at a time.  So every second wave of a SIMD runs one phase behind: it requests the rows of step t at the
     // END of the step's interval and adds them at the start of the next one, while its neighbours request theirs.
-    auto wait_and_issue = [&](int j) {
-        // The pieces of step j+1 (this wave's newest 3 or 2 DMAs) stay in flight across the
-        // barrier, only step j must have landed.  lgkmcnt(0): this wave has finished reading
-        // step j-1, whose buffer step j+2 is about to overwrite.
-        if (j + 1 >= kN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    auto wait_and_issue = [&](int t) {
+        // The pieces of step t+1 (this wave's newest 3 or 2 DMAs) stay in flight across the
+        // barrier, only step t must have landed.  lgkmcnt(0): this wave has finished reading
+        // step t-1, whose buffer step t+2 is about to overwrite.
+        if (t + 1 >= steps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if (wave < 8) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        issue(j + 2);
+        issue(t + 2);
     };
-    static_assert(kKsBuffers == 3, "the j loops are unrolled by the number of buffers");
+    static_assert(kKsBuffers == 3, "the loops over t are unrolled by the number of buffers");
+    const int whole = steps - steps % 3;       // steps is a power of two: one or two steps follow the unrolled loop
     KsRow r[kKsT];
     // (with at most two live waves per SIMD -- per_wg <= 8 -- the shift costs more than it hides: 0.90 against 0.86 ms per 2048)
     if (per_wg <= 8 || !((wave >> 2) & 1)) {
-        auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
-            wait_and_issue(j);
+        auto step = [&](int t, const uint32_t (&pb)[kKsPieces]) {
+            wait_and_issue(t);
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
             return;                                               // timing only: the table pipeline without the digits
 #endif
             if (!live) return;                                    // wave-uniform: this wave only serves the table pipeline
-            const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
+            const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[t]);
             ks_load_all(dj, pb, r);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ks_acc_all(dj, r, res);
         };
 #pragma unroll 1
-        for (int j = 0; j + 2 < kN; j += 3) {
-            step(j, pbase[0]);
-            step(j + 1, pbase[1]);
-            step(j + 2, pbase[2]);
+        for (int t = 0; t < whole; t += 3) {
+            step(t, pbase[0]);
+            step(t + 1, pbase[1]);
+            step(t + 2, pbase[2]);
         }
-        step(kN - 1, pbase[(kN - 1) % kKsBuffers]);   // 1024 = 3 * 341 + 1
+        step(whole, pbase[0]);
+        if (whole + 1 < steps) step(whole + 1, pbase[1]);
     } else {
-        auto step = [&](int j, const uint32_t (&pb)[kKsPieces]) {
-            wait_and_issue(j);                                    // its lgkmcnt(0): the rows of step j-1 are in r
+        auto step = [&](int t, const uint32_t (&pb)[kKsPieces]) {
+            wait_and_issue(t);                                    // its lgkmcnt(0): the rows of step t-1 are in r
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
             return;                                               // timing only: the table pipeline without the digits
 #endif
             if (!live) return;
-            if (j > 0) ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[j - 1]), r, res);
-            ks_load_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[j]), pb, r);
+            if (t > 0) ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[t - 1]), r, res);
+            ks_load_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[t]), pb, r);
         };
 #pragma unroll 1
-        for (int j = 0; j + 2 < kN; j += 3) {
-            step(j, pbase[0]);
-            step(j + 1, pbase[1]);
-            step(j + 2, pbase[2]);
+        for (int t = 0; t < whole; t += 3) {
+            step(t, pbase[0]);
+            step(t + 1, pbase[1]);
+            step(t + 2, pbase[2]);
         }
-        step(kN - 1, pbase[(kN - 1) % kKsBuffers]);
+        step(whole, pbase[0]);
+        if (whole + 1 < steps) step(whole + 1, pbase[1]);
         if (live) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[kN - 1]), r, res);
+            ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[steps - 1]), r, res);
         }
     }
     if (!live) return;
-    {
-        uint32_t* o = d.out;                                 // 4-byte aligned only (ciphertexts packed at 631 words)
+    uint32_t* o = d.out;                                     // 4-byte aligned only (ciphertexts packed at 631 words)
+    const int i = 512 + 2 * lane;
+    if (slices == 1) {
 #pragma unroll
         for (int m = 0; m < 4; m++) { o[4 * lane + m] = res[m]; o[256 + 4 * lane + m] = res[4 + m]; }      // words 0 .. 511
-        const int i = 512 + 2 * lane;
         if (i + 0 <= kLvl0N) o[i + 0] = res[8];
         if (i + 1 <= kLvl0N) o[i + 1] = res[9];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) { atomicAdd(&o[4 * lane + m], res[m]); atomicAdd(&o[256 + 4 * lane + m], res[4 + m]); }
+        if (i + 0 <= kLvl0N) atomicAdd(&o[i + 0], res[8]);
+        if (i + 1 <= kLvl0N) atomicAdd(&o[i + 1], res[9]);
     }
 }
 

@@ -32,18 +32,15 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
     if (count == 0) return 0;
     EventPair ev{};
     if (int rc = prof_begin(s, st, ev)) return rc;
-    const long wg_max = g_ks_wg_threshold < 0 ? ks_auto_wg(cus_of(s)) : g_ks_wg_threshold;
+    // a set with the default key-switch shape takes keyswitch_kernel, which cuts j into runs and wins at any count; the
+    // whole-sweep kernel written over PS only above 25/4 ciphertexts per CU (the round-5 rule: 1600 on 256 CUs)
+    const long wg_auto = ps_ks_is_default_shape<PS> ? 0 : 25L * std::max(1, cus_of(s)) / 4;
+    const long wg_max = g_ks_wg_threshold < 0 ? wg_auto : g_ks_wg_threshold;
     if ((long)count > wg_max && ps.ksk_padded) {
         // 16 ciphertexts per workgroup, table rows through LDS
         const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
         if constexpr (ps_ks_is_default_shape<PS>) {
-            if (!s.ks_lds_opt_in) {
-                HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
-                s.ks_lds_opt_in = true;
-            }
-            const int per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : ks_auto_per_wg(count, cus_of(s));
-            hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count,
-                               ps.ksk_padded, per_wg);
+            if (int rc = launch_keyswitch_shared(s, st, d, count, ps.ksk_padded)) return rc;
         } else {
             if (!ps.ks_lds_opt_in) {
                 HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_ps_shared_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsKs<PS>::lds_bytes));

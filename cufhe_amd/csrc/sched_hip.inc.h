@@ -135,8 +135,8 @@ class HipBackend : public sched::Backend {
         return keep(::run_gates(device_, (void*)st, level, n, [&](size_t i) { return g[i]; }));
     }
     // Two lanes: measured on MI355X with both lanes running (tools/two_lane_probe.py, profiles/r06_two_lane_probe.txt) -- a step of the
-    // paired low-latency kernel on half of the CUs, key switch included, 5.15 ms beside the bulk lane (4.66 alone); a chunk of the batch
-    // kernel on the other half 19.9 ms (18.3 alone).  Half of the CUs each: an in-order stream then never has more workgroups in flight
+    // paired low-latency kernel on half of the CUs, key switch included, 4.80 ms beside the bulk lane (4.59 alone); a chunk of the batch
+    // kernel on the other half 18.6 ms (17.9 alone).  Half of the CUs each: an in-order stream then never has more workgroups in flight
     // than the other lane leaves free, so neither lane ever queues behind the other (full-width chunks beside the chain: 132 ms
     // against 79).  Only for the hand-scheduled BASELINE path: the parameter-set and N = 2048 paths pick their own shapes.
     bool lane_model(LaneModel* m) override
@@ -146,8 +146,8 @@ class HipBackend : public sched::Backend {
         if (cus < 16) return false;
         m->chain_gates = 2 * (cus / 2);
         m->bulk_gates = (size_t)kBrWavesPerBlock * (cus / 2);
-        m->chain_ms = 5.15;
-        m->bulk_ms = 19.9;
+        m->chain_ms = 4.80;
+        m->bulk_ms = 18.6;
         return true;
     }
     // one dependence level of n rotations by the rules of launch_blind_rotate, key switch and launch gaps included (MI355X, ms)
@@ -156,13 +156,13 @@ class HipBackend : public sched::Backend {
         if (n == 0) return 0.0;
         const size_t c = std::max<size_t>(1, round_gates() / kBrWavesPerBlock), round = (size_t)kBrWavesPerBlock * c;
         auto small = [&](size_t t) {
-            if (t <= c) return 3.45;
-            if (t > 6 * c) return 19.3;
+            if (t <= c) return 3.1;
+            if (t > 6 * c) return 18.2;
             const size_t rem = t % (2 * c), paired = (rem == 0 || rem > c) ? t : t - rem;
-            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.7 + (paired < t ? 3.45 : 0.0);
+            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.0 + (paired < t ? 2.9 : 0.0);
         };
         const size_t full = n / round, tail = n % round;
-        return (double)full * 18.7 + (tail ? small(tail) : 0.0);
+        return (double)full * 18.25 + (tail ? small(tail) : 0.0);      // tools/tail_times.py, gpurun_out/r06_tail_times_ks.txt
     }
     int gate_weight(int op) override { return op == CUFHE_AMD_MUX || op == CUFHE_AMD_NMUX ? 2 : op == CUFHE_AMD_NOT || op == CUFHE_AMD_COPY ? 0 : 1; }
     int run_gates_lane(int s, int level, const sched::GateRef* g, size_t n, int lane) override

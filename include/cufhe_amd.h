@@ -252,12 +252,13 @@ int cufhe_amd_polymul512_batch(int device, void* stream, size_t count, const int
  * launch up to n) governs the paired form; "ll_threshold" / "half_threshold" (default -1 = by cost) force the single
  * form / the batch kernel with one rotation per SIMD up to the given count, "tail_split" 0 launches everything above
  * one round as one grid.
- * "ks_wg_threshold" / "ks_split_threshold" (default -1 = by measured cost: 1024 / 192 on 256 CUs): the same choice
- * for the key switch -- up to ks_split_threshold ciphertexts each is split over 8 workgroups (0.05 ms
- * up to 32, 0.19 ms at 192), up to ks_wg_threshold one workgroup per ciphertext (0.22 ms up to 256,
- * 0.8 ms at 1024), above that the ciphertexts of a workgroup share each step of the key in LDS:
- * "ks_per_wg" (default -1 = ceil(count / 256), i.e. one grid round with the fewest ciphertexts per
- * workgroup; 1..16 forces it): 0.86 ms for 2048, 1.04 ms for 4096.  All variants produce identical words.
+ * "ks_split_threshold" (default -1 = by measured cost: 32 on 256 CUs): up to that many ciphertexts per launch each key
+ * switch is split over 8 workgroups (0.05 ms); above, the ciphertexts of a workgroup share each step of the key in LDS
+ * (keyswitch_kernel): "ks_per_wg" ciphertexts per workgroup (1..16) and the 1024 steps of j cut into "ks_slices" runs (a
+ * power of two up to 64, partial sums meeting in the output through atomics), both -1 = the cheapest shape by a model of
+ * the measured times: 0.07 ms for 64, 0.12 for 256, 0.31 for 1024, 0.57 for 2048, 0.86 for 3072, 1.04 ms for 4096.
+ * "ks_wg_threshold" (default -1 = never) forces one workgroup per ciphertext up to the given count (0.22 ms up to 256,
+ * 0.8 ms at 1024).  All variants produce identical words.
  * "ps_batch_threshold" (default -1 = by cost: 1025, 1281 for N = 512, 1537 for sets with key limbs): rotations per launch from which the parameter-set path
  * (cufhe_amd_ps_*) uses the wave-per-rotation kernel instead of a workgroup per rotation.
  * "lvl0_ring": 1024 (default) or 2048 -- the ring through which gates on lvl0 ciphertexts

@@ -700,19 +700,19 @@ class NullBackend : public Backend {
 // tuned here, on the CPU.
 class ModelBackend : public NullBackend {
    public:
-    bool lane_model(LaneModel* m) override { m->chain_gates = 256; m->bulk_gates = 1024; m->chain_ms = 5.15; m->bulk_ms = 19.9; return true; }
+    bool lane_model(LaneModel* m) override { m->chain_gates = 256; m->bulk_gates = 1024; m->chain_ms = 4.80; m->bulk_ms = 18.6; return true; }
     double launch_ms(size_t n) override
     {
         if (n == 0) return 0.0;
         const size_t c = 256, round = 8 * c;
         auto small = [&](size_t t) {
-            if (t <= c) return 3.45;
-            if (t > 6 * c) return 19.3;
+            if (t <= c) return 3.1;
+            if (t > 6 * c) return 18.2;
             const size_t rem = t % (2 * c), paired = (rem == 0 || rem > c) ? t : t - rem;
-            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.7 + (paired < t ? 3.45 : 0.0);
+            return (double)((paired + 2 * c - 1) / (2 * c)) * 5.0 + (paired < t ? 2.9 : 0.0);
         };
         const size_t full = n / round, tail = n % round;
-        return (double)full * 18.7 + (tail ? small(tail) : 0.0);
+        return (double)full * 18.25 + (tail ? small(tail) : 0.0);
     }
     int gate_weight(int op) override { return op == 10 || op == 11 ? 2 : op == 12 || op == 13 ? 0 : 1; }
     uint64_t lanes[3] = {0, 0, 0};

@@ -153,16 +153,17 @@ def test_keyswitch_shared_table_groupings(engine, keys, oracle, count):
     d1 = _upload(engine, t1)
     d0 = engine.api.DeviceBuffer(count * (ol.n + 1))
 
-    def run(split, wg, per):
+    def run(split, wg, per, slices=-1):
         engine.api.set_option("ks_split_threshold", split)
         engine.api.set_option("ks_wg_threshold", wg)
         engine.api.set_option("ks_per_wg", per)
+        engine.api.set_option("ks_slices", slices)
         try:
             d0.upload(np.full(count * (ol.n + 1), 0xDEADBEEF, np.uint32))
             engine.keyswitch_batch(d1, d0, count)
             return d0.download().reshape(count, ol.n + 1).copy()
         finally:
-            for k in ("ks_split_threshold", "ks_wg_threshold", "ks_per_wg"):
+            for k in ("ks_split_threshold", "ks_wg_threshold", "ks_per_wg", "ks_slices"):
                 engine.api.set_option(k, -1)
 
     ref = run(0, 1 << 30, -1)                      # one workgroup per ciphertext
@@ -170,9 +171,10 @@ def test_keyswitch_shared_table_groupings(engine, keys, oracle, count):
         want = np.zeros(ol.n + 1, np.uint32)
         oracle.orc_keyswitch(keys.ek, want, np.ascontiguousarray(t1[g]))
         assert np.array_equal(ref[g], want)
-    for per in (-1, 1, 6, 16):
-        got = run(0, 0, per)
-        assert np.array_equal(got, ref), f"shared-table key switch, {count} ciphertexts, {per} per workgroup"
+    # (ciphertexts per workgroup, runs the steps of j are cut into: above one the partial sums meet in the output through atomics)
+    for per, slices in ((-1, -1), (1, 1), (6, 1), (16, 1), (16, 2), (9, 4), (-1, 16), (16, 64)):
+        got = run(0, 0, per, slices)
+        assert np.array_equal(got, ref), f"shared-table key switch, {count} ciphertexts, {per} per workgroup, {slices} runs of j"
 
 
 @pytest.mark.parametrize("level", [0, 1])
