@@ -116,28 +116,28 @@ long g_ll2_threshold = -1;      // two-rotations-per-workgroup low-latency kerne
 long g_ks_wg_threshold = -1;    // key switches per launch up to which the workgroup-per-ciphertext kernel is used
 long g_ks_per_wg = -1;          // ciphertexts per workgroup of the shared-table key switch: -1 by count, else 1..16
 long g_ks_slices = -1;          // runs the shared-table key switch cuts j into: -1 by count, else a power of two 1..64
-// The shape of a shared-table launch (keyswitch_kernel: per_wg ciphertexts per workgroup, the 1024 steps of j cut into `slices` runs):
+// The shape of a shared-table launch (keyswitch_kernel: per_wg ciphertexts per workgroup, the kn steps of j cut into `slices` runs):
 // the cheapest by a model of the measured times -- a workgroup of 16 live waves takes 1.03 us per step (0.68 + 0.022 per live wave),
 // 12 us around its steps; the workgroups run in rounds of one per CU (hipDeviceProp_t::multiProcessorCount, cached in
-// DeviceState); a launch with runs zeroes the outputs first.  4096 ciphertexts: 256 workgroups x 1024 steps; 3072: 768 x 256 (three
-// rounds); 2048: 256 x 512; 256: 256 x 64.
-void ks_auto_shape(size_t count, int cus, int* per_wg, int* slices)
+// DeviceState); a launch with runs zeroes the outputs first.  kn = 1024 -- 4096 ciphertexts: 256 workgroups x 1024 steps; 3072:
+// 768 x 256 (three rounds); 2048: 256 x 512; 256: 256 x 64.  min_slices: a workgroup keeps the digit words of at most 1024 steps.
+void ks_auto_shape(size_t count, int cus, int kn, int min_slices, int* per_wg, int* slices)
 {
     const size_t c = cus > 0 ? (size_t)cus : 256;
     if (g_ks_slices > 0 || g_ks_per_wg > 0) {            // forced (tests, sweeps): the other one by the round-5 rule
         const size_t p = (count + c - 1) / c;
         *per_wg = g_ks_per_wg > 0 ? (int)g_ks_per_wg : (int)(p < 1 ? 1 : p > 16 ? 16 : p);
-        *slices = g_ks_slices > 0 ? (int)g_ks_slices : 1;
+        *slices = std::max(min_slices, g_ks_slices > 0 ? (int)g_ks_slices : 1);
         return;
     }
     auto cost = [&](int p, int sl) {                      // us
         const size_t wgs = (count + p - 1) / p * sl, rounds = (wgs + c - 1) / c;
-        return rounds * (kN / sl * (0.68 + 0.022 * p) + 12.0) + (sl > 1 ? 20.0 : 15.0);
+        return rounds * (kn / sl * (0.68 + 0.022 * p) + 12.0) + (sl > 1 ? 20.0 : 15.0);
     };
-    const size_t fit = (count + c - 1) / c;               // fewest ciphertexts per workgroup that still fit one round
-    int best_p = (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit), best_sl = 1;
-    double best = cost(best_p, 1);
-    for (int sl = 1; sl <= 64; sl *= 2) {
+    const size_t fit = (count * min_slices + c - 1) / c;  // fewest ciphertexts per workgroup that still fit one round
+    int best_p = (int)(fit < 1 ? 1 : fit > 16 ? 16 : fit), best_sl = min_slices;
+    double best = cost(best_p, best_sl);
+    for (int sl = min_slices; sl <= 64; sl *= 2) {
         const double t = cost(kKsWaves, sl);
         if (t < best) { best = t; best_p = kKsWaves; best_sl = sl; }
     }
@@ -664,18 +664,19 @@ int launch_blind_rotate(DeviceState& s, hipStream_t st, const LinDesc* d, size_t
     }
     return 0;
 }
-// keyswitch_kernel over `ksk_padded` (the default set's table, or that of a parameter set with the same key-switch shape)
-int launch_keyswitch_shared(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count, const uint32_t* ksk_padded)
+// keyswitch_kernel<S> over `ksk_padded` ([kn][t][2][row_pad] u32); *opted_in: the instantiation's dynamic-LDS opt-in on this device
+template <class S>
+int launch_keyswitch_shared(DeviceState& s, hipStream_t st, const typename S::Desc* d, size_t count, const uint32_t* ksk_padded, bool* opted_in)
 {
-    if (!s.ks_lds_opt_in) {
-        HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kKsLdsBytes));
-        s.ks_lds_opt_in = true;
+    if (!*opted_in) {
+        HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, KsDims<S>::lds_bytes));
+        *opted_in = true;
     }
     int per_wg, slices;
-    ks_auto_shape(count, cus_of(s), &per_wg, &slices);
-    if (slices > 1) hipLaunchKernelGGL(keyswitch_split_zero_kernel, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
+    ks_auto_shape(count, cus_of(s), S::kn, KsDims<S>::min_slices, &per_wg, &slices);
+    if (slices > 1) hipLaunchKernelGGL(keyswitch_zero_kernel<S>, dim3((unsigned)count), dim3(256), 0, st, d, (int)count);
     const unsigned ks_blocks = (unsigned)((count + per_wg - 1) / per_wg) * (unsigned)slices;
-    hipLaunchKernelGGL(keyswitch_kernel, dim3(ks_blocks), dim3(kKsThreads), kKsLdsBytes, st, d, (int)count, ksk_padded, per_wg, slices);
+    hipLaunchKernelGGL(keyswitch_kernel<S>, dim3(ks_blocks), dim3(kKsThreads), KsDims<S>::lds_bytes, st, d, (int)count, ksk_padded, per_wg, slices);
     return 0;
 }
 int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t count)
@@ -695,7 +696,7 @@ int launch_keyswitch(DeviceState& s, hipStream_t st, const LinDesc* d, size_t co
     } else if ((long)count <= wg_max) {
         hipLaunchKernelGGL(keyswitch_wg_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk);
     } else {
-        if (int rc = launch_keyswitch_shared(s, st, d, count, s.ksk)) return rc;
+        if (int rc = launch_keyswitch_shared<KsShapeDefault>(s, st, d, count, s.ksk, &s.ks_lds_opt_in)) return rc;
     }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {

@@ -401,68 +401,146 @@ __global__ __launch_bounds__(kBrThreads, 2) void blind_rotate_kernel(
 constexpr int kKsWaves = 16;
 constexpr int kKsThreads = 64 * kKsWaves;                        // 1024
 constexpr int kKsRowPad = 640;                                   // words per padded row
-constexpr int kKsPieces = 3;                                     // 16-byte pieces per lane
+constexpr int kKsPieces = 3;                                     // 16-byte pieces per lane (the workgroup-per-ciphertext kernels)
 constexpr int kKsStepBytes = kKsT * kKsNumBase * kKsRowPad * 4;  // 40960: all rows of one j
 constexpr int kKsBuffers = 3;
-constexpr int kKsLdsDigits = kKsWaves * kN * 2;                  // u16 digit words: 32768
-constexpr int kKsLdsBytes = kKsLdsDigits + kKsBuffers * kKsStepBytes;   // 155648
+constexpr int kKsDigitSteps = 1024;                              // digit words a wave keeps in LDS: the steps of one workgroup
+constexpr int kKsLdsDigits = kKsWaves * kKsDigitSteps * 2;       // u16 digit words: 32768
+
+// The kernel is written once over the SHAPE of a key switch (basebit = 2 everywhere):
+//   Desc                      what a launch is made of (LinDesc / LinDesc64)
+//   kn, t                     values a'_j per ciphertext, digits per value
+//   row_pad, n_out            words per padded row of the table (512 or 640), index of the last output word (b')
+//   digit_word(d, j)          the t digit fields of a'_j, most significant first, in the top bits of a 16-bit word
+//   bprime(d)                 the start of output word n_out
+// KsShapeDefault: lvl10 of the BASELINE set (here); KsShapeCggi16 (kernels_ps.hip.h); KsShapeLvl2: lvl20 (kernels_ks2.hip.h).
+struct KsShapeDefault {
+    using Desc = LinDesc;
+    static constexpr int kn = kN, t = kKsT, row_pad = kKsRowPad, n_out = kLvl0N;
+    // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98; only the top t*basebit = 16 bits of a'_j + offset carry digits
+    static constexpr uint32_t koff()
+    {
+        uint32_t o = 1u << (32 - (1 + kKsBasebit * kKsT));
+        for (int i = 1; i <= kKsT; i++) o += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
+        return o;
+    }
+    static __device__ __forceinline__ uint32_t digit_word(const Desc& d, int j)
+    {
+        return ((uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j] + koff()) >> 16;
+    }
+    static __device__ __forceinline__ uint32_t bprime(const Desc& d) { return (uint32_t)d.ca * d.in0[kn] + (uint32_t)d.cb * d.in1[kn] + d.off; }
+};
+template <class S>
+struct KsDims {
+    static constexpr int pairs = (S::row_pad - 512) / 128;              // 8-byte pieces per lane behind the two 16-byte ones: 0 or 1
+    static constexpr int words = 8 + 2 * pairs;                         // output words per lane
+    static constexpr int step_bytes = S::t * kKsNumBase * S::row_pad * 4;       // all rows of one j
+    static constexpr int dma_pieces = step_bytes / 1024;                // LDS-DMA pieces of 1 KiB per step
+    static constexpr int dma_more = dma_pieces - 2 * kKsWaves;          // waves that move three pieces (the others two)
+    static constexpr int lds_bytes = kKsLdsDigits + kKsBuffers * step_bytes;
+    static constexpr int min_slices = (S::kn + kKsDigitSteps - 1) / kKsDigitSteps;
+    static_assert(S::row_pad == 512 || S::row_pad == 640, "a lane owns two quads and at most one pair of a row");
+    static_assert(step_bytes % 1024 == 0 && dma_more >= 0 && dma_more <= kKsWaves, "two or three DMA pieces per wave and step");
+    static_assert(S::t * kKsBasebit <= 16 && S::n_out < S::row_pad, "digit word of 16 bits; the output fits a row");
+    static_assert(lds_bytes <= 160 * 1024, "digit words + three step buffers fit the CU's LDS");
+};
+static_assert(KsDims<KsShapeDefault>::step_bytes == kKsStepBytes && KsDims<KsShapeDefault>::lds_bytes == 155648, "BASELINE shape");
 
 // One digit of one key-switch step on one wave: f = val + 2 (wave-uniform, in an SGPR) selects +row(v=2) [f 0], +row(v=1) [f 1],
-// nothing [f 2] or -row(v=1) [f 3]; the row lies at a compile-time offset from the lane's three LDS addresses and is added to the
-// lane's ten sums IN PLACE.  The three-way choice is spelled as scalar branches INSIDE asm blocks, so that the compiler sees
+// nothing [f 2] or -row(v=1) [f 3]; the row lies at a compile-time offset from the lane's LDS addresses and is added to the
+// lane's eight or ten sums IN PLACE.  The three-way choice is spelled as scalar branches INSIDE asm blocks, so that the compiler sees
 // straight-line code: written as `if (f == 3) res -= r; else res += r;` the structurised control flow gave every arm fresh result
 // registers and copied them back (6 v_mov_b64 per digit) and the row offset went through a VGPR (3 v_add per digit) -- 21 vector
 // instructions per digit where 10 do the work.  And the rows of ALL digits of a step are requested before the first is added (one
 // wait): waited for one by one they are a chain of eight dependent LDS round trips per step, which with the scalar branching around
-// them was what a step took (0.75 us even for a single ciphertext per workgroup; the table pipeline alone: 0.2 us).
+// them was what a step took (0.75 us even for a single ciphertext per workgroup; the table pipeline alone: 0.4 us).
 // profiles/r06_keyswitch.md
 typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t ks_u32x2 __attribute__((ext_vector_type(2)));
 struct KsRow { ks_u32x4 a, b; ks_u32x2 c; };
 // ... the loads: issued, NOT waited for
-template <int ROW1, int ROW2>
+template <int ROW1, int ROW2, int PAIRS>
 __device__ __forceinline__ void ks_digit_load(const uint32_t f, const uint32_t a0, const uint32_t a1, const uint32_t a2, KsRow& r)
 {
-    asm volatile(
-        "s_cmp_eq_u32 %3, 2\n\t"
-        "s_cbranch_scc1 .Lks_ld_end_%=\n\t"
-        "s_cmp_eq_u32 %3, 0\n\t"
-        "s_cbranch_scc1 .Lks_ld_two_%=\n\t"
-        "ds_read_b128 %0, %4 offset:%7\n\t"
-        "ds_read_b128 %1, %5 offset:%7\n\t"
-        "ds_read_b64 %2, %6 offset:%7\n\t"
-        "s_branch .Lks_ld_end_%=\n"
-        ".Lks_ld_two_%=:\n\t"
-        "ds_read_b128 %0, %4 offset:%8\n\t"
-        "ds_read_b128 %1, %5 offset:%8\n\t"
-        "ds_read_b64 %2, %6 offset:%8\n"
-        ".Lks_ld_end_%=:"
-        : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c)
-        : "s"(f), "v"(a0), "v"(a1), "v"(a2), "n"(ROW1), "n"(ROW2)
-        : "memory", "scc");
+    if constexpr (PAIRS) {
+        asm volatile(
+            "s_cmp_eq_u32 %3, 2\n\t"
+            "s_cbranch_scc1 .Lks_ld_end_%=\n\t"
+            "s_cmp_eq_u32 %3, 0\n\t"
+            "s_cbranch_scc1 .Lks_ld_two_%=\n\t"
+            "ds_read_b128 %0, %4 offset:%7\n\t"
+            "ds_read_b128 %1, %5 offset:%7\n\t"
+            "ds_read_b64 %2, %6 offset:%7\n\t"
+            "s_branch .Lks_ld_end_%=\n"
+            ".Lks_ld_two_%=:\n\t"
+            "ds_read_b128 %0, %4 offset:%8\n\t"
+            "ds_read_b128 %1, %5 offset:%8\n\t"
+            "ds_read_b64 %2, %6 offset:%8\n"
+            ".Lks_ld_end_%=:"
+            : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c)
+            : "s"(f), "v"(a0), "v"(a1), "v"(a2), "n"(ROW1), "n"(ROW2)
+            : "memory", "scc");
+    } else {
+        asm volatile(
+            "s_cmp_eq_u32 %2, 2\n\t"
+            "s_cbranch_scc1 .Lks_ld_end_%=\n\t"
+            "s_cmp_eq_u32 %2, 0\n\t"
+            "s_cbranch_scc1 .Lks_ld_two_%=\n\t"
+            "ds_read_b128 %0, %3 offset:%5\n\t"
+            "ds_read_b128 %1, %4 offset:%5\n\t"
+            "s_branch .Lks_ld_end_%=\n"
+            ".Lks_ld_two_%=:\n\t"
+            "ds_read_b128 %0, %3 offset:%6\n\t"
+            "ds_read_b128 %1, %4 offset:%6\n"
+            ".Lks_ld_end_%=:"
+            : "=&v"(r.a), "=&v"(r.b)
+            : "s"(f), "v"(a0), "v"(a1), "n"(ROW1), "n"(ROW2)
+            : "memory", "scc");
+    }
 }
-// ... the ten additions or subtractions.  (Without a branch for the sign -- res += row ^ s through v_xad_u32, s = 0 or ~0, the
+// ... the additions or subtractions.  (Without a branch for the sign -- res += row ^ s through v_xad_u32, s = 0 or ~0, the
 // subtractions counted in the prologue and added to every word at the end -- a launch of up to 1024 ciphertexts is 7 % faster and
 // one of 4096 is 4 % slower: profiles/r06_keyswitch_xad_experiment.patch.)
-__device__ __forceinline__ void ks_digit_acc(const uint32_t f, const KsRow& r, uint32_t (&res)[10])
+template <int PAIRS>
+__device__ __forceinline__ void ks_digit_acc(const uint32_t f, const KsRow& r, uint32_t (&res)[8 + 2 * PAIRS])
 {
-#define CUFHE_AMD_KS_TEN(OP)                                                                                               \
+    if constexpr (PAIRS) {
+#define CUFHE_AMD_KS_ALL(OP)                                                                                               \
     OP " %0, %0, %11\n\t" OP " %1, %1, %12\n\t" OP " %2, %2, %13\n\t" OP " %3, %3, %14\n\t" OP " %4, %4, %15\n\t"             \
     OP " %5, %5, %16\n\t" OP " %6, %6, %17\n\t" OP " %7, %7, %18\n\t" OP " %8, %8, %19\n\t" OP " %9, %9, %20\n"
-    asm volatile(
-        "s_cmp_eq_u32 %10, 2\n\t"
-        "s_cbranch_scc1 .Lks_acc_end_%=\n\t"
-        "s_cmp_eq_u32 %10, 3\n\t"
-        "s_cbranch_scc1 .Lks_acc_sub_%=\n\t"
-        CUFHE_AMD_KS_TEN("v_add_u32_e32")
-        "\ts_branch .Lks_acc_end_%=\n"
-        ".Lks_acc_sub_%=:\n\t"
-        CUFHE_AMD_KS_TEN("v_sub_u32_e32")
-        ".Lks_acc_end_%=:"
-        : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9])
-        : "s"(f), "v"(r.a.x), "v"(r.a.y), "v"(r.a.z), "v"(r.a.w), "v"(r.b.x), "v"(r.b.y), "v"(r.b.z), "v"(r.b.w), "v"(r.c.x), "v"(r.c.y)
-        : "scc");
-#undef CUFHE_AMD_KS_TEN
+        asm volatile(
+            "s_cmp_eq_u32 %10, 2\n\t"
+            "s_cbranch_scc1 .Lks_acc_end_%=\n\t"
+            "s_cmp_eq_u32 %10, 3\n\t"
+            "s_cbranch_scc1 .Lks_acc_sub_%=\n\t"
+            CUFHE_AMD_KS_ALL("v_add_u32_e32")
+            "\ts_branch .Lks_acc_end_%=\n"
+            ".Lks_acc_sub_%=:\n\t"
+            CUFHE_AMD_KS_ALL("v_sub_u32_e32")
+            ".Lks_acc_end_%=:"
+            : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7]), "+v"(res[8]), "+v"(res[9])
+            : "s"(f), "v"(r.a.x), "v"(r.a.y), "v"(r.a.z), "v"(r.a.w), "v"(r.b.x), "v"(r.b.y), "v"(r.b.z), "v"(r.b.w), "v"(r.c.x), "v"(r.c.y)
+            : "scc");
+#undef CUFHE_AMD_KS_ALL
+    } else {
+#define CUFHE_AMD_KS_ALL(OP)                                                                                               \
+    OP " %0, %0, %9\n\t" OP " %1, %1, %10\n\t" OP " %2, %2, %11\n\t" OP " %3, %3, %12\n\t" OP " %4, %4, %13\n\t"              \
+    OP " %5, %5, %14\n\t" OP " %6, %6, %15\n\t" OP " %7, %7, %16\n"
+        asm volatile(
+            "s_cmp_eq_u32 %8, 2\n\t"
+            "s_cbranch_scc1 .Lks_acc_end_%=\n\t"
+            "s_cmp_eq_u32 %8, 3\n\t"
+            "s_cbranch_scc1 .Lks_acc_sub_%=\n\t"
+            CUFHE_AMD_KS_ALL("v_add_u32_e32")
+            "\ts_branch .Lks_acc_end_%=\n"
+            ".Lks_acc_sub_%=:\n\t"
+            CUFHE_AMD_KS_ALL("v_sub_u32_e32")
+            ".Lks_acc_end_%=:"
+            : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]), "+v"(res[4]), "+v"(res[5]), "+v"(res[6]), "+v"(res[7])
+            : "s"(f), "v"(r.a.x), "v"(r.a.y), "v"(r.a.z), "v"(r.a.w), "v"(r.b.x), "v"(r.b.y), "v"(r.b.z), "v"(r.b.w)
+            : "scc");
+#undef CUFHE_AMD_KS_ALL
+    }
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void ks_for(F&& f)
@@ -472,88 +550,99 @@ __device__ __forceinline__ void ks_for(F&& f)
         ks_for<I + 1, N>(f);
     }
 }
-// the 8 digits of a'_j (dj: its 16 digit bits, most significant digit first): all rows requested (not waited for) / all additions
+// the t digits of a'_j (dj: its digit bits, most significant digit first): all rows requested (not waited for) / all additions
 __device__ __forceinline__ uint32_t ks_field(const uint32_t dj, const int k) { return (dj >> (16 - (k + 1) * kKsBasebit)) & ((1u << kKsBasebit) - 1); }
-__device__ __forceinline__ void ks_load_all(const uint32_t dj, const uint32_t (&pb)[3], KsRow (&r)[kKsT])
+template <class S>
+__device__ __forceinline__ void ks_load_all(const uint32_t dj, const uint32_t (&pb)[3], KsRow (&r)[S::t])
 {
-    ks_for<0, kKsT>([&](auto kc) {
+    ks_for<0, S::t>([&](auto kc) {
         constexpr int K = decltype(kc)::value;
-        ks_digit_load<(K * kKsNumBase) * (kKsRowPad * 4), (K * kKsNumBase + 1) * (kKsRowPad * 4)>(ks_field(dj, K), pb[0], pb[1], pb[2], r[K]);
+        ks_digit_load<(K * kKsNumBase) * (S::row_pad * 4), (K * kKsNumBase + 1) * (S::row_pad * 4), KsDims<S>::pairs>(ks_field(dj, K), pb[0], pb[1], pb[2], r[K]);
     });
 }
-__device__ __forceinline__ void ks_acc_all(const uint32_t dj, const KsRow (&r)[kKsT], uint32_t (&res)[10])
+template <class S>
+__device__ __forceinline__ void ks_acc_all(const uint32_t dj, const KsRow (&r)[S::t], uint32_t (&res)[KsDims<S>::words])
 {
-    ks_for<0, kKsT>([&](auto kc) { ks_digit_acc(ks_field(dj, decltype(kc)::value), r[decltype(kc)::value], res); });
+    ks_for<0, S::t>([&](auto kc) { ks_digit_acc<KsDims<S>::pairs>(ks_field(dj, decltype(kc)::value), r[decltype(kc)::value], res); });
+}
+
+// the outputs of a launch that cuts j into runs: zeroed first (the runs add their partial sums with atomics)
+template <class S>
+__global__ __launch_bounds__(256) void keyswitch_zero_kernel(const typename S::Desc* __restrict__ descs, int count)
+{
+    const int g = blockIdx.x;
+    if (g >= count) return;
+    uint32_t* out = descs[g].out;
+    for (int i = threadIdx.x; i <= S::n_out; i += blockDim.x) out[i] = 0u;
 }
 
 // per_wg (1..16): ciphertexts per workgroup.  Waves at and above per_wg only move table pieces and keep the barriers: a
 // launch of fewer than 4096 ciphertexts then still covers every CU, and a step carries fewer row reads and additions.
-// slices (a power of two, 1..64): the 1024 steps of j are cut into `slices` runs and workgroup i takes run i % slices for the
-// ciphertexts of group i / slices (workgroups of one XCD -- i % 8 -- then walk the same part of the table).  With slices > 1 the
-// partial sums are added into d.out with atomics, which keyswitch_split_zero_kernel has zeroed before: a launch of 2048 ciphertexts
-// is then 128 groups x 2 runs of 512 steps with all 16 waves live instead of 256 workgroups x 1024 steps with 8, one of 256 is
-// 16 groups x 16 runs of 64 steps (profiles/r06_keyswitch.md).
+// slices (a power of two, at most 64, at least kn / 1024): the steps of j are cut into `slices` runs and workgroup i takes run
+// i % slices for the ciphertexts of group i / slices (workgroups of one XCD -- i % 8 -- then walk the same part of the table).  With
+// slices > 1 the partial sums are added into d.out with atomics, which keyswitch_zero_kernel has zeroed before: a launch of 2048
+// ciphertexts is then 128 groups x 2 runs of 512 steps with all 16 waves live instead of 256 workgroups x 1024 steps with 8, one of
+// 256 is 16 groups x 16 runs of 64 steps (profiles/r06_keyswitch.md).
+template <class S>
 __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
-    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded, int per_wg, int slices)
+    const typename S::Desc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded, int per_wg, int slices)
 {
+    using K = KsDims<S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int slice = blockIdx.x % slices;
-    const int steps = kN / slices, j_lo = slice * steps;       // this workgroup's run of j: [j_lo, j_lo + steps); t below = j - j_lo
+    const int steps = S::kn / slices, j_lo = slice * steps;    // this workgroup's run of j: [j_lo, j_lo + steps); t below = j - j_lo
     int g = (blockIdx.x / slices) * per_wg + wave;
     const bool live = wave < per_wg && g < count;
     if (!live) g = count - 1;
-    const LinDesc d = descs[g];
-    uint16_t* dig = (uint16_t*)smem + wave * kN;
+    const typename S::Desc d = descs[g];
+    uint16_t* dig = (uint16_t*)smem + wave * kKsDigitSteps;
     char* bufs = smem + kKsLdsDigits;
 
-    // LDS-DMA of step t: 40 pieces of 1 KiB; waves 0-7 move 3, waves 8-15 move 2
+    // LDS-DMA of step t in pieces of 1 KiB: the first dma_more waves move three, the others two
+    const bool three = wave < K::dma_more;
+    const int piece0 = 2 * wave + (three ? wave : K::dma_more);
     auto issue = [&](int t) {
         if (t >= steps) return;
-        const char* src = (const char*)ksk_padded + (size_t)(j_lo + t) * kKsStepBytes + lane * 16;
-        char* dst = bufs + (t % kKsBuffers) * kKsStepBytes;
+        const char* src = (const char*)ksk_padded + (size_t)(j_lo + t) * K::step_bytes + lane * 16;
+        char* dst = bufs + (t % kKsBuffers) * K::step_bytes;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const int piece = wave < 8 ? 3 * wave + c : 24 + 2 * (wave - 8) + c;
-            if (c == 2 && wave >= 8) break;
+            if (c == 2 && !three) break;
 #if !(defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DMA))
-            lds_dma16(src + piece * 1024, dst + piece * 1024);
+            lds_dma16(src + (piece0 + c) * 1024, dst + (piece0 + c) * 1024);
 #endif
         }
     };
     issue(0);
     issue(1);
 
-    // iksoffsetgen + roundoffset, include/keyswitch_gpu.cuh:13-23,92-98; only the top
-    // t*basebit = 16 bits of a'_j + offset carry digits
-    uint32_t koff = 1u << (32 - (1 + kKsBasebit * kKsT));
-    for (int i = 1; i <= kKsT; i++) koff += ((1u << kKsBasebit) / 2) << (32 - i * kKsBasebit);
-    for (int t = lane; t < steps; t += 64) {
-        const uint32_t v = (uint32_t)d.ca * d.in0[j_lo + t] + (uint32_t)d.cb * d.in1[j_lo + t];
-        dig[t] = (uint16_t)((v + koff) >> 16);
-    }
-    // b' = ca in0[1024] + cb in1[1024] + off: the start of word 630, in the first run only
-    const uint32_t bprime = slice == 0 ? (uint32_t)d.ca * d.in0[kN] + (uint32_t)d.cb * d.in1[kN] + d.off : 0u;
+    for (int t = lane; t < steps; t += 64) dig[t] = (uint16_t)S::digit_word(d, j_lo + t);
+    const uint32_t bprime = slice == 0 ? S::bprime(d) : 0u;     // the start of word n_out, in the first run only
 
-    // Lane L owns 16-byte pieces L and L + 64 (words 4 L .. 4 L + 3 and 256 + 4 L ..) and the 8-byte piece L behind them (words
-    // 512 + 2 L, 513 + 2 L): ten words, no lane idles on a third quad.
-    uint32_t res[10];
+    // Lane L owns 16-byte pieces L and L + 64 (words 4 L .. 4 L + 3 and 256 + 4 L ..) and, in a row of 640 words, the 8-byte piece L
+    // behind them (words 512 + 2 L, 513 + 2 L): eight or ten words, no lane idles on a third quad.
+    uint32_t res[K::words];
 #pragma unroll
-    for (int m = 0; m < 10; m++) res[m] = 0;
-    if (lane == 59) res[8] = bprime;             // word 630 = 512 + 2 * 59
-    // per-buffer LDS addresses of the three pieces kept in VGPRs: a row is then "VGPR + immediate"
-    uint32_t pbase[kKsBuffers][kKsPieces];
+    for (int m = 0; m < K::words; m++) res[m] = 0;
+    {
+        constexpr int n = S::n_out, m = n < 256 ? n % 4 : n < 512 ? 4 + (n - 256) % 4 : 8 + (n - 512) % 2;
+        constexpr int owner = n < 256 ? n / 4 : n < 512 ? (n - 256) / 4 : (n - 512) / 2;
+        if (lane == owner) res[m] = bprime;
+    }
+    // per-buffer LDS addresses of the pieces kept in VGPRs: a row is then "VGPR + immediate"
+    uint32_t pbase[kKsBuffers][3];
 #pragma unroll
     for (int bi = 0; bi < kKsBuffers; bi++) {
-        const uint32_t buf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(smem + kKsLdsDigits + bi * kKsStepBytes);
+        const uint32_t buf = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(bufs + bi * K::step_bytes);
         pbase[bi][0] = buf + lane * 16;
         pbase[bi][1] = buf + 1024 + lane * 16;
         pbase[bi][2] = buf + 2048 + lane * 8;
     }
 
     __syncthreads();          // digit words visible; the prologue's plain loads have drained vmcnt
-    // One step t: counted wait + barrier, issue step t+2, apply the 8 digits of a'_j.  The waves of a SIMD (wave w runs on SIMD w % 4)
+    // One step t: counted wait + barrier, issue step t+2, apply the digits of a'_j.  The waves of a SIMD (wave w runs on SIMD w % 4)
     // come out of the barrier together and would all request rows (scalar and LDS work), then all wait, then all add (vector
     // work), one pipe busy at a time.  So every second wave of a SIMD runs one phase behind: it requests the rows of step t at the
     // END of the step's interval and adds them at the start of the next one, while its neighbours request theirs.
@@ -562,26 +651,26 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         // barrier, only step t must have landed.  lgkmcnt(0): this wave has finished reading
         // step t-1, whose buffer step t+2 is about to overwrite.
         if (t + 1 >= steps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (wave < 8) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if (three) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         issue(t + 2);
     };
     static_assert(kKsBuffers == 3, "the loops over t are unrolled by the number of buffers");
     const int whole = steps - steps % 3;       // steps is a power of two: one or two steps follow the unrolled loop
-    KsRow r[kKsT];
+    KsRow r[S::t];
     // (with at most two live waves per SIMD -- per_wg <= 8 -- the shift costs more than it hides: 0.90 against 0.86 ms per 2048)
     if (per_wg <= 8 || !((wave >> 2) & 1)) {
-        auto step = [&](int t, const uint32_t (&pb)[kKsPieces]) {
+        auto step = [&](int t, const uint32_t (&pb)[3]) {
             wait_and_issue(t);
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
             return;                                               // timing only: the table pipeline without the digits
 #endif
             if (!live) return;                                    // wave-uniform: this wave only serves the table pipeline
             const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[t]);
-            ks_load_all(dj, pb, r);
+            ks_load_all<S>(dj, pb, r);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ks_acc_all(dj, r, res);
+            ks_acc_all<S>(dj, r, res);
         };
 #pragma unroll 1
         for (int t = 0; t < whole; t += 3) {
@@ -592,14 +681,14 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         step(whole, pbase[0]);
         if (whole + 1 < steps) step(whole + 1, pbase[1]);
     } else {
-        auto step = [&](int t, const uint32_t (&pb)[kKsPieces]) {
+        auto step = [&](int t, const uint32_t (&pb)[3]) {
             wait_and_issue(t);                                    // its lgkmcnt(0): the rows of step t-1 are in r
 #if defined(CUFHE_AMD_DIAGNOSTIC_BUILD) && defined(CUFHE_AMD_ABL_KS_NO_DIGITS)
             return;                                               // timing only: the table pipeline without the digits
 #endif
             if (!live) return;
-            if (t > 0) ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[t - 1]), r, res);
-            ks_load_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[t]), pb, r);
+            if (t > 0) ks_acc_all<S>(__builtin_amdgcn_readfirstlane((uint32_t)dig[t - 1]), r, res);
+            ks_load_all<S>(__builtin_amdgcn_readfirstlane((uint32_t)dig[t]), pb, r);
         };
 #pragma unroll 1
         for (int t = 0; t < whole; t += 3) {
@@ -611,23 +700,19 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_kernel(
         if (whole + 1 < steps) step(whole + 1, pbase[1]);
         if (live) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ks_acc_all(__builtin_amdgcn_readfirstlane((uint32_t)dig[steps - 1]), r, res);
+            ks_acc_all<S>(__builtin_amdgcn_readfirstlane((uint32_t)dig[steps - 1]), r, res);
         }
     }
     if (!live) return;
-    uint32_t* o = d.out;                                     // 4-byte aligned only (ciphertexts packed at 631 words)
-    const int i = 512 + 2 * lane;
-    if (slices == 1) {
+    uint32_t* o = d.out;                                     // 4-byte aligned only (ciphertexts packed at n_out + 1 words)
+    auto put = [&](int i, uint32_t v) {
+        if (i > S::n_out) return;
+        if (slices == 1) o[i] = v;
+        else atomicAdd(&o[i], v);
+    };
 #pragma unroll
-        for (int m = 0; m < 4; m++) { o[4 * lane + m] = res[m]; o[256 + 4 * lane + m] = res[4 + m]; }      // words 0 .. 511
-        if (i + 0 <= kLvl0N) o[i + 0] = res[8];
-        if (i + 1 <= kLvl0N) o[i + 1] = res[9];
-    } else {
-#pragma unroll
-        for (int m = 0; m < 4; m++) { atomicAdd(&o[4 * lane + m], res[m]); atomicAdd(&o[256 + 4 * lane + m], res[4 + m]); }
-        if (i + 0 <= kLvl0N) atomicAdd(&o[i + 0], res[8]);
-        if (i + 1 <= kLvl0N) atomicAdd(&o[i + 1], res[9]);
-    }
+    for (int m = 0; m < 4; m++) { put(4 * lane + m, res[m]); put(256 + 4 * lane + m, res[4 + m]); }
+    if constexpr (K::pairs) { put(512 + 2 * lane, res[8]); put(513 + 2 * lane, res[9]); }
 }
 
 // Low-latency key switch: one workgroup (16 waves) per ciphertext, wave w takes the 64 values

@@ -893,147 +893,33 @@ __global__ __launch_bounds__(kKsThreads) void keyswitch_ps_kernel(
 }
 
 // ----------------------------------------------------------------------------------------------
-// The same key switch for large launches with the table shared through LDS: keyswitch_kernel (kernels.hip.h)
-// written over PS.  A workgroup of 16 waves handles 16 ciphertexts and walks j in lock-step; the t x 2^(basebit-1)
-// candidate rows of one j are copied once into LDS by LDS-DMA two steps ahead (3 buffers) and every wave adds or
-// subtracts the rows its own digits select.  ksk_padded: [kN][t][2^(basebit-1)][row_pad] u32, rows padded to a
-// multiple of 64 words (paramsets.inc.h).  Lane L owns the 16-byte pieces L, L + 64, ... of a row.
+// The same key switch with the table shared through LDS: keyswitch_kernel (kernels.hip.h) over the set's shape.
+// ksk_padded: [kN][t][2^(basebit-1)][row_pad] u32, rows padded to a multiple of 128 words (paramsets.inc.h).
 // ----------------------------------------------------------------------------------------------
 template <class PS>
 struct PsKs {
     using D = PsDims<PS>;
     static constexpr int KN = PS::k * D::N;
     static constexpr int W0 = D::lvl0_words;
-    static constexpr int row_pad = (W0 + 63) / 64 * 64;                    // words
-    static constexpr int row_pieces = row_pad / 4;                         // 16-byte pieces per row
-    static constexpr int per_lane = (row_pieces + 63) / 64;                // pieces per lane (the last may be partial)
+    static constexpr int row_pad = (W0 + 127) / 128 * 128;                 // words: two quads per lane and whole pairs behind them
     static constexpr int step_rows = PS::t * D::ks_numbase;
-    static constexpr int step_bytes = step_rows * row_pad * 4;
-    static constexpr int dma_pieces = step_bytes / 1024;
-    static constexpr int lds_digits = kKsWaves * KN * 2;
-    static constexpr int lds_bytes = lds_digits + kKsBuffers * step_bytes;
-    static_assert(step_bytes % 1024 == 0, "a step is moved in 1 KiB pieces");
-    static_assert(dma_pieces <= 4 * kKsWaves, "at most four DMA pieces per wave and step");
-    static_assert(PS::basebit == 2, "the digit decoding below is written for basebit = 2 (values -2 .. 1)");
-    static_assert(PS::t * PS::basebit <= 16, "digit word is 16 bits");
-    static_assert(lds_bytes <= 160 * 1024, "key switch of this set does not fit the CU's LDS");
+    static_assert(PS::basebit == kKsBasebit, "keyswitch_kernel decodes digits of two bits (values -2 .. 1)");
 };
-
 template <class PS>
-__global__ __launch_bounds__(kKsThreads) void keyswitch_ps_shared_kernel(
-    const LinDesc* __restrict__ descs, int count, const uint32_t* __restrict__ ksk_padded)
-{
-    using K = PsKs<PS>;
-    constexpr int KN = K::KN, PER = K::per_lane;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int g = blockIdx.x * kKsWaves + wave;
-    const bool live = g < count;
-    if (!live) g = count - 1;
-    const LinDesc d = descs[g];
-    uint16_t* dig = (uint16_t*)smem + wave * KN;
-    char* bufs = smem + K::lds_digits;
-    const int my_pieces = (K::dma_pieces - wave + kKsWaves - 1) / kKsWaves;      // DMA pieces wave, wave + 16, ... of a step
-
-    auto issue = [&](int j) {
-        if (j >= KN) return;
-        const char* src = (const char*)ksk_padded + (size_t)j * K::step_bytes + lane * 16;
-        char* dst = bufs + (j % kKsBuffers) * K::step_bytes;
-#pragma unroll
-        for (int c = 0; c < (K::dma_pieces + kKsWaves - 1) / kKsWaves; c++) {
-            const int piece = wave + kKsWaves * c;
-            if (piece < K::dma_pieces)
-                lds_dma16(src + piece * 1024, dst + piece * 1024);
-        }
-    };
-    issue(0);
-    issue(1);
-
-    uint32_t koff = (PS::t * PS::basebit < 32) ? 1u << (32 - (1 + PS::basebit * PS::t)) : 0u;     // roundoffset, keyswitch_gpu.cuh:92-98
-    for (int i = 1; i <= PS::t; i++) koff += ((1u << PS::basebit) / 2) << (32 - i * PS::basebit); // iksoffsetgen, :13-23
-    uint32_t bprime = 0;
-    for (int j = lane; j <= KN; j += 64) {
-        const uint32_t v = (uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j];
-        if (j == KN) bprime = v + d.off;
-        else dig[j] = (uint16_t)((v + koff) >> 16);
+struct KsShapePs {
+    using Desc = LinDesc;
+    static constexpr int kn = PsKs<PS>::KN, t = PS::t, row_pad = PsKs<PS>::row_pad, n_out = PS::n;
+    static constexpr uint32_t koff()
+    {
+        uint32_t o = (PS::t * PS::basebit < 32) ? 1u << (32 - (1 + PS::basebit * PS::t)) : 0u;     // roundoffset, keyswitch_gpu.cuh:92-98
+        for (int i = 1; i <= PS::t; i++) o += ((1u << PS::basebit) / 2) << (32 - i * PS::basebit); // iksoffsetgen, :13-23
+        return o;
     }
-    bprime = __builtin_amdgcn_readlane(bprime, KN % 64);
-
-    uint4 res[PER];
-#pragma unroll
-    for (int m = 0; m < PER; m++) res[m] = make_uint4(0, 0, 0, 0);
-    {   // word n starts from b'
-        constexpr int piece = PS::n / 4, comp = PS::n % 4;
-        if (lane == piece % 64) {
-            uint32_t* w = (uint32_t*)&res[piece / 64];
-            w[comp] = bprime;
-        }
+    static __device__ __forceinline__ uint32_t digit_word(const Desc& d, int j)
+    {
+        return ((uint32_t)d.ca * d.in0[j] + (uint32_t)d.cb * d.in1[j] + koff()) >> 16;
     }
-    int off[PER];
-#pragma unroll
-    for (int m = 0; m < PER; m++) {
-        const int piece = lane + 64 * m;
-        off[m] = (piece < K::row_pieces ? piece : K::row_pieces - 1) * 16;       // lanes past the row re-read its last piece
-    }
-    const char* pbase[kKsBuffers][PER];
-#pragma unroll
-    for (int bi = 0; bi < kKsBuffers; bi++)
-#pragma unroll
-        for (int m = 0; m < PER; m++) pbase[bi][m] = smem + opaque(K::lds_digits + bi * K::step_bytes + off[m]);
-
-    __syncthreads();
-    auto step = [&](int j, const char* const (&pb)[PER]) {
-        // the pieces of step j+1 (this wave's newest DMAs) stay in flight across the barrier, only step j must have landed
-        if (j + 1 >= KN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        issue(j + 2);
-        const uint32_t dj = __builtin_amdgcn_readfirstlane((uint32_t)dig[j]);
-#pragma unroll
-        for (int k = 0; k < PS::t; k++) {
-            // field f = val + 2: 0 -> +row(v=2), 1 -> +row(v=1), 2 -> nothing, 3 -> -row(v=1)
-            const uint32_t f = (dj >> (16 - (k + 1) * PS::basebit)) & ((1u << PS::basebit) - 1);
-            if (f != 2) {
-                const int roff = (k * K::D::ks_numbase + (f == 0 ? 1 : 0)) * (K::row_pad * 4);
-                uint4 r[PER];
-#pragma unroll
-                for (int m = 0; m < PER; m++) r[m] = *(const uint4*)(pb[m] + roff);
-                if (f == 3) {
-#pragma unroll
-                    for (int m = 0; m < PER; m++) { res[m].x -= r[m].x; res[m].y -= r[m].y; res[m].z -= r[m].z; res[m].w -= r[m].w; }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < PER; m++) { res[m].x += r[m].x; res[m].y += r[m].y; res[m].z += r[m].z; res[m].w += r[m].w; }
-                }
-            }
-        }
-    };
-    static_assert(kKsBuffers == 3, "the j loop is unrolled by the number of buffers");
-    int j = 0;
-#pragma unroll 1
-    for (; j + 2 < KN; j += 3) {
-        step(j, pbase[0]);
-        step(j + 1, pbase[1]);
-        step(j + 2, pbase[2]);
-    }
-    if (KN % 3 >= 1) step(KN - KN % 3, pbase[0]);
-    if (KN % 3 == 2) step(KN - 1, pbase[1]);
-    if (!live) return;
-#pragma unroll
-    for (int m = 0; m < PER; m++) {
-        const int piece = lane + 64 * m;
-        if (piece >= K::row_pieces) break;
-        const int i = 4 * piece;
-        if (i + 0 < K::W0) d.out[i + 0] = res[m].x;
-        if (i + 1 < K::W0) d.out[i + 1] = res[m].y;
-        if (i + 2 < K::W0) d.out[i + 2] = res[m].z;
-        if (i + 3 < K::W0) d.out[i + 3] = res[m].w;
-    }
-}
+    static __device__ __forceinline__ uint32_t bprime(const Desc& d) { return (uint32_t)d.ca * d.in0[kn] + (uint32_t)d.cb * d.in1[kn] + d.off; }
+};
 
 }  // namespace cufhe_amd

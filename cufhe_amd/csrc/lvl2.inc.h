@@ -150,18 +150,12 @@ int launch_keyswitch_lvl2(DeviceState& s, hipStream_t st, const LinDesc64* d, si
         HIP_TRY(hipEventCreate(&ev.b));
         HIP_TRY(hipEventRecord(ev.a, st));
     }
-    // a workgroup per ciphertext costs 2.1 us per ciphertext (8.5 ms per 4096 on 256 CUs), the shared-table kernel 3.1 ms per launch:
-    // the first up to 1400 = 5.5 ciphertexts per CU
-    if ((long)count <= (g_ks_wg_threshold < 0 ? 11L * std::max(1, cus_of(s)) / 2 : g_ks_wg_threshold)) {
-        // a workgroup per ciphertext, rows from L2: lowest latency for small and middle-sized launches
+    // keyswitch_kernel over the lvl20 shape (j cut into runs that fill the CUs) at any count; the workgroup-per-ciphertext kernel
+    // (2.1 us per ciphertext) only by "ks_wg_threshold"
+    if (g_ks_wg_threshold > 0 && (long)count <= g_ks_wg_threshold) {
         hipLaunchKernelGGL(keyswitch_lvl2_kernel, dim3((unsigned)count), dim3(kKsThreads), 0, st, d, (int)count, s.ksk2);
     } else {
-        if (!s.ks2_lds_opt_in) {
-            HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_lvl2_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2KsLdsBytes));
-            s.ks2_lds_opt_in = true;
-        }
-        const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
-        hipLaunchKernelGGL(keyswitch_lvl2_shared_kernel, dim3(blocks), dim3(kKsThreads), k2KsLdsBytes, st, d, (int)count, s.ksk2);
+        if (int rc = launch_keyswitch_shared<KsShapeLvl2>(s, st, d, count, s.ksk2, &s.ks2_lds_opt_in)) return rc;
     }
     HIP_TRY(hipGetLastError());
     if (s.profiling) {

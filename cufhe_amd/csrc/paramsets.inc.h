@@ -24,7 +24,7 @@ struct PsState {
 // kN = 1024, n = 630, t = 8, basebit = 2: the hand-scheduled shared-table key switch of kernels.hip.h applies as it is
 template <class PS>
 constexpr bool ps_ks_is_default_shape = PS::k * PsDims<PS>::N == kN && PS::n == kLvl0N && PS::t == kKsT && PS::basebit == kKsBasebit;
-static_assert(PsKs<PsDefault>::row_pad == kKsRowPad, "one padded table serves both shared-table kernels");
+static_assert(PsKs<PsDefault>::row_pad == kKsRowPad, "a set with the default key-switch shape shares keyswitch_kernel<KsShapeDefault>");
 
 template <class PS>
 int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDesc* d, size_t count)
@@ -32,21 +32,13 @@ int ps_launch_keyswitch(DeviceState& s, PsState& ps, hipStream_t st, const LinDe
     if (count == 0) return 0;
     EventPair ev{};
     if (int rc = prof_begin(s, st, ev)) return rc;
-    // a set with the default key-switch shape takes keyswitch_kernel, which cuts j into runs and wins at any count; the
-    // whole-sweep kernel written over PS only above 25/4 ciphertexts per CU (the round-5 rule: 1600 on 256 CUs)
-    const long wg_auto = ps_ks_is_default_shape<PS> ? 0 : 25L * std::max(1, cus_of(s)) / 4;
-    const long wg_max = g_ks_wg_threshold < 0 ? wg_auto : g_ks_wg_threshold;
-    if ((long)count > wg_max && ps.ksk_padded) {
-        // 16 ciphertexts per workgroup, table rows through LDS
-        const unsigned blocks = (unsigned)((count + kKsWaves - 1) / kKsWaves);
+    // keyswitch_kernel over the set's shape (j cut into runs that fill the CUs) at any count; the workgroup-per-ciphertext kernel
+    // only by "ks_wg_threshold" (or when the padded table could not be built)
+    if (ps.ksk_padded && !(g_ks_wg_threshold > 0 && (long)count <= g_ks_wg_threshold)) {
         if constexpr (ps_ks_is_default_shape<PS>) {
-            if (int rc = launch_keyswitch_shared(s, st, d, count, ps.ksk_padded)) return rc;
+            if (int rc = launch_keyswitch_shared<KsShapeDefault>(s, st, d, count, ps.ksk_padded, &s.ks_lds_opt_in)) return rc;
         } else {
-            if (!ps.ks_lds_opt_in) {
-                HIP_TRY(hipFuncSetAttribute((const void*)keyswitch_ps_shared_kernel<PS>, hipFuncAttributeMaxDynamicSharedMemorySize, PsKs<PS>::lds_bytes));
-                ps.ks_lds_opt_in = true;
-            }
-            hipLaunchKernelGGL(keyswitch_ps_shared_kernel<PS>, dim3(blocks), dim3(kKsThreads), PsKs<PS>::lds_bytes, st, d, (int)count, ps.ksk_padded);
+            if (int rc = launch_keyswitch_shared<KsShapePs<PS>>(s, st, d, count, ps.ksk_padded, &ps.ks_lds_opt_in)) return rc;
         }
         HIP_TRY(hipGetLastError());
         return prof_end(s, st, ev, count, true);

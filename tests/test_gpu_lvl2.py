@@ -82,9 +82,9 @@ def test_keyswitch_words(engine2, keys2):
 
 @pytest.mark.parametrize("count", [129, 203])
 def test_keyswitch_words_shared_table_kernel(engine2, keys2, count):
-    """keyswitch_lvl2_shared_kernel (16 ciphertexts per workgroup, table rows through LDS; the default above 1400
-    ciphertexts per launch, forced here); 129 and 203 leave a ragged last workgroup.  Same words as the oracle and as
-    the workgroup-per-ciphertext kernel."""
+    """keyswitch_kernel over the lvl20 shape (16 ciphertexts per workgroup, table rows through LDS, the 2048 steps of j in at least
+    two runs; the default at any count) in three shapes; 129 and 203 leave a ragged last workgroup.  Same words as the oracle
+    and as the workgroup-per-ciphertext kernel."""
     rng = np.random.default_rng(count)
     t2 = rng.integers(0, 2**64, size=(count, ol.LVL2_WORDS), dtype=np.uint64)
     t2[0] = 0
@@ -102,8 +102,16 @@ def test_keyswitch_words_shared_table_kernel(engine2, keys2, count):
         engine2.api.set_option("ks_wg_threshold", 1 << 20)
         engine2.lvl2_keyswitch_batch(d2, d0, count)
         assert np.array_equal(d0.download().reshape(count, ol.n + 1), got)
+        engine2.api.set_option("ks_wg_threshold", 0)
+        for per, slices in ((16, 2), (5, 8), (16, 64)):      # (ciphertexts per workgroup, runs of j)
+            engine2.api.set_option("ks_per_wg", per)
+            engine2.api.set_option("ks_slices", slices)
+            d0.upload(np.full(count * (ol.n + 1), 0xDEADBEEF, np.uint32))
+            engine2.lvl2_keyswitch_batch(d2, d0, count)
+            assert np.array_equal(d0.download().reshape(count, ol.n + 1), got), f"{per} per workgroup, {slices} runs"
     finally:
-        engine2.api.set_option("ks_wg_threshold", -1)
+        for k in ("ks_wg_threshold", "ks_per_wg", "ks_slices"):
+            engine2.api.set_option(k, -1)
 
 
 def test_every_gate_words_and_truth(engine2, keys, keys2, oracle):

@@ -94,16 +94,21 @@ def test_keyswitch_words(engine, pset):
     t1[0] = 0
     t1[1] = 0xFFFFFFFF
     d0 = engine.api.DeviceBuffer(count * K.words[0])
-    for thr in (-1, 0):       # 0: sets with the default key-switch shape take the shared-table kernel of kernels.hip.h
+    # -1: keyswitch_kernel over the set's shape, launch shape by the rule; 1 << 20: a workgroup per ciphertext; then forced shapes
+    # (ciphertexts per workgroup, runs of j)
+    for thr, per, slices in ((-1, -1, -1), (1 << 20, -1, -1), (0, 16, 1), (0, 7, 4), (0, 16, 64)):
         engine.api.set_option("ks_wg_threshold", thr)
+        engine.api.set_option("ks_per_wg", per)
+        engine.api.set_option("ks_slices", slices)
         try:
-            d0.upload(np.zeros(count * K.words[0], np.uint32))
+            d0.upload(np.full(count * K.words[0], 0xDEADBEEF, np.uint32))
             engine.api.ps_keyswitch_batch(idx, _up(engine, t1), d0, count)
         finally:
-            engine.api.set_option("ks_wg_threshold", -1)
+            for k in ("ks_wg_threshold", "ks_per_wg", "ks_slices"):
+                engine.api.set_option(k, -1)
         got = d0.download().reshape(count, -1)
         for g in range(count):
-            assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g} (ks_wg_threshold {thr})"
+            assert np.array_equal(got[g], K.keyswitch(t1[g])), f"{name}: key switch {g} (ks_wg_threshold {thr}, {per} per workgroup, {slices} runs)"
 
 
 @pytest.mark.parametrize("level", [0, 1])

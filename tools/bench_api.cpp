@@ -22,7 +22,7 @@ int main(int argc, char** argv)
     // key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
     // reps=R timed repetitions (the first is a warm-up), netlist=0 skips the adder netlist, identify=1 refuses to run when
     // the G logical devices are fewer than G distinct physical GPUs (unless share_devices=1 asked for exactly that)
-    int gpus = 1, reps = 4, netlist = 1, identify = 0;
+    int gpus = 1, reps = 8, netlist = 1, identify = 0;
     long share = 0;
     for (int i = 2; i < argc; i++) {
         std::string kv(argv[i]);
@@ -161,7 +161,7 @@ int main(int argc, char** argv)
             for (auto& w : c.tlwehost) w = eng();
         double best = 1e30;
         cufhe_amd_sched_stats ns{};
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < 3; rep++) {
             all_stats(ns, 1);
             auto t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < kAdders; i++) {
@@ -203,7 +203,7 @@ int main(int argc, char** argv)
             for (auto& w : carry[(size_t)i * (kBits + 1)].tlwehost) w = eng();
         double best = 1e30;
         cufhe_amd_sched_stats ns{};
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < 3; rep++) {
             all_stats(ns, 1);
             auto t0 = std::chrono::steady_clock::now();
             for (int i = 0; i < kAdders; i++) {

@@ -38,8 +38,9 @@ KERNELS = {
     "blind_rotate_ps_batch_kernel<cggi16>": ("blind_rotate_ps_batch_kernel<cufhe_amd::PsCggi16", (), 8, 8, 2, 500),
     # units per workgroup: 16 for the launches of 4096 ciphertexts (capi.hip: ks_auto_shape); the smaller launches of the profiled
     # command fill the same grid with runs of j and are left out by their duration (main() below)
-    "keyswitch_kernel": ("keyswitch_kernel", ("lvl2", "ps_", "wg_", "split"), 16, 16, 4, None),
-    "keyswitch_lvl2_shared_kernel": ("keyswitch_lvl2_shared_kernel", (), 16, 16, 4, None),
+    "keyswitch_kernel": ("keyswitch_kernel<cufhe_amd::KsShapeDefault", (), 16, 16, 4, None),
+    # the lvl20 shape always cuts j into at least two runs: 4096 ciphertexts are 512 workgroups of 16
+    "keyswitch_kernel<lvl2>": ("keyswitch_kernel<cufhe_amd::KsShapeLvl2", (), 8, 16, 4, None),      # 16 ciphertexts per TWO workgroups
 }
 
 
@@ -93,7 +94,7 @@ def main():
         if rows:
             gmax = max(r[0] for r in rows)
             durs = sorted(r[3] for r in rows if r[0] == gmax)
-            if k == "keyswitch_kernel":
+            if k.startswith("keyswitch_kernel"):
                 durs = [x for x in durs if x >= 0.85 * durs[-1]]
             if durs[-1] > 1.25 * durs[0]:
                 print(f"WARNING {k}: launches of the largest grid differ in duration ({durs[0] * 1e-6:.2f} .. {durs[-1] * 1e-6:.2f} ms): "
@@ -107,7 +108,7 @@ def main():
             rows = [r for r in rows if r[0] == gmax]
             # keyswitch_kernel fills one grid round at every launch size (fewer ciphertexts per workgroup, or fewer steps of j per
             # workgroup): the launches of 4096 ciphertexts -- 16 per workgroup, all 1024 steps -- are the slowest of that grid
-            if k == "keyswitch_kernel":
+            if k.startswith("keyswitch_kernel"):
                 dmax = max(r[3] for r in rows)
                 rows = [r for r in rows if r[3] >= 0.85 * dmax]
             return sum(r[2] for r in rows) / len(rows), gmax // rows[0][1], sum(r[3] for r in rows) / len(rows)
