@@ -692,6 +692,11 @@ class DeviceSched {
     int resolve_host(cufhe_amd_ctxt* c, bool* need_upload, void* stream);
     void record_upload(cufhe_amd_ctxt* c, void* stream);
     int after_record();
+    bool two_lane_available()       // could a flush of several levels be compiled into a per-gate plan? (the gates of compile_two_lane)
+    {
+        Backend::LaneModel m;
+        return two_lane && rename_outputs && nstreams_ >= 2 && be_->lane_model(&m) && m.chain_gates != 0 && m.bulk_gates != 0;
+    }
     int launch(Group* g);                       // worker (or inline): submit the group's work
     // one launch of a per-gate scheduled flush: lane 0 = chain, 1 = bulk; wait_other = the newest launch of the OTHER lane that
     // produces one of its operands (-1: none; launches of one lane run in order on one stream)
@@ -1250,11 +1255,14 @@ inline int DeviceSched::after_record()
     // adders whose independent gates fill the front level) launching it would move the front, and the chains recorded
     // afterwards would sit one level later than their siblings: every chain level would then be a mix of all bit
     // positions and cost a started round more (measured: 310 ms against 251 for 256 sixteen-bit adders).  Such a front
-    // level waits for the caller's Synchronize, up to eight rounds.
+    // level waits for the caller's Synchronize, up to eight rounds -- unless what follows can be scheduled gate by gate
+    // (compile_two_lane: levels then do not matter): the idle device takes the first round of the front level at once and the
+    // recording of the rest (0.33 us per gate: 6.8 ms for 20 480) and its plan overlap that launch.
     if (!levels_.empty()) {
         const size_t front = levels_.front()->gate_count();
         // (the idle check polls events: only once per workgroup-per-CU's worth of gates)
-        if (front >= idle_flush_gates && front < level_flush_gates && (front - idle_flush_gates) % std::max<size_t>(1, round_gates_ / 8) == 0 && levels_.size() == 1 && device_idle())
+        if (front >= idle_flush_gates && front < level_flush_gates && (front - idle_flush_gates) % std::max<size_t>(1, round_gates_ / 8) == 0 &&
+            (levels_.size() == 1 || two_lane_available()) && device_idle())
             return flush(1);
         if (front >= level_flush_gates &&
             (levels_.size() == 1 || 2 * levels_[1]->gate_count() >= level_flush_gates || front >= 8 * level_flush_gates))
