@@ -1,6 +1,8 @@
 // bench_api.cpp -- PCIe-inclusive rate of the reference-style per-gate API (not the headline metric).
 // 4096 cufhe::Nand(out, a, b, st) calls on host-resident ciphertexts over 256 streams, then
 // Synchronize(): what test/test_util.h:29-72 times in the reference ("Throughput: ms/gate").
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -22,7 +24,7 @@ int main(int argc, char** argv)
     // key=value (cufhe_amd_set_option), e.g. sched_level_gates=4096
     // reps=R timed repetitions (the first is a warm-up), netlist=0 skips the adder netlist, identify=1 refuses to run when
     // the G logical devices are fewer than G distinct physical GPUs (unless share_devices=1 asked for exactly that)
-    int gpus = 1, reps = 8, netlist = 1, identify = 0;
+    int gpus = 1, reps = 8, netlist = 1, identify = 0, pin = 0;
     long share = 0;
     for (int i = 2; i < argc; i++) {
         std::string kv(argv[i]);
@@ -33,6 +35,7 @@ int main(int argc, char** argv)
         if (key == "reps") { reps = std::max(2, atoi(kv.c_str() + eq + 1)); continue; }
         if (key == "netlist") { netlist = atoi(kv.c_str() + eq + 1); continue; }
         if (key == "identify") { identify = atoi(kv.c_str() + eq + 1); continue; }
+        if (key == "pin") { pin = atoi(kv.c_str() + eq + 1); continue; }
         if (key == "share_devices") share = atol(kv.c_str() + eq + 1);
         CUFHE_AMD_CHECK(cufhe_amd_set_option(key.c_str(), atol(kv.c_str() + eq + 1)));
     }
@@ -59,6 +62,27 @@ int main(int argc, char** argv)
     if (identify && (int)distinct.size() < gpus && !share) {
         std::fprintf(stderr, "bench_api: %d logical devices on %zu distinct GPU(s); pass share_devices=1 to rehearse on this box\n", gpus, distinct.size());
         return 3;
+    }
+    // pin=1 (one GPU): the issuing thread (and the ciphertexts it allocates) on the CPUs close to the GPU, as an application placed with
+    // numactl would be -- the identity string names them (local_cpus=0-63,128-191).  Default off: measured on a two-socket EPYC 9575F
+    // box it makes no difference to the best repetition (38.2-38.4 ms pinned, 37.9-38.4 left to the OS; the launch worker and its
+    // copy helpers are pinned by the library either way).
+    int pinned_cpus = 0;
+    if (gpus == 1 && pin) {
+        const size_t at = ident[0].find("local_cpus=");
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (at != std::string::npos) {
+            const char* q = ident[0].c_str() + at + 11;
+            while (*q >= '0' && *q <= '9') {
+                char* e;
+                long lo = strtol(q, &e, 10), hi = lo;
+                if (*e == '-') hi = strtol(e + 1, &e, 10);
+                for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &set); pinned_cpus++; }
+                q = *e == ',' ? e + 1 : e;
+            }
+        }
+        if (pinned_cpus == 0 || sched_setaffinity(0, sizeof set, &set) != 0) pinned_cpus = 0;
     }
     Initialize(bk.data(), bk.size(), ksk.data(), ksk.size());
     std::vector<Ctxt<P>> a(kNumTests), b(kNumTests), o(kNumTests);
@@ -113,7 +137,7 @@ int main(int argc, char** argv)
         std::printf("%s{\"device\": %d, \"gpu\": \"%s\", \"gates\": %llu, \"launch_sequences\": %llu, \"worker_launch_ms\": %.3f, "
                     "\"worker_pinned_cpus\": %llu}", dev ? ", " : "", dev, ident[dev].c_str(), (unsigned long long)per_dev[dev].gates,
                     (unsigned long long)per_dev[dev].launch_sequences, per_dev[dev].launch_ns * 1e-6, (unsigned long long)per_dev[dev].worker_cpus);
-    std::printf("]");
+    std::printf("], \"issuing_thread_pinned_cpus\": %d", pinned_cpus);
     {
         // one more repetition with HIP timing events on (cufhe_amd_profile_enable) for the timeline of the run: where the
         // milliseconds between the first Nand() and the return of Synchronize() go, flush by flush (device 0)
